@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+metric : SNPs x samples / sec through the randomized PCA (gpca_rsvd) at k = 20  (l = 30, q = 2)
+step   : one gpca_rsvd over the resident int8 genotype matrix (sketch + 2 power iterations + projection +
+         small SVD + scores + loadings = 4 passes over G, 12*l flop per genotype -- SURVEY.md 8d)
+N = 1  : configs[1] = synthetic 1M SNPs x 10k samples int8, k = 20, fixed seed, resident in HBM
+N > 1  : SNP-row shards, one rank per GPU (torch.distributed.run), weak scaling: every rank holds
+         --snps rows; the N x l sketch is all-reduced with RCCL inside libgpca.so (f64).
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel, from HIP events recorded on the engine's
+own stream inside the timed region; `cpu_baseline` is the oracle's f32 restatement ("port") timed on this
+box's host cores on a bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def cpu_baseline(N, k, oversample, q, seed, target_s=15.0):
+    """Oracle restatement (REAL=float, OpenMP) timed on a bounded sample of the same workload."""
+    from oracle import oracle as O   # cpu_baseline leg only
+    import genomic_pca_amd as g
+    threads = O.num_threads("f32")
+
+    def run(Ms):
+        th = g.synth_thresholds(Ms, 3, seed=seed)
+        G = O.synth_genotypes(Ms, N, seed, th)
+        st = O.snp_stats(G, N, 0.0, 0.0, 1.0)
+        r, b = O.scale_shift(st["mu"], st["sigma"], st["keep"])
+        t0 = time.perf_counter()
+        O.rsvd(G, N, r, b, k, oversample, q, seed=seed, real="f32")
+        return time.perf_counter() - t0
+    Ms = 4000
+    t = run(Ms)
+    rate = Ms * N / t
+    Ms2 = int(min(max(rate * target_s / N, Ms), 400000))
+    if Ms2 > 2 * Ms:
+        t = run(Ms2); Ms = Ms2
+    return {"value": Ms * N / t, "unit": "SNPs*samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/gpca_oracle.c REAL=float, {Ms} SNPs x {N} samples, k={k}, l={k + oversample}, q={q}, "
+                      f"{t:.1f} s on {threads} OpenMP threads (CPU restatement, not the Rust/faer binary)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--snps", type=int, default=1_000_000, help="SNP rows per GPU")
+    ap.add_argument("--samples", type=int, default=10_000)
+    ap.add_argument("--components", "-k", type=int, default=20)
+    ap.add_argument("--oversample", type=int, default=10)
+    ap.add_argument("--power-iters", type=int, default=2)
+    ap.add_argument("--rfit-seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "i8"])
+    a = ap.parse_args()
+
+    import torch
+    import genomic_pca_amd as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    M_local, N, k = a.snps, a.samples, a.components
+    l = k + a.oversample
+    M_total = M_local * world
+    snp_offset = rank * M_local
+    prec = g._lib.PREC_F32_MFMA if a.precision == "f32" else g._lib.PREC_I8_EXACT
+    eng = g.GpcaEngine(device=local_rank, precision=prec)
+    th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
+    eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
+    del th
+    t0 = time.perf_counter()
+    eng.snp_stats(g.QcConfig.none(), fetch=False)
+    t_stats = time.perf_counter() - t0
+    if world > 1:
+        uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
+        eng.comm_init(world, rank, uid, snp_offset)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+    eng.reset_timings()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    timings = eng.timings()
+    ev = eng.eigenvalues()
+
+    if rank == 0:
+        per_step = dt / a.steps
+        value = M_total * N / per_step
+        gq, gt = timings.get("gemm_GQ"), timings.get("gemm_GtT")
+        dom_name, dom = max((("gemm_GQ", gq), ("gemm_GtT", gt)), key=lambda kv: kv[1]["total_ms"] if kv[1] else 0.0)
+        avg_ms = dom["total_ms"] / dom["launches"]
+        tflops = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                    "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+                    "hbm_GBs_algorithmic": dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9,
+                    "all_kernels_ms_per_step": {n: t["total_ms"] / a.steps for n, t in timings.items()}}
+        out = {
+            "metric": "SNPs x samples / sec through rSVD at k=20", "value": value, "unit": "SNPs*samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.precision == "f32" else "i8", "data": "synthetic",
+            "config": {"workload": f"synthetic {M_total} SNPs x {N} samples int8 genotypes (3 populations, F_ST 0.05), "
+                                   f"k={k}, l={l}, q={a.power_iters}, seed={a.rfit_seed}, resident in HBM",
+                       "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample,
+                       "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}"},
+            "roofline": roofline,
+            "snp_stats_s": t_stats,
+            "top_eigenvalues": [float(x) for x in ev[:3]],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, k, a.oversample, a.power_iters, a.rfit_seed)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

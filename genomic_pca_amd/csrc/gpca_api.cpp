@@ -1,0 +1,808 @@
+// C ABI + host driver of the randomized-PCA engine (declared in include/gpca.h).
+//
+// The driver keeps genotypes, basis, sketches and results in HBM behind the opaque handle and only
+// moves l x l (<= 64 x 64) f64 blocks to the host for Cholesky / Jacobi.  Per randomized-PCA call:
+//   sketch Y = A^T Omega, orth;  q x { T = A Q, Y = A^T T, orth };  B = A Q;  eig(B^T B)
+// = 4 passes over the int8 matrix, 12*l flop per genotype.
+#include "../../include/gpca.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace gpca;
+
+// ---- minimal RCCL surface, resolved with dlopen so that libgpca.so loads on hosts without a GPU ----
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId_t;
+typedef int (*pfn_ncclGetUniqueId)(ncclUniqueId_t*);
+typedef int (*pfn_ncclCommInitRank)(ncclComm_t*, int, ncclUniqueId_t, int);
+typedef int (*pfn_ncclAllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*pfn_ncclCommDestroy)(ncclComm_t);
+typedef const char* (*pfn_ncclGetErrorString)(int);
+static struct RcclApi {
+    void* lib = nullptr;
+    pfn_ncclGetUniqueId GetUniqueId = nullptr;
+    pfn_ncclCommInitRank CommInitRank = nullptr;
+    pfn_ncclAllReduce AllReduce = nullptr;
+    pfn_ncclCommDestroy CommDestroy = nullptr;
+    pfn_ncclGetErrorString GetErrorString = nullptr;
+    bool load() {
+        if (lib) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        GetUniqueId = (pfn_ncclGetUniqueId)dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (pfn_ncclCommInitRank)dlsym(lib, "ncclCommInitRank");
+        AllReduce = (pfn_ncclAllReduce)dlsym(lib, "ncclAllReduce");
+        CommDestroy = (pfn_ncclCommDestroy)dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (pfn_ncclGetErrorString)dlsym(lib, "ncclGetErrorString");
+        return GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+    }
+} g_rccl;
+enum { kNcclFloat64 = 8, kNcclSum = 0 };  // ncclDataType_t / ncclRedOp_t values (rccl.h)
+
+struct TimingRec { std::string name; hipEvent_t a, b; double flops, bytes; };
+
+struct gpca_handle {
+    int device = 0;
+    int precision = GPCA_PREC_F32_MFMA;
+    hipStream_t st = nullptr;
+    std::string err;
+
+    // genotypes
+    int64_t M = 0, N = 0, ldg = 0;
+    int8_t* dG = nullptr;
+
+    // stats
+    bool have_stats = false;
+    float *d_mu = nullptr, *d_sigma = nullptr, *d_r = nullptr, *d_b = nullptr;
+    uint8_t *d_keep = nullptr, *d_reason = nullptr;
+    uint32_t *d_counts = nullptr, *d_flags = nullptr;
+    int64_t n_pca = 0;
+    std::vector<int64_t> pca_rows;
+    int64_t* d_pca_rows = nullptr;
+    uint32_t flags = 0;
+
+    // rsvd workspace / results
+    int k = 0, l = 0, L = 0;
+    bool have_rsvd = false;
+    float *dQ = nullptr, *dT = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
+    double *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
+    double* d_scores64 = nullptr; float* d_scores32 = nullptr; float* d_load32 = nullptr; int* d_sign = nullptr;
+    size_t cap_Q = 0, cap_T = 0, cap_Ypart = 0, cap_cpart = 0, cap_Y = 0, cap_part64 = 0, cap_scores = 0, cap_load = 0;
+    std::vector<double> eig, sv;
+    GttPlan plan{};
+
+    // comm
+    int world = 1, rank = 0;
+    int64_t snp_offset = 0;
+    ncclComm_t comm = nullptr;
+    gpca_allreduce_fn hook = nullptr;
+    void* hook_user = nullptr;
+    std::vector<double> hook_buf;
+
+    // timings
+    bool timing_on = true;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static thread_local std::string g_last_global_err;
+
+static int fail(gpca_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_last_global_err = msg;
+    return code;
+}
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            char buf_[512];                                                                            \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return fail(h, e_ == hipErrorOutOfMemory ? GPCA_ERR_OOM : GPCA_ERR_HIP, buf_);             \
+        }                                                                                              \
+    } while (0)
+#define CHK(x) do { int rc_ = (x); if (rc_ != GPCA_OK) return rc_; } while (0)
+
+template <typename T>
+static int ensure(gpca_handle* h, T*& p, size_t& cap, size_t need_elems) {
+    if (cap >= need_elems && p) return GPCA_OK;
+    if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+    HIPCHK(hipMalloc((void**)&p, need_elems * sizeof(T)));
+    cap = need_elems;
+    return GPCA_OK;
+}
+template <typename T>
+static void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- timing ---------------------------------------------------------------------------------------
+struct ScopedTimer {
+    gpca_handle* h; bool on; size_t idx = 0;
+    ScopedTimer(gpca_handle* h_, const char* name, double flops, double bytes) : h(h_), on(h_->timing_on) {
+        if (!on) return;
+        TimingRec r; r.name = name; r.flops = flops; r.bytes = bytes; r.a = r.b = nullptr;
+        for (hipEvent_t* e : {&r.a, &r.b}) {
+            if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
+        }
+        (void)hipEventRecord(r.a, h->st);
+        h->recs.push_back(r); idx = h->recs.size() - 1;
+    }
+    ~ScopedTimer() { if (on) (void)hipEventRecord(h->recs[idx].b, h->st); }
+};
+
+// ---- lifecycle --------------------------------------------------------------------------------------
+extern "C" int gpca_version(void) { return GPCA_VERSION; }
+
+extern "C" const char* gpca_status_string(int s) {
+    switch (s) {
+        case GPCA_OK: return "ok";
+        case GPCA_ERR_BAD_ARG: return "bad argument";
+        case GPCA_ERR_OOM: return "out of device memory";
+        case GPCA_ERR_HIP: return "HIP runtime error";
+        case GPCA_ERR_RCCL: return "RCCL error";
+        case GPCA_ERR_MISSING_GENOTYPE: return "missing genotype in a PCA SNP";
+        case GPCA_ERR_NOT_CONVERGED: return "sketch lost rank";
+        case GPCA_ERR_STATE: return "call out of order";
+        case GPCA_ERR_NO_DEVICE: return "no HIP device";
+        case GPCA_ERR_INVALID_GENOTYPE: return "genotype outside {0,1,2} in a PCA SNP";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* gpca_last_error(gpca_handle* h) { return h ? h->err.c_str() : g_last_global_err.c_str(); }
+
+extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
+    if (!out) return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, GPCA_ERR_NO_DEVICE, "gpca_create: no HIP device visible (this engine has no CPU fallback)");
+    gpca_handle* h = new gpca_handle();
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: device ordinal out of range"); }
+    h->device = dev;
+    h->precision = cfg ? cfg->precision : GPCA_PREC_F32_MFMA;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
+        delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            // kernels are compiled for gfx950 only; any other device cannot run them
+            std::string m = std::string("gpca_create: device is ") + prop.gcnArchName + ", this library only carries gfx950 code";
+            (void)hipStreamDestroy(h->st); delete h; return fail(nullptr, GPCA_ERR_NO_DEVICE, m);
+        }
+    }
+    *out = h;
+    return GPCA_OK;
+}
+
+static void free_stats(gpca_handle* h) {
+    dfree(h->d_mu); dfree(h->d_sigma); dfree(h->d_r); dfree(h->d_b); dfree(h->d_keep); dfree(h->d_reason);
+    dfree(h->d_counts); dfree(h->d_flags); dfree(h->d_pca_rows);
+    h->have_stats = false; h->n_pca = 0; h->pca_rows.clear();
+}
+static void free_ws(gpca_handle* h) {
+    dfree(h->dQ); dfree(h->dT); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
+    dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
+    dfree(h->d_load32); dfree(h->d_sign);
+    h->cap_Q = h->cap_T = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
+    h->have_rsvd = false;
+}
+
+extern "C" int gpca_destroy(gpca_handle* h) {
+    if (!h) return GPCA_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->st);
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    free_stats(h); free_ws(h); dfree(h->dG);
+    (void)hipStreamDestroy(h->st);
+    delete h;
+    return GPCA_OK;
+}
+
+extern "C" int gpca_synchronize(gpca_handle* h) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(h->st));
+    return GPCA_OK;
+}
+
+// ---- genotype residency -------------------------------------------------------------------------------
+static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return fail(h, GPCA_ERR_BAD_ARG, "genotype matrix must have M > 0 SNPs and N > 0 samples");
+    HIPCHK(hipSetDevice(h->device));
+    free_stats(h); free_ws(h); dfree(h->dG);
+    h->M = M; h->N = N; h->ldg = round_up(N, kSamplePad);
+    HIPCHK(hipMalloc((void**)&h->dG, (size_t)M * (size_t)h->ldg));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_upload_genotypes_i8(gpca_handle* h, const int8_t* src, int64_t M, int64_t N, int64_t ld) {
+    if (!h || !src || ld < N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_upload_genotypes_i8: bad arguments");
+    CHK(alloc_genotypes(h, M, N));
+    if (h->ldg != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ldg, h->st));
+    HIPCHK(hipMemcpy2DAsync(h->dG, (size_t)h->ldg, src, (size_t)ld, (size_t)N, (size_t)M, hipMemcpyHostToDevice, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_upload_bed2bit(gpca_handle* h, const uint8_t* bed_rows, int64_t M, int64_t N) {
+    if (!h || !bed_rows) return fail(h, GPCA_ERR_BAD_ARG, "gpca_upload_bed2bit: bad arguments");
+    CHK(alloc_genotypes(h, M, N));
+    const int64_t bpr = (N + 3) / 4;
+    uint8_t* d_bed = nullptr;
+    HIPCHK(hipMalloc((void**)&d_bed, (size_t)M * (size_t)bpr));
+    hipError_t e = hipMemcpyAsync(d_bed, bed_rows, (size_t)M * (size_t)bpr, hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) { launch_bed_decode(h->st, d_bed, bpr, h->dG, M, N, h->ldg); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    (void)hipFree(d_bed);
+    HIPCHK(e);
+    return GPCA_OK;
+}
+
+extern "C" int gpca_synth_genotypes(gpca_handle* h, int64_t M, int64_t N, uint64_t seed, const uint32_t* thresh,
+                                    int32_t P, int64_t snp_offset) {
+    if (!h || !thresh || P <= 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_synth_genotypes: bad arguments");
+    CHK(alloc_genotypes(h, M, N));
+    uint32_t* d_th = nullptr;
+    HIPCHK(hipMalloc((void**)&d_th, (size_t)M * P * sizeof(uint32_t)));
+    hipError_t e = hipMemcpyAsync(d_th, thresh, (size_t)M * P * sizeof(uint32_t), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) { launch_synth(h->st, h->dG, M, N, h->ldg, snp_offset, seed, d_th, P); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    (void)hipFree(d_th);
+    HIPCHK(e);
+    return GPCA_OK;
+}
+
+extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t ld) {
+    if (!h || !out || !h->dG || ld < h->N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_download_genotypes_i8: bad arguments / nothing resident");
+    HIPCHK(hipMemcpy2D(out, (size_t)ld, h->dG, (size_t)h->ldg, (size_t)h->N, (size_t)h->M, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    if (M) *M = h->M;
+    if (N) *N = h->N;
+    return GPCA_OK;
+}
+
+// ---- a1 ---------------------------------------------------------------------------------------------------
+static int alloc_stats(gpca_handle* h) {
+    const size_t M = (size_t)h->M;
+    if (h->d_mu) return GPCA_OK;
+    HIPCHK(hipMalloc((void**)&h->d_mu, M * 4)); HIPCHK(hipMalloc((void**)&h->d_sigma, M * 4));
+    HIPCHK(hipMalloc((void**)&h->d_r, M * 4)); HIPCHK(hipMalloc((void**)&h->d_b, M * 4));
+    HIPCHK(hipMalloc((void**)&h->d_keep, M)); HIPCHK(hipMalloc((void**)&h->d_reason, M));
+    HIPCHK(hipMalloc((void**)&h->d_counts, M * 16)); HIPCHK(hipMalloc((void**)&h->d_flags, 16));
+    HIPCHK(hipMemset(h->d_counts, 0, M * 16));
+    return GPCA_OK;
+}
+
+static int refresh_pca_rows(gpca_handle* h) {
+    std::vector<uint8_t> keep((size_t)h->M);
+    HIPCHK(hipMemcpy(keep.data(), h->d_keep, (size_t)h->M, hipMemcpyDeviceToHost));
+    h->pca_rows.clear();
+    for (int64_t i = 0; i < h->M; ++i) if (keep[(size_t)i]) h->pca_rows.push_back(i);
+    h->n_pca = (int64_t)h->pca_rows.size();
+    dfree(h->d_pca_rows);
+    if (h->n_pca) {
+        HIPCHK(hipMalloc((void**)&h->d_pca_rows, (size_t)h->n_pca * 8));
+        HIPCHK(hipMemcpy(h->d_pca_rows, h->pca_rows.data(), (size_t)h->n_pca * 8, hipMemcpyHostToDevice));
+    }
+    return GPCA_OK;
+}
+
+extern "C" int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* mu, float* sigma, uint8_t* keep) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    if (!h->dG) return fail(h, GPCA_ERR_STATE, "gpca_snp_stats: no genotypes resident");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(alloc_stats(h));
+    QcParams q{0.0, 0.0, 1.0};
+    if (qc) { q.min_call_rate = qc->min_snp_call_rate; q.min_maf = qc->min_snp_maf; q.max_hwe_p = qc->max_snp_hwe_p_value; }
+    HIPCHK(hipMemsetAsync(h->d_flags, 0, 16, h->st));
+    {
+        ScopedTimer t(h, "snp_stats", 0.0, (double)h->M * (double)h->N);
+        launch_snp_stats(h->st, h->dG, h->M, h->N, h->ldg, q, h->d_mu, h->d_sigma, h->d_r, h->d_b, h->d_keep, h->d_reason,
+                         h->d_counts, h->d_flags);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&h->flags, h->d_flags, 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    CHK(refresh_pca_rows(h));
+    h->have_stats = true; h->have_rsvd = false;
+    if (mu) HIPCHK(hipMemcpy(mu, h->d_mu, (size_t)h->M * 4, hipMemcpyDeviceToHost));
+    if (sigma) HIPCHK(hipMemcpy(sigma, h->d_sigma, (size_t)h->M * 4, hipMemcpyDeviceToHost));
+    if (keep) HIPCHK(hipMemcpy(keep, h->d_keep, (size_t)h->M, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_get_snp_qc_detail(gpca_handle* h, uint32_t* counts, uint8_t* reason) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_get_snp_qc_detail: run gpca_snp_stats first");
+    if (counts) HIPCHK(hipMemcpy(counts, h->d_counts, (size_t)h->M * 16, hipMemcpyDeviceToHost));
+    if (reason) HIPCHK(hipMemcpy(reason, h->d_reason, (size_t)h->M, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_set_standardization(gpca_handle* h, const float* mu, const float* sigma, const uint8_t* keep) {
+    if (!h || !mu || !sigma) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_standardization: mu and sigma are required");
+    if (!h->dG) return fail(h, GPCA_ERR_STATE, "gpca_set_standardization: no genotypes resident");
+    HIPCHK(hipSetDevice(h->device));
+    // a stats pass supplies the missing/invalid flags for the rows the caller keeps
+    if (!h->have_stats) { gpca_qc_config none{0.0, 0.0, 1.0}; CHK(gpca_snp_stats(h, &none, nullptr, nullptr, nullptr)); }
+    const size_t M = (size_t)h->M;
+    HIPCHK(hipMemcpy(h->d_mu, mu, M * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_sigma, sigma, M * 4, hipMemcpyHostToDevice));
+    if (keep) HIPCHK(hipMemcpy(h->d_keep, keep, M, hipMemcpyHostToDevice));
+    else HIPCHK(hipMemset(h->d_keep, 1, M));
+    launch_set_scale(h->st, h->M, h->d_mu, h->d_sigma, h->d_keep, h->d_r, h->d_b);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->st));
+    CHK(refresh_pca_rows(h));
+    // recompute flags for the caller's keep set from the counts of the stats pass
+    std::vector<uint32_t> counts(M * 4);
+    HIPCHK(hipMemcpy(counts.data(), h->d_counts, M * 16, hipMemcpyDeviceToHost));
+    h->flags = 0;
+    for (int64_t i : h->pca_rows) {
+        const uint32_t* c = &counts[(size_t)i * 4];
+        if ((int64_t)c[0] != h->N) h->flags |= 1u;
+        if ((uint64_t)c[1] + c[2] + c[3] != c[0]) h->flags |= 2u;
+    }
+    h->have_rsvd = false;
+    return GPCA_OK;
+}
+
+extern "C" double gpca_hwe_chi_squared_p_value(uint64_t n1h, uint64_t nhet, uint64_t n2h) {
+    // same branches as prepare.rs:1641-1745 (host restatement; device copy: kernels.hip hwe_p_dev)
+    const uint64_t tot = n1h + nhet + n2h;
+    if (tot == 0) return 1.0;
+    const double c1 = 2.0 * (double)n1h + (double)nhet, c2 = 2.0 * (double)n2h + (double)nhet;
+    const double ta = c1 + c2;
+    if (ta <= 1e-9) return 1.0;
+    const double f1 = c1 / ta, f2 = c2 / ta;
+    if (f1 < 1e-9 || f2 < 1e-9) return 1.0;
+    if (std::fabs(f1 + f2 - 1.0) > 1e-6) return 1.0;
+    const double e1 = f1 * f1 * (double)tot, eh = 2.0 * f1 * f2 * (double)tot, e2 = f2 * f2 * (double)tot;
+    double chi = 0.0;
+    const double MINE = 1e-9;
+    if (e1 > MINE) { double d = (double)n1h - e1; chi += d * d / e1; } else if ((double)n1h > MINE) chi = INFINITY;
+    if (std::isfinite(chi)) { if (eh > MINE) { double d = (double)nhet - eh; chi += d * d / eh; } else if ((double)nhet > MINE) chi = INFINITY; }
+    if (std::isfinite(chi)) { if (e2 > MINE) { double d = (double)n2h - e2; chi += d * d / e2; } else if ((double)n2h > MINE) chi = INFINITY; }
+    if (std::isnan(chi)) return 1.0;
+    if (chi == INFINITY) return 0.0;
+    const double cdf = std::erf(std::sqrt(chi * 0.5));
+    if (std::isnan(cdf)) return 1.0;
+    const double p = 1.0 - cdf;
+    return p > 0.0 ? p : 0.0;
+}
+
+// ---- a2 ---------------------------------------------------------------------------------------------------
+extern "C" int64_t gpca_num_pca_snps(gpca_handle* h) { return (h && h->have_stats) ? h->n_pca : 0; }
+extern "C" int64_t gpca_num_qc_samples(gpca_handle* h) { return h ? h->N : 0; }
+extern "C" int gpca_get_pca_snp_rows(gpca_handle* h, int64_t* rows) {
+    if (!h || !rows) return GPCA_ERR_BAD_ARG;
+    if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_get_pca_snp_rows: run gpca_snp_stats first");
+    std::copy(h->pca_rows.begin(), h->pca_rows.end(), rows);
+    return GPCA_OK;
+}
+
+extern "C" int gpca_standardize_block(gpca_handle* h, const int64_t* snp_ids, int64_t ns, const int64_t* sample_ids,
+                                      int64_t nj, float* out) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_standardize_block: run gpca_snp_stats first");
+    if (ns < 0 || nj < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: negative block size");
+    if (ns == 0 || nj == 0) return GPCA_OK;  // prepare.rs:1848-1850: empty block, nothing to fill
+    if (!snp_ids || !sample_ids || !out) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: NULL pointer");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int64_t> rows((size_t)ns);
+    for (int64_t a = 0; a < ns; ++a) {
+        if (snp_ids[a] < 0 || snp_ids[a] >= h->n_pca) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: PcaSnpId out of range");
+        rows[(size_t)a] = h->pca_rows[(size_t)snp_ids[a]];
+    }
+    for (int64_t c = 0; c < nj; ++c)
+        if (sample_ids[c] < 0 || sample_ids[c] >= h->N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: QcSampleId out of range");
+    int64_t *d_rows = nullptr, *d_cols = nullptr; float* d_out = nullptr; unsigned long long* d_err = nullptr;
+    hipError_t e = hipMalloc((void**)&d_rows, (size_t)ns * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_cols, (size_t)nj * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)ns * (size_t)nj * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_err, 8);
+    unsigned long long err_idx = ~0ull;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), (size_t)ns * 8, hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cols, sample_ids, (size_t)nj * 8, hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_err, &err_idx, 8, hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) {
+        launch_standardize_block(h->st, h->dG, h->ldg, h->d_mu, h->d_sigma, d_rows, ns, d_cols, nj, d_out, d_err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&err_idx, d_err, 8, hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    if (e == hipSuccess && err_idx == ~0ull) e = hipMemcpy(out, d_out, (size_t)ns * (size_t)nj * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rows); (void)hipFree(d_cols); (void)hipFree(d_out); (void)hipFree(d_err);
+    HIPCHK(e);
+    if (err_idx != ~0ull) {
+        const int64_t a = (int64_t)(err_idx / (unsigned long long)nj), c = (int64_t)(err_idx % (unsigned long long)nj);
+        char buf[400];  // wording of prepare.rs:1910-1911
+        snprintf(buf, sizeof buf,
+                 "Unexpected missing genotype (-127i8) in SnpBlockData for PCA SNP ID %lld (original BIM index %lld), "
+                 "requested sample index %lld. This should have been filtered by QC.",
+                 (long long)snp_ids[a], (long long)rows[(size_t)a], (long long)sample_ids[c]);
+        return fail(h, GPCA_ERR_MISSING_GENOTYPE, buf);
+    }
+    return GPCA_OK;
+}
+
+// ---- e: exchange step ------------------------------------------------------------------------------------
+extern "C" int gpca_comm_get_unique_id(void* out_id) {
+    if (!out_id) return GPCA_ERR_BAD_ARG;
+    if (!g_rccl.load()) return fail(nullptr, GPCA_ERR_RCCL, "librccl.so could not be loaded");
+    ncclUniqueId_t id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return fail(nullptr, GPCA_ERR_RCCL, "ncclGetUniqueId failed");
+    memcpy(out_id, &id, GPCA_UNIQUE_ID_BYTES);
+    return GPCA_OK;
+}
+
+extern "C" int gpca_comm_init(gpca_handle* h, int32_t world, int32_t rank, const void* unique_id, int64_t snp_offset) {
+    if (!h || world < 1 || rank < 0 || rank >= world || !unique_id || snp_offset < 0)
+        return fail(h, GPCA_ERR_BAD_ARG, "gpca_comm_init: bad arguments");
+    if (!g_rccl.load()) return fail(h, GPCA_ERR_RCCL, "librccl.so could not be loaded");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId_t id;
+    memcpy(&id, unique_id, GPCA_UNIQUE_ID_BYTES);
+    const int rc = g_rccl.CommInitRank(&h->comm, world, id, rank);
+    if (rc != 0) {
+        std::string m = "ncclCommInitRank failed: ";
+        m += g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?";
+        return fail(h, GPCA_ERR_RCCL, m);
+    }
+    h->world = world; h->rank = rank; h->snp_offset = snp_offset; h->hook = nullptr;
+    return GPCA_OK;
+}
+
+extern "C" int gpca_set_allreduce_hook(gpca_handle* h, gpca_allreduce_fn fn, void* user, int32_t world, int32_t rank,
+                                       int64_t snp_offset) {
+    if (!h || world < 1 || rank < 0 || rank >= world || snp_offset < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_allreduce_hook: bad arguments");
+    h->hook = fn; h->hook_user = user; h->world = world; h->rank = rank; h->snp_offset = snp_offset;
+    return GPCA_OK;
+}
+
+// in-place sum of a device f64 buffer across the ranks that share the sharded matrix
+static int allreduce_f64(gpca_handle* h, double* dbuf, int64_t count) {
+    if (h->world <= 1 && !h->hook) return GPCA_OK;
+    if (h->hook) {
+        h->hook_buf.resize((size_t)count);
+        HIPCHK(hipMemcpyAsync(h->hook_buf.data(), dbuf, (size_t)count * 8, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        if (h->hook(h->hook_user, h->hook_buf.data(), count) != 0) return fail(h, GPCA_ERR_RCCL, "all-reduce hook reported failure");
+        HIPCHK(hipMemcpyAsync(dbuf, h->hook_buf.data(), (size_t)count * 8, hipMemcpyHostToDevice, h->st));
+        return GPCA_OK;
+    }
+    if (!h->comm) return fail(h, GPCA_ERR_STATE, "world > 1 but no communicator: call gpca_comm_init");
+    ScopedTimer t(h, "allreduce", 0.0, (double)count * 8.0);
+    const int rc = g_rccl.AllReduce(dbuf, dbuf, (size_t)count, kNcclFloat64, kNcclSum, h->comm, h->st);
+    if (rc != 0) {
+        std::string m = "ncclAllReduce failed: ";
+        m += g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?";
+        return fail(h, GPCA_ERR_RCCL, m);
+    }
+    return GPCA_OK;
+}
+
+// ---- small dense (host, f64) ----------------------------------------------------------------------------------
+static int chol_upper(std::vector<double>& W, int n, int ld) {  // W = R^T R in place (upper), 0 ok / j+1 on failure
+    for (int j = 0; j < n; ++j) {
+        double d = W[j * ld + j];
+        for (int k = 0; k < j; ++k) d -= W[k * ld + j] * W[k * ld + j];
+        if (!(d > 0.0) || !std::isfinite(d)) return j + 1;
+        d = std::sqrt(d);
+        W[j * ld + j] = d;
+        for (int c = j + 1; c < n; ++c) {
+            double s = W[j * ld + c];
+            for (int k = 0; k < j; ++k) s -= W[k * ld + j] * W[k * ld + c];
+            W[j * ld + c] = s / d;
+        }
+    }
+    return 0;
+}
+static void upper_inverse(const std::vector<double>& R, std::vector<double>& X, int n, int ld) {
+    std::fill(X.begin(), X.end(), 0.0);
+    for (int j = 0; j < n; ++j) {
+        X[j * ld + j] = 1.0 / R[j * ld + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int k = i + 1; k <= j; ++k) s += R[i * ld + k] * X[k * ld + j];
+            X[i * ld + j] = -s / R[i * ld + i];
+        }
+    }
+}
+static void jacobi_eigh(std::vector<double>& A, std::vector<double>& V, std::vector<double>& w, int n) {
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < n; ++i) { dg += A[i*n+i] * A[i*n+i]; for (int j = i + 1; j < n; ++j) off += A[i*n+j] * A[i*n+j]; }
+        if (off <= 1e-30 * dg || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
+            const double apq = A[p * n + q];
+            if (apq == 0.0) continue;
+            const double theta = (A[q*n+q] - A[p*n+p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < n; ++k) { const double a = A[k*n+p], b = A[k*n+q]; A[k*n+p] = c*a - s*b; A[k*n+q] = s*a + c*b; }
+            for (int k = 0; k < n; ++k) { const double a = A[p*n+k], b = A[q*n+k]; A[p*n+k] = c*a - s*b; A[q*n+k] = s*a + c*b; }
+            for (int k = 0; k < n; ++k) { const double a = V[k*n+p], b = V[k*n+q]; V[k*n+p] = c*a - s*b; V[k*n+q] = s*a + c*b; }
+        }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+    for (int i = 0; i < n - 1; ++i) {
+        int m = i;
+        for (int j = i + 1; j < n; ++j) if (w[j] > w[m]) m = j;
+        if (m != i) { std::swap(w[i], w[m]); for (int k = 0; k < n; ++k) std::swap(V[k*n+i], V[k*n+m]); }
+    }
+}
+
+// ---- rsvd stages -----------------------------------------------------------------------------------------------
+static int stage_sum_c(gpca_handle* h, int64_t parts) {
+    launch_sum_partials_f32(h->st, h->d_cpart, parts, h->L, h->d_c);
+    HIPCHK(hipGetLastError());
+    return GPCA_OK;
+}
+
+// Y = A^T T  (T' = r o T already in dT, c = b^T T in d_c), then the exchange step
+static int stage_AtT(gpca_handle* h) {
+    const double elems = (double)h->M * (double)h->N;
+    {
+        ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, elems);
+        launch_gtt_f32(h->st, h->dG, h->ldg, h->M, h->ldg, h->dT, h->L, h->dYpart, h->plan);
+    }
+    HIPCHK(hipGetLastError());
+    launch_reduce_y(h->st, h->dYpart, h->plan.W, h->ldg, h->N, h->L, h->d_c, h->dY);
+    HIPCHK(hipGetLastError());
+    return allreduce_f64(h, h->dY, h->N * h->L);
+}
+
+// T = A Q (scale_out: r o T and c)
+static int stage_AQ(gpca_handle* h, int scale_out) {
+    const double elems = (double)h->M * (double)h->N;
+    {
+        ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, elems);
+        launch_gq_f32(h->st, h->dG, h->ldg, h->M, h->ldg, h->dQ, h->L, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+    }
+    HIPCHK(hipGetLastError());
+    if (scale_out) CHK(stage_sum_c(h, gq_num_parts(h->M)));
+    return GPCA_OK;
+}
+
+// CholeskyQR2 of dY -> dQ (f32, padded), s = 1^T Q
+static int stage_orth(gpca_handle* h) {
+    const int L = h->L, l = h->l;
+    std::vector<double> W((size_t)L * L), X((size_t)L * L);
+    for (int round = 0; round < 2; ++round) {
+        const int64_t parts = gram_num_parts(h->N);
+        launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
+        HIPCHK(hipGetLastError());
+        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(W.data(), h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        const int rc = chol_upper(W, l, L);
+        if (rc) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not positive (rank-deficient sketch)", rc - 1, l);
+            return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
+        }
+        upper_inverse(W, X, l, L);
+        HIPCHK(hipMemcpyAsync(h->dZ, X.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, h->st));
+        launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, round == 1 ? h->dQ : nullptr, h->ldg);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->st));  // X (host) is reused next round
+    }
+    const int64_t parts = colsum_num_parts(h->ldg);
+    launch_colsum_f32(h->st, h->dQ, h->ldg, L, h->d_part64);
+    HIPCHK(hipGetLastError());
+    launch_sum_partials_f64(h->st, h->d_part64, parts, L, h->d_s64);
+    HIPCHK(hipGetLastError());
+    launch_f64_to_f32(h->st, h->d_s64, h->d_s32, L);
+    HIPCHK(hipGetLastError());
+    return GPCA_OK;
+}
+
+static int ensure_workspace(gpca_handle* h) {
+    const int L = h->L;
+    const int64_t Npad = h->ldg, M = h->M, N = h->N;
+    h->plan = gtt_plan(M, Npad, L, 2048);
+    CHK(ensure(h, h->dQ, h->cap_Q, (size_t)Npad * L));
+    CHK(ensure(h, h->dT, h->cap_T, (size_t)M * L));
+    CHK(ensure(h, h->dYpart, h->cap_Ypart, (size_t)h->plan.W * (size_t)Npad * L));
+    const int64_t cparts = std::max(gq_num_parts(M), omega_num_parts(M));
+    CHK(ensure(h, h->d_cpart, h->cap_cpart, (size_t)cparts * L));
+    CHK(ensure(h, h->dY, h->cap_Y, (size_t)N * L));
+    const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L});
+    CHK(ensure(h, h->d_part64, h->cap_part64, (size_t)p64));
+    if (!h->d_c) {
+        HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));
+        HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, 64 * 64 * 8));
+        HIPCHK(hipMalloc((void**)&h->dZ, 64 * 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
+    }
+    size_t cap2 = h->cap_scores;
+    CHK(ensure(h, h->d_scores64, h->cap_scores, (size_t)N * h->k));
+    CHK(ensure(h, h->d_scores32, cap2, (size_t)N * h->k));
+    CHK(ensure(h, h->d_load32, h->cap_load, (size_t)std::max<int64_t>(h->n_pca, 1) * h->k));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    if (!h->dG) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: no genotypes resident");
+    if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: run gpca_snp_stats or gpca_set_standardization first");
+    if (k <= 0) return fail(h, GPCA_ERR_BAD_ARG, "Number of components (-k) must be > 0.");  // main.rs:607-609
+    if (oversample < 0 || power_iters < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: negative oversample/power_iters");
+    if (h->N < 2) return fail(h, GPCA_ERR_BAD_ARG, "PCA requires at least 2 samples.");   // main.rs:614-616
+    if (h->world <= 1 && h->n_pca == 0) return fail(h, GPCA_ERR_BAD_ARG, "PCA requires at least 1 variant (feature), found 0.");  // main.rs:617-619
+    const int l = k + oversample;
+    if (l > 64) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: k + oversample must be <= 64");
+    if (l > h->N || (h->world <= 1 && l > h->n_pca)) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: k + oversample exceeds min(samples, PCA SNPs)");
+    if (h->flags & 1u) return fail(h, GPCA_ERR_MISSING_GENOTYPE,
+        "Unexpected missing genotype (-127i8) in a PCA SNP. This should have been filtered by QC.");  // prepare.rs:1909-1911
+    if (h->flags & 2u) return fail(h, GPCA_ERR_INVALID_GENOTYPE, "a PCA SNP holds a dosage outside {0,1,2}");
+    if (h->precision != GPCA_PREC_F32_MFMA) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: unsupported precision mode");
+    HIPCHK(hipSetDevice(h->device));
+    h->k = k; h->l = l; h->L = l <= 32 ? 32 : 64;
+    h->have_rsvd = false;
+    CHK(ensure_workspace(h));
+    const int L = h->L;
+
+    // 1. sketch: T' = r o Omega, c = b^T Omega;  Y = A^T Omega;  Q = orth(Y)
+    {
+        ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
+        launch_omega(h->st, h->M, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart);
+    }
+    HIPCHK(hipGetLastError());
+    CHK(stage_sum_c(h, omega_num_parts(h->M)));
+    CHK(stage_AtT(h));
+    CHK(stage_orth(h));
+    // 2. power iterations
+    for (int it = 0; it < power_iters; ++it) {
+        CHK(stage_AQ(h, 1));
+        CHK(stage_AtT(h));
+        CHK(stage_orth(h));
+    }
+    // 3. projection B = A Q, small eigenproblem of B^T B
+    CHK(stage_AQ(h, 0));
+    {
+        const int64_t parts = gram_num_parts(h->M);
+        launch_gram_f32(h->st, h->dT, h->M, L, h->d_part64);
+        HIPCHK(hipGetLastError());
+        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_f64(h, h->dW, (int64_t)L * L));
+    }
+    std::vector<double> Wfull((size_t)L * L), C((size_t)l * l), V((size_t)l * l), w((size_t)l);
+    HIPCHK(hipMemcpyAsync(Wfull.data(), h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    for (int a = 0; a < l; ++a) for (int c = 0; c < l; ++c) C[(size_t)a * l + c] = 0.5 * (Wfull[(size_t)a * L + c] + Wfull[(size_t)c * L + a]);
+    jacobi_eigh(C, V, w, l);
+    h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
+    for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
+    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
+    // 4. scores = Q V_k diag(s) ; sign ; loadings = B V_k diag(sign/s)
+    std::vector<double> Z((size_t)L * k, 0.0);
+    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Z[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
+    HIPCHK(hipMemcpyAsync(h->dZ, Z.data(), sizeof(double) * L * k, hipMemcpyHostToDevice, h->st));
+    launch_rightmul_f32(h->st, h->dQ, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);
+    HIPCHK(hipGetLastError());
+    launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
+    HIPCHK(hipGetLastError());
+    launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
+    HIPCHK(hipGetLastError());
+    std::vector<int> sign((size_t)k, 1);
+    HIPCHK(hipMemcpyAsync(sign.data(), h->d_sign, sizeof(int) * k, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));  // Z (host) is rewritten below
+    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c)
+        Z[(size_t)j * k + c] = h->sv[(size_t)c] > 0 ? V[(size_t)j * l + c] * (double)sign[(size_t)c] / h->sv[(size_t)c] : 0.0;
+    HIPCHK(hipMemcpyAsync(h->dZ, Z.data(), sizeof(double) * L * k, hipMemcpyHostToDevice, h->st));
+    launch_rightmul_gather_f32(h->st, h->dT, h->d_pca_rows, h->n_pca, L, h->dZ, k, h->d_load32);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->st));
+    h->have_rsvd = true;
+    return GPCA_OK;
+}
+
+#define NEED_RSVD(name) \
+    if (!h || !out) return GPCA_ERR_BAD_ARG; \
+    if (!h->have_rsvd) return fail(h, GPCA_ERR_STATE, name ": run gpca_rsvd first")
+
+extern "C" int gpca_get_scores(gpca_handle* h, float* out) {
+    NEED_RSVD("gpca_get_scores");
+    HIPCHK(hipMemcpy(out, h->d_scores32, (size_t)h->N * h->k * 4, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+extern "C" int gpca_get_scores_f64(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_get_scores_f64");
+    HIPCHK(hipMemcpy(out, h->d_scores64, (size_t)h->N * h->k * 8, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+extern "C" int gpca_get_eigenvalues(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_get_eigenvalues");
+    std::copy(h->eig.begin(), h->eig.end(), out);
+    return GPCA_OK;
+}
+extern "C" int gpca_get_singular_values(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_get_singular_values");
+    std::copy(h->sv.begin(), h->sv.end(), out);
+    return GPCA_OK;
+}
+extern "C" int gpca_get_loadings(gpca_handle* h, float* out) {
+    NEED_RSVD("gpca_get_loadings");
+    if (h->n_pca) HIPCHK(hipMemcpy(out, h->d_load32, (size_t)h->n_pca * h->k * 4, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+
+// PCA::transform (main.rs:659): scores = A^T U on the resident matrix, U = loadings.
+__attribute__((visibility("hidden"))) int transform_impl(gpca_handle* h, double* out);
+
+extern "C" int gpca_transform(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_transform");
+    return transform_impl(h, out);
+}
+
+// ---- d: timings ------------------------------------------------------------------------------------------------
+extern "C" int gpca_enable_timings(gpca_handle* h, int32_t on) { if (!h) return GPCA_ERR_BAD_ARG; h->timing_on = on != 0; return GPCA_OK; }
+extern "C" int gpca_reset_timings(gpca_handle* h) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(h->st));
+    for (auto& r : h->recs) { h->ev_pool.push_back(r.a); h->ev_pool.push_back(r.b); }
+    h->recs.clear();
+    return GPCA_OK;
+}
+extern "C" int gpca_get_timings(gpca_handle* h, gpca_kernel_timing* out, int32_t cap, int32_t* n) {
+    if (!h || !n) return GPCA_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(h->st));
+    std::vector<gpca_kernel_timing> agg;
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        size_t i = 0;
+        for (; i < agg.size(); ++i) if (r.name == agg[i].name) break;
+        if (i == agg.size()) { gpca_kernel_timing t{}; snprintf(t.name, sizeof t.name, "%s", r.name.c_str()); agg.push_back(t); }
+        agg[i].launches++; agg[i].total_ms += ms; agg[i].flops += r.flops; agg[i].bytes += r.bytes;
+    }
+    *n = (int32_t)agg.size();
+    if (out) for (int32_t i = 0; i < *n && i < cap; ++i) out[i] = agg[(size_t)i];
+    return GPCA_OK;
+}
+
+int transform_impl(gpca_handle* h, double* out) {
+    HIPCHK(hipSetDevice(h->device));
+    const int L = h->L, k = h->k;
+    // T' = r o U (zero rows for dropped SNPs), c = b^T U
+    HIPCHK(hipMemsetAsync(h->dT, 0, (size_t)h->M * L * 4, h->st));
+    launch_expand_loadings(h->st, h->d_load32, h->d_pca_rows, h->n_pca, k, L, h->dT);
+    HIPCHK(hipGetLastError());
+    launch_scale_rows(h->st, h->dT, h->M, L, h->d_r, h->d_b, h->d_cpart);
+    HIPCHK(hipGetLastError());
+    CHK(stage_sum_c(h, omega_num_parts(h->M)));
+    CHK(stage_AtT(h));
+    std::vector<double> Y((size_t)h->N * L);
+    HIPCHK(hipMemcpyAsync(Y.data(), h->dY, (size_t)h->N * L * 8, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    for (int64_t n = 0; n < h->N; ++n) for (int c = 0; c < k; ++c) out[n * k + c] = Y[(size_t)n * L + c];
+    h->have_rsvd = true;  // dT (=B) is consumed, but scores/loadings/eigenvalues stay valid
+    return GPCA_OK;
+}

@@ -1,0 +1,79 @@
+// Launchers for the gfx950 kernels (kernels.hip).  Every launcher only enqueues work on `st`;
+// none allocates or synchronises.  Shapes are validated by the callers in gpca_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpca {
+
+// Row pitch of the int8 genotype matrix and row count of Q/Y buffers: multiple of this many samples.
+constexpr int64_t kSamplePad = 256;   // = samples covered by one wave tile of the G^T T kernel
+constexpr int kGQRowsPerWave = 128;   // SNP rows per wave in the G Q kernel (R = 4 tiles of 32)
+
+struct QcParams { double min_call_rate, min_maf, max_hwe_p; };
+
+void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset,
+                  uint64_t seed, const uint32_t* d_thresh, int P);
+void launch_bed_decode(hipStream_t st, const uint8_t* bed, int64_t bytes_per_row, int8_t* G, int64_t M,
+                       int64_t N, int64_t ld);
+// a1: per-SNP {n_valid,n0,n1,n2}, mu, sigma, r = 1/sigma, b = -mu r, keep, reason; flags[0] |= 1 if any
+// kept SNP holds a missing value, |= 2 if any kept SNP holds a value outside {0,1,2}.
+void launch_snp_stats(hipStream_t st, const int8_t* G, int64_t M, int64_t N, int64_t ld, QcParams qc,
+                      float* mu, float* sigma, float* r, float* b, uint8_t* keep, uint8_t* reason,
+                      uint32_t* counts, uint32_t* flags);
+// recompute r, b, flags from caller-supplied mu/sigma/keep (needs counts from a stats pass for the flags)
+void launch_set_scale(hipStream_t st, int64_t M, const float* mu, const float* sigma, const uint8_t* keep,
+                      float* r, float* b);
+// a2: out[a][c] = fma((f32)g, 1/sigma, -mu/sigma); err_idx = min flat index of a missing genotype (or -1)
+void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const float* mu,
+                              const float* sigma, const int64_t* rows, int64_t ns, const int64_t* cols,
+                              int64_t nj, float* out, unsigned long long* err_idx);
+
+// sketch operand: Tp[i][j] = r_i * Omega[i][j] (j < l, else 0); cpart[wave][j] = sum_i b_i Omega[i][j]
+int64_t omega_num_parts(int64_t M);
+void launch_omega(hipStream_t st, int64_t M, int l, int L, int64_t snp_offset, uint64_t seed,
+                  const float* r, const float* b, float* Tp, float* cpart);
+
+// K1: T = r o (G Q) + b s^T   (scale_out: write r o T instead, plus cpart = per-wave sum_i b_i T_ij)
+int64_t gq_num_parts(int64_t M);
+void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Q,
+                   int L, const float* r, const float* b, const float* s, float* Tout, float* cpart,
+                   int scale_out);
+// K2: Ypart[w][n][j] = sum over the wave's SNP rows of G[i][n] * Tp[i][j]
+struct GttPlan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; };
+GttPlan gtt_plan(int64_t M, int64_t Npad, int L, int target_waves);
+void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Tp,
+                    int L, float* Ypart, const GttPlan& plan);
+// Y[n][j] = c[j] + sum_w Ypart[w][n][j]   (f64 sum), n < N
+void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, int64_t N, int L, const double* c,
+                     double* Y);
+
+// generic tall-skinny helpers
+void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out);
+void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out);
+int64_t gram_num_parts(int64_t rows);
+void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part);
+void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part);
+// X[n][:] <- X[n][:] * Z  (Z: [L][L] f64, in place); optionally also Qout f32 [rows_pad][L] (pad rows zeroed)
+void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,
+                                int64_t rows_pad);
+// out[n][kc] = sum_j X[n][j] Z[j][kc]   (Z: [L][K] f64)
+void launch_rightmul_f32(hipStream_t st, const float* X, int64_t rows, int L, const double* Z, int K, double* out64,
+                         float* out32);
+// rows gathered through an index list (loadings of kept SNPs)
+void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
+                                const double* Z, int K, float* out32);
+int64_t colsum_num_parts(int64_t rows);
+void launch_colsum_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part);
+// sign[c] = sign of the first element of column c with maximal |x|
+void launch_col_sign(hipStream_t st, const double* X, int64_t rows, int K, int* sign);
+void launch_scale_cols(hipStream_t st, double* X64, float* X32, int64_t rows, int K, const int* sign);
+void launch_f64_to_f32(hipStream_t st, const double* in, float* out, int64_t n);
+// exclusive scan of keep -> row list of kept SNPs (small M only needs one block; large M uses 2 passes)
+void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v);
+// Tp[rows[a]][c] = load[a][c] for c < k (other entries untouched: caller zero-fills Tp first)
+void launch_expand_loadings(hipStream_t st, const float* load, const int64_t* rows, int64_t n_pca, int k, int L, float* Tp);
+// in place X[i][:] <- r_i X[i][:]; cpart[wave][j] = sum over the wave's 64 rows of b_i X[i][j] (omega_num_parts(M) waves)
+void launch_scale_rows(hipStream_t st, float* X, int64_t M, int L, const float* r, const float* b, float* cpart);
+
+}  // namespace gpca

@@ -1,0 +1,826 @@
+// gfx950 (MI355X, CDNA4) kernels of the randomized-PCA hot path.  wave = 64 lanes everywhere.
+//
+// Data layout in HBM
+//   G      int8  [M][ldg]      SNP-major dosages, ldg = round_up(N, 256), pad bytes are 0
+//   Q      f32   [Npad][L]     sample-side orthonormal basis, Npad = ldg, L = 32 or 64, pad rows/cols 0
+//   T / B  f32   [M][L]        SNP-side sketch (r o T for power iterations, T itself for the projection)
+//   Y      f64   [N][L]        sketch accumulator (sum over SNP shards / GPUs happens in f64)
+//
+// The standardised matrix A[i][n] = g*r_i + b_i (r = 1/sigma, b = -mu r: prepare.rs:1948-1949) is never
+// materialised:  A Q = r o (G Q) + b (1^T Q)   and   A^T T = G^T (r o T) + 1 (b^T T).
+// So both tall-skinny GEMMs run on the raw 0/1/2 bytes (one v_cvt_f32_ubyteN per MFMA operand) and the
+// standardisation is a per-row epilogue -- the reference's per-block f32 standardise pass
+// (prepare.rs:1884-2016) disappears from the hot loop.
+#include "kernels.h"
+#include "philox.hpp"
+
+namespace gpca {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DEVINL __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic genotypes.  One thread = 8 consecutive samples of one SNP (one 8-byte store).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_synth(int8_t* __restrict__ G, int64_t M, int64_t N, int64_t ld,
+                                                int64_t snp_offset, uint64_t seed,
+                                                const uint32_t* __restrict__ thresh, int P) {
+    const int64_t per_row = ld >> 3;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * per_row) return;
+    const int64_t i = t / per_row;
+    const int64_t n0 = (t - i * per_row) << 3;
+    const uint64_t gi = (uint64_t)(i + snp_offset);
+    const uint32_t* th = thresh + i * P;
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t n = n0 + 2 * q;
+        if (n < N) {
+            philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)(n >> 1), GPCA_STREAM_GENO,
+                                         (uint32_t)seed, (uint32_t)(seed >> 32));
+            uint32_t ta = th[n % P];
+            uint32_t g0 = (uint32_t)(o.v[0] < ta) + (uint32_t)(o.v[1] < ta);
+            uint32_t g1 = 0;
+            if (n + 1 < N) {
+                uint32_t tb = th[(n + 1) % P];
+                g1 = (uint32_t)(o.v[2] < tb) + (uint32_t)(o.v[3] < tb);
+            }
+            w[q >> 1] |= (g0 | (g1 << 8)) << (16 * (q & 1));
+        }
+    }
+    *reinterpret_cast<uint2*>(G + i * ld + n0) = make_uint2(w[0], w[1]);
+}
+
+void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset, uint64_t seed,
+                  const uint32_t* d_thresh, int P) {
+    const int64_t total = M * (ld >> 3);
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, G, M, N, ld, snp_offset, seed,
+                       d_thresh, P);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PLINK .bed 2-bit -> int8 dosage, count_a1 semantics (prepare.rs:622-629: .i8().count_a1()):
+//   code 00 -> 2, 10 -> 1, 11 -> 0, 01 -> missing (-127).  One thread = 4 packed bytes = 16 samples.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bed_decode(const uint8_t* __restrict__ bed, int64_t bpr, int8_t* __restrict__ G,
+                                                    int64_t M, int64_t N, int64_t ld) {
+    const int64_t per_row = ld >> 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * per_row) return;
+    const int64_t i = t / per_row;
+    const int64_t n0 = (t - i * per_row) << 4;
+    uint32_t packed = 0;
+    const uint8_t* src = bed + i * bpr + (n0 >> 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((n0 >> 2) + k < bpr) packed |= (uint32_t)src[k] << (8 * k);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const uint32_t code = (packed >> (2 * s)) & 3u;
+        // 00->2, 01->0x81, 10->1, 11->0
+        uint32_t v = code == 0u ? 2u : (code == 1u ? 0x81u : (code == 2u ? 1u : 0u));
+        if (n0 + s >= N) v = 0u;
+        w[s >> 2] |= v << (8 * (s & 3));
+    }
+    *reinterpret_cast<uint4*>(G + i * ld + n0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+void launch_bed_decode(hipStream_t st, const uint8_t* bed, int64_t bytes_per_row, int8_t* G, int64_t M, int64_t N,
+                       int64_t ld) {
+    const int64_t total = M * (ld >> 4);
+    hipLaunchKernelGGL(k_bed_decode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bed, bytes_per_row, G, M, N,
+                       ld);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1: SNP QC + standardisation parameters.  One wave per SNP row, 16 B per lane per step.
+//
+// Restates prepare.rs:1216-1375.  Integer sums are exact, so instead of the reference's second f64
+// pass the sum of squared deviations is formed as (n*sum(g^2) - sum(g)^2)/n from exact integers
+// (< 2^53) with a single rounding -- the exact value the two-pass f64 loop approximates.
+// Fast path handles bytes in {0,1,2,-127} with packed-byte logic + v_dot4; any other byte value
+// flags the row, which is then recounted byte by byte (signed), keeping prepare.rs:1272-1277's semantics.
+// ------------------------------------------------------------------------------------------------
+DEVINL double hwe_p_dev(unsigned n1h, unsigned nhet, unsigned n2h) {  // prepare.rs:1641-1745
+    const unsigned long long tot = (unsigned long long)n1h + nhet + n2h;
+    if (tot == 0) return 1.0;
+    const double c1 = 2.0 * (double)n1h + (double)nhet;
+    const double c2 = 2.0 * (double)n2h + (double)nhet;
+    const double ta = c1 + c2;
+    if (ta <= 1e-9) return 1.0;
+    const double f1 = c1 / ta, f2 = c2 / ta;
+    if (f1 < 1e-9 || f2 < 1e-9) return 1.0;
+    if (fabs(f1 + f2 - 1.0) > 1e-6) return 1.0;
+    const double e1 = f1 * f1 * (double)tot, eh = 2.0 * f1 * f2 * (double)tot, e2 = f2 * f2 * (double)tot;
+    double chi = 0.0;
+    const double MINE = 1e-9;
+    if (e1 > MINE) { const double d = (double)n1h - e1; chi += d * d / e1; }
+    else if ((double)n1h > MINE) chi = INFINITY;
+    if (isfinite(chi)) {
+        if (eh > MINE) { const double d = (double)nhet - eh; chi += d * d / eh; }
+        else if ((double)nhet > MINE) chi = INFINITY;
+    }
+    if (isfinite(chi)) {
+        if (e2 > MINE) { const double d = (double)n2h - e2; chi += d * d / e2; }
+        else if ((double)n2h > MINE) chi = INFINITY;
+    }
+    if (isnan(chi)) return 1.0;
+    if (chi == INFINITY) return 0.0;
+    const double cdf = erf(sqrt(chi * 0.5));
+    if (isnan(cdf)) return 1.0;
+    const double p = 1.0 - cdf;
+    return p > 0.0 ? p : 0.0;
+}
+
+DEVINL int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+DEVINL long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_snp_stats(const int8_t* __restrict__ G, int64_t M, int64_t N, int64_t ld,
+                                                    QcParams qc, float* __restrict__ mu, float* __restrict__ sigma,
+                                                    float* __restrict__ rr, float* __restrict__ bb,
+                                                    uint8_t* __restrict__ keep, uint8_t* __restrict__ reason,
+                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const uint4* p = reinterpret_cast<const uint4*>(G + row * ld);
+    const int64_t nvec = ld >> 4;  // ld is a multiple of 256
+    int nmiss = 0, sum = 0, sq = 0;
+    unsigned weird = 0;
+    for (int64_t v0 = lane; v0 < nvec; v0 += 64) {
+        const uint4 q = p[v0];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned v = w[k];
+            const unsigned m7 = v & 0x80808080u;
+            nmiss += __builtin_popcount(m7);
+            weird |= (v & 0x7C7C7C7Cu) | ((v & (v >> 1)) & 0x01010101u) | ((m7 >> 7) & (~v | (v >> 1)) & 0x01010101u);
+            const unsigned vm = v & ~(m7 | (m7 >> 7));
+            sum = __builtin_amdgcn_sdot4((int)vm, 0x01010101, sum, false);
+            sq = __builtin_amdgcn_sdot4((int)vm, (int)vm, sq, false);
+        }
+    }
+    const unsigned long long anyweird = __ballot(weird != 0);
+    long long nv, s1, s2;
+    unsigned n0, n1, n2;
+    if (anyweird == 0ull) {
+        nmiss = wave_sum_i32(nmiss); sum = wave_sum_i32(sum); sq = wave_sum_i32(sq);
+        nv = (long long)N - nmiss;  // pad bytes are 0 = valid hom-ref: removed from n0 below
+        s1 = sum; s2 = sq;
+        n2 = (unsigned)((s2 - s1) >> 1);
+        n1 = (unsigned)(s1 - 2 * (long long)n2);
+        n0 = (unsigned)(nv - n1 - n2);
+    } else {  // exact byte-wise recount, signed values (prepare.rs:1267-1279)
+        long long a_nv = 0, a_s1 = 0, a_s2 = 0; int a0 = 0, a1 = 0, a2 = 0;
+        const int8_t* rb = G + row * ld;
+        for (int64_t n = lane; n < N; n += 64) {
+            const int v = rb[n];
+            if (v != -127) { a_nv++; a_s1 += v; a_s2 += v * v; a0 += (v == 0); a1 += (v == 1); a2 += (v == 2); }
+        }
+        nv = wave_sum_i64(a_nv); s1 = wave_sum_i64(a_s1); s2 = wave_sum_i64(a_s2);
+        n0 = (unsigned)wave_sum_i32(a0); n1 = (unsigned)wave_sum_i32(a1); n2 = (unsigned)wave_sum_i32(a2);
+    }
+    if (lane != 0) return;
+    counts[4 * row + 0] = (unsigned)nv; counts[4 * row + 1] = n0; counts[4 * row + 2] = n1; counts[4 * row + 3] = n2;
+    uint8_t why = 0;
+    double mean = 0.0;
+    do {
+        const double call_rate = (double)nv / (double)N;                       // prepare.rs:1283
+        if (call_rate < qc.min_call_rate) { why = 1; break; }
+        if (nv == 0) { why = 2; break; }                                       // :1292
+        mean = (double)s1 / (double)nv;                                        // :1294
+        const double pfr = mean / 2.0;
+        const double maf = pfr < 1.0 - pfr ? pfr : 1.0 - pfr;                  // :1296
+        if (maf < qc.min_maf) { why = 3; break; }                              // :1299
+        if (fabs(pfr) < 1e-9 || fabs(1.0 - pfr) < 1e-9) { why = 4; break; }    // :1302
+        if (qc.max_hwe_p < 1.0) {
+            if (hwe_p_dev(n0, n1, n2) <= qc.max_hwe_p) { why = 5; break; }     // :1306-1311
+        }
+    } while (0);
+    float m32 = 0.f, s32 = 0.f, r32 = 0.f, b32 = 0.f;
+    if (!why) {
+        double var = 0.0;
+        if (nv >= 2) {
+            const double num = (double)nv * (double)s2 - (double)s1 * (double)s1;  // exact integers < 2^53
+            var = (num / (double)nv) / (double)(nv - 1);                           // :1358
+        }
+        if (var <= 1e-9) why = 6;                                                  // :1363
+        else {
+            m32 = (float)mean;                                                     // :1313
+            s32 = (float)sqrt(var);                                                // :1364
+            r32 = 1.0f / s32;                                                      // :1948
+            b32 = -m32 * r32;                                                      // :1949
+            unsigned f = 0;
+            if (nv != N) f |= 1u;
+            if ((long long)n0 + n1 + n2 != nv) f |= 2u;
+            if (f) atomicOr(flags, f);
+        }
+    }
+    mu[row] = m32; sigma[row] = s32; rr[row] = r32; bb[row] = b32;
+    keep[row] = why ? 0 : 1; reason[row] = why;
+}
+
+void launch_snp_stats(hipStream_t st, const int8_t* G, int64_t M, int64_t N, int64_t ld, QcParams qc, float* mu,
+                      float* sigma, float* r, float* b, uint8_t* keep, uint8_t* reason, uint32_t* counts,
+                      uint32_t* flags) {
+    hipLaunchKernelGGL(k_snp_stats, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, G, M, N, ld, qc, mu, sigma, r, b,
+                       keep, reason, counts, flags);
+}
+
+__global__ void k_set_scale(int64_t M, const float* mu, const float* sigma, const uint8_t* keep, float* r, float* b) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float rv = 0.f, bv = 0.f;
+    if (keep[i] && !(fabsf(sigma[i]) < 1e-9f)) { rv = 1.0f / sigma[i]; bv = -mu[i] * rv; }
+    r[i] = rv; b[i] = bv;
+}
+void launch_set_scale(hipStream_t st, int64_t M, const float* mu, const float* sigma, const uint8_t* keep, float* r,
+                      float* b) {
+    hipLaunchKernelGGL(k_set_scale, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, mu, sigma, keep, r, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2: the pull API, prepare.rs:1884-2016.  Gather (row, col) -> fma((f32)g, 1/sigma, -mu * (1/sigma)).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_standardize_block(const int8_t* __restrict__ G, int64_t ld,
+                                                            const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                            const int64_t* __restrict__ rows, int64_t ns,
+                                                            const int64_t* __restrict__ cols, int64_t nj,
+                                                            float* __restrict__ out, unsigned long long* err_idx) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ns * nj) return;
+    const int64_t a = t / nj, c = t - a * nj;
+    const int64_t i = rows[a];
+    const int v = G[i * ld + cols[c]];
+    if (v == -127) { atomicMin(err_idx, (unsigned long long)t); return; }   // :1909-1911
+    const float sd = sigma[i];
+    float o = 0.0f;                                                          // :1899 zero-sigma branch
+    if (!(fabsf(sd) < 1e-9f)) {
+        const float rs = 1.0f / sd;                                          // :1948
+        const float bt = -mu[i] * rs;                                        // :1949
+        o = __builtin_fmaf((float)v, rs, bt);                                // :1988 / :2011
+    }
+    out[t] = o;
+}
+void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const float* mu, const float* sigma,
+                              const int64_t* rows, int64_t ns, const int64_t* cols, int64_t nj, float* out,
+                              unsigned long long* err_idx) {
+    const int64_t total = ns * nj;
+    hipLaunchKernelGGL(k_standardize_block, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, G, ld, mu, sigma, rows,
+                       ns, cols, nj, out, err_idx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sketch operand.  Omega[i][j] ~ N(0,1): Philox4x32-10, counter (i_lo, i_hi, j/4, stream), two
+// Box-Muller pairs in f64 (bit-compatible recipe with oracle/gpca_oracle.c:omega4).
+// One wave = 64 rows; writes Tp = r o Omega and the wave's partial of c = b^T Omega.
+// ------------------------------------------------------------------------------------------------
+int64_t omega_num_parts(int64_t M) { return (M + 63) / 64; }
+
+__global__ __launch_bounds__(256) void k_omega(int64_t M, int l, int L, int64_t snp_offset, uint64_t seed,
+                                               const float* __restrict__ r, const float* __restrict__ b,
+                                               float* __restrict__ Tp, float* __restrict__ cpart) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t i = wave * 64 + lane;
+    const bool live = i < M;
+    const float ri = live ? r[i] : 0.f, bi = live ? b[i] : 0.f;
+    const uint64_t gi = (uint64_t)(i + snp_offset);
+    for (int jq = 0; jq < L / 4; ++jq) {
+        double z[4] = {0, 0, 0, 0};
+        if (4 * jq < l) {
+            philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)jq, GPCA_STREAM_OMEGA,
+                                         (uint32_t)seed, (uint32_t)(seed >> 32));
+            const double sc = 1.0 / 4294967296.0, twopi = 6.283185307179586476925286766559;
+            const double u0 = ((double)o.v[0] + 1.0) * sc, u1 = ((double)o.v[1] + 1.0) * sc;
+            const double u2 = ((double)o.v[2] + 1.0) * sc, u3 = ((double)o.v[3] + 1.0) * sc;
+            const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+            z[0] = r0 * cos(twopi * u1); z[1] = r0 * sin(twopi * u1);
+            z[2] = r1 * cos(twopi * u3); z[3] = r1 * sin(twopi * u3);
+        }
+        float4 tv;
+        float zf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) zf[t] = (4 * jq + t < l) ? (float)z[t] : 0.f;
+        tv.x = ri * zf[0]; tv.y = ri * zf[1]; tv.z = ri * zf[2]; tv.w = ri * zf[3];
+        if (live) *reinterpret_cast<float4*>(Tp + i * L + 4 * jq) = tv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float cv = bi * zf[t];
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) cv += __shfl_xor(cv, o2);
+            if (lane == 0) red[wv][4 * jq + t] = cv;
+        }
+    }
+    __syncthreads();
+    if (lane < L && wave < (M + 63) / 64) cpart[wave * L + lane] = red[wv][lane];
+}
+
+void launch_omega(hipStream_t st, int64_t M, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
+                  const float* b, float* Tp, float* cpart) {
+    const int64_t waves = omega_num_parts(M);
+    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, M, l, L, snp_offset, seed, r, b, Tp,
+                       cpart);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: T[M][L] = r o (G Q) + b s^T            (MFMA-fp32 bound: 2*M*N*l flop on M*N bytes)
+//
+// v_mfma_f32_32x32x2_f32: A = 32 SNP rows x 2 samples (one f32 per lane: lane l -> row l&31, k = l>>5),
+// B = 2 samples x 32 columns of Q, D = 32x32 f32 in 16 VGPRs.  A wave owns R*32 SNP rows and walks
+// the sample axis in chunks of 32: each lane loads 16 B of its row (16 consecutive samples of half h),
+// byte u of that load is the A operand of k-step u (v_cvt_f32_ubyteN), and the Q fragment of k-step u
+// (rows s0+16h+u) is shared by the wave's R row tiles.  Next chunk's loads are issued before the
+// current chunk's 16*R MFMAs (register double buffer).
+// ------------------------------------------------------------------------------------------------
+int64_t gq_num_parts(int64_t M) { return (M + kGQRowsPerWave - 1) / kGQRowsPerWave; }
+
+template <int R, int LT>
+__global__ __launch_bounds__(256, (LT == 1 ? 2 : 1)) void k_gq_f32(
+    const int8_t* __restrict__ G, int64_t ldg, int64_t M, int64_t Npad, const float* __restrict__ Q,
+    const float* __restrict__ rv, const float* __restrict__ bv, const float* __restrict__ sv, float* __restrict__ Tout,
+    float* __restrict__ cpart, int scale_out) {
+    constexpr int L = 32 * LT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t row0 = wave * (32 * R);
+    if (row0 >= M) return;
+
+    const char* gp[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        int64_t row = row0 + 32 * t + c;
+        row = row < M ? row : M - 1;
+        gp[t] = reinterpret_cast<const char*>(G) + row * ldg + 16 * h;
+    }
+    const float* qp = Q + (int64_t)(16 * h) * L + c;
+
+    f32x16 acc[R][LT];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
+
+    uint4 ga[R], gb[R];
+    float qa[16][LT], qb[16][LT];
+#pragma unroll
+    for (int t = 0; t < R; ++t) ga[t] = *reinterpret_cast<const uint4*>(gp[t]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt) qa[u][lt] = qp[(int64_t)u * L + 32 * lt];
+
+    for (int64_t s0 = 0; s0 < Npad; s0 += 32) {
+        const int64_t s1 = (s0 + 32 < Npad) ? s0 + 32 : s0;  // last iteration re-loads the same chunk (unused)
+#pragma unroll
+        for (int t = 0; t < R; ++t) gb[t] = *reinterpret_cast<const uint4*>(gp[t] + s1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt) qb[u][lt] = qp[(s1 + u) * L + 32 * lt];
+
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const unsigned w = (u < 4) ? ga[t].x : (u < 8) ? ga[t].y : (u < 12) ? ga[t].z : ga[t].w;
+                const float a = (float)((w >> (8 * (u & 3))) & 0xffu);
+#pragma unroll
+                for (int lt = 0; lt < LT; ++lt)
+                    acc[t][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qa[u][lt], acc[t][lt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) ga[t] = gb[t];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt) qa[u][lt] = qb[u][lt];
+    }
+
+    // epilogue: D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float csum[LT];
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) csum[lt] = 0.f;
+    float sj[LT];
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) sj[lt] = sv[32 * lt + c];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < M) {
+                const float ri = rv[row], bi = bv[row];
+#pragma unroll
+                for (int lt = 0; lt < LT; ++lt) {
+                    const float tv = ri * acc[t][lt][e] + bi * sj[lt];
+                    csum[lt] += bi * tv;
+                    Tout[row * L + 32 * lt + c] = scale_out ? ri * tv : tv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) {
+        const float o = csum[lt] + __shfl_xor(csum[lt], 32);
+        if (h == 0) cpart[wave * L + 32 * lt + c] = o;
+    }
+}
+
+void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Q, int L,
+                   const float* r, const float* b, const float* s, float* Tout, float* cpart, int scale_out) {
+    const int64_t waves = gq_num_parts(M);
+    const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+    if (L == 32)
+        hipLaunchKernelGGL((k_gq_f32<4, 1>), grid, blk, 0, st, G, ldg, M, Npad, Q, r, b, s, Tout, cpart, scale_out);
+    else
+        hipLaunchKernelGGL((k_gq_f32<4, 2>), grid, blk, 0, st, G, ldg, M, Npad, Q, r, b, s, Tout, cpart, scale_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: Ypart[w][n][j] = sum_{i in wave's rows} G[i][n] * Tp[i][j]      (MFMA-fp32 bound)
+//
+// D = Y^T tile: A = Tp^T (32 columns j x 2 SNPs), B = G (2 SNPs x 32 samples).  Each lane loads 8 B of
+// SNP row (m + 2u + h) at sample n0 + 8c: a wave-load covers 2 rows x 256 contiguous bytes.  Byte t of
+// that load feeds accumulator tile t, whose MFMA column c is sample n0 + 8c + t.  A wave owns one
+// 256-sample block and a contiguous range of SNP rows; partial Y^T tiles go to Ypart and are summed
+// in f64 by k_reduce_y (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------------
+GttPlan gtt_plan(int64_t M, int64_t Npad, int L, int target_waves) {
+    GttPlan p;
+    p.nblocks_n = Npad / kSamplePad;
+    int64_t W = target_waves / p.nblocks_n;
+    if (W < 1) W = 1;
+    const int64_t maxW = (M + 15) / 16;
+    if (W > maxW) W = maxW;
+    int64_t rpw = (M + W - 1) / W;
+    rpw = (rpw + 15) / 16 * 16;
+    W = (M + rpw - 1) / rpw;
+    p.W = (int)W;
+    p.rows_per_wave = rpw;
+    const int64_t ngroups = (p.nblocks_n + 3) / 4;
+    p.grid = ngroups * W;
+    (void)L;
+    return p;
+}
+
+template <int LT>
+__global__ __launch_bounds__(256, (LT == 1 ? 2 : 1)) void k_gtt_f32(const int8_t* __restrict__ G, int64_t ldg, int64_t M,
+                                                                    int64_t Npad, const float* __restrict__ Tp,
+                                                                    float* __restrict__ Ypart, int64_t ngroups,
+                                                                    int64_t rows_per_wave) {
+    constexpr int L = 32 * LT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ngroup = blockIdx.x % ngroups;
+    const int64_t wchunk = blockIdx.x / ngroups;
+    const int64_t nblock = ngroup * 4 + wv;
+    const int64_t n0 = nblock * kSamplePad;
+    if (n0 >= Npad) return;
+    const int64_t m_begin = wchunk * rows_per_wave;
+    const int64_t m_end = (m_begin + rows_per_wave < M) ? m_begin + rows_per_wave : M;
+
+    f32x16 acc[8][LT];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
+
+    const char* gbase = reinterpret_cast<const char*>(G) + n0 + 8 * c;
+    const float* tbase = Tp + c;
+
+    uint2 ga[8], gb[8];
+    float ta[8][LT], tb[8][LT];
+    auto load = [&](int64_t m, uint2(&g)[8], float(&tt)[8][LT]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t row = m + 2 * u + h;
+            const bool ok = row < m_end;
+            const int64_t rc = ok ? row : (M - 1);
+            g[u] = *reinterpret_cast<const uint2*>(gbase + rc * ldg);
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt) {
+                const float v = tbase[rc * L + 32 * lt];
+                tt[u][lt] = ok ? v : 0.f;
+            }
+        }
+    };
+    load(m_begin, ga, ta);
+    for (int64_t m = m_begin; m < m_end; m += 16) {
+        const int64_t mn = (m + 16 < m_end) ? m + 16 : m;
+        load(mn, gb, tb);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const unsigned w = (t < 4) ? ga[u].x : ga[u].y;
+                const float bval = (float)((w >> (8 * (t & 3))) & 0xffu);
+#pragma unroll
+                for (int lt = 0; lt < LT; ++lt)
+                    acc[t][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[u][lt], bval, acc[t][lt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ga[u] = gb[u];
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt) ta[u][lt] = tb[u][lt];
+        }
+    }
+    // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h (+32 lt), col = c -> sample n0 + 8c + t
+    float* yp = Ypart + (wchunk * Npad) * L;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int64_t n = n0 + 8 * c + t;
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                // regs e..e+3 are 4 consecutive j: one 16-byte store
+                const int j = 32 * lt + 8 * (e >> 2) + 4 * h;
+                float4 o;
+                o.x = acc[t][lt][e]; o.y = acc[t][lt][e + 1]; o.z = acc[t][lt][e + 2]; o.w = acc[t][lt][e + 3];
+                *reinterpret_cast<float4*>(yp + n * L + j) = o;
+            }
+    }
+}
+
+void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Tp, int L,
+                    float* Ypart, const GttPlan& plan) {
+    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    const dim3 grid((unsigned)plan.grid), blk(256);
+    if (L == 32)
+        hipLaunchKernelGGL((k_gtt_f32<1>), grid, blk, 0, st, G, ldg, M, Npad, Tp, Ypart, ngroups, plan.rows_per_wave);
+    else
+        hipLaunchKernelGGL((k_gtt_f32<2>), grid, blk, 0, st, G, ldg, M, Npad, Tp, Ypart, ngroups, plan.rows_per_wave);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_y(const float* __restrict__ Ypart, int W, int64_t Npad, int64_t N, int L,
+                                                  const double* __restrict__ cvec, double* __restrict__ Y) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * L) return;
+    const int j = (int)(e % L);
+    double a = cvec[j];
+    const int64_t stride = Npad * L;
+    for (int w = 0; w < W; ++w) a += (double)Ypart[w * stride + e];
+    Y[e] = a;
+}
+void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, int64_t N, int L, const double* c, double* Y) {
+    const int64_t total = N * L;
+    hipLaunchKernelGGL(k_reduce_y, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, L, c, Y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small helpers (HBM/latency bound, negligible next to K1/K2).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_sum_partials(const T* __restrict__ part, int64_t P, int64_t E,
+                                                      double* __restrict__ out) {
+    // one block per 64 outputs; 4 waves stride over P, LDS combine in fixed order -> deterministic
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    double a = 0.0;
+    if (e < E)
+        for (int64_t p = wv; p < P; p += 4) a += (double)part[p * E + e];
+    red[wv][lane] = a;
+    __syncthreads();
+    if (wv == 0 && e < E) out[e] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out) {
+    hipLaunchKernelGGL((k_sum_partials<float>), dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, part, P, E, out);
+}
+void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out) {
+    hipLaunchKernelGGL((k_sum_partials<double>), dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, part, P, E, out);
+}
+
+// Gram: part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c]  (f64 accumulate)
+constexpr int kGramRowsPerBlock = 512;
+int64_t gram_num_parts(int64_t rows) { return (rows + kGramRowsPerBlock - 1) / kGramRowsPerBlock; }
+
+template <typename T, int L>
+__global__ __launch_bounds__(256) void k_gram(const T* __restrict__ X, int64_t rows, double* __restrict__ part) {
+    constexpr int TPR = 256 / L;   // threads per output row a
+    constexpr int CPT = L / TPR;   // output columns per thread
+    __shared__ double tile[32][L + 1];
+    const int a = threadIdx.x / TPR, c0 = (threadIdx.x % TPR) * CPT;
+    double acc[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) acc[k] = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.x * kGramRowsPerBlock;
+    const int64_t r1 = (r0 + kGramRowsPerBlock < rows) ? r0 + kGramRowsPerBlock : rows;
+    for (int64_t rb = r0; rb < r1; rb += 32) {
+        for (int e = threadIdx.x; e < 32 * L; e += 256) {
+            const int rr = e / L, cc = e % L;
+            tile[rr][cc] = (rb + rr < r1) ? (double)X[(rb + rr) * L + cc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = 0; rr < 32; ++rr) {
+            const double xa = tile[rr][a];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) acc[k] += xa * tile[rr][c0 + k];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) part[(int64_t)blockIdx.x * L * L + a * L + c0 + k] = acc[k];
+}
+void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part) {
+    const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
+    if (L == 32) hipLaunchKernelGGL((k_gram<double, 32>), grid, blk, 0, st, X, rows, part);
+    else hipLaunchKernelGGL((k_gram<double, 64>), grid, blk, 0, st, X, rows, part);
+}
+void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part) {
+    const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
+    if (L == 32) hipLaunchKernelGGL((k_gram<float, 32>), grid, blk, 0, st, X, rows, part);
+    else hipLaunchKernelGGL((k_gram<float, 64>), grid, blk, 0, st, X, rows, part);
+}
+
+// X[n][:] <- X[n][:] Z, in place through an LDS row tile; optional f32 copy into Qout (pad rows zeroed)
+template <int L>
+__global__ __launch_bounds__(256) void k_apply_right(double* __restrict__ X, int64_t rows, const double* __restrict__ Z,
+                                                     float* __restrict__ Qout, int64_t rows_pad) {
+    constexpr int RPB = 256 / L;
+    __shared__ double zs[L][L + 1];
+    __shared__ double xs[RPB][L];
+    for (int e = threadIdx.x; e < L * L; e += 256) zs[e / L][e % L] = Z[e];
+    const int rr = threadIdx.x / L, cc = threadIdx.x % L;
+    const int64_t n = (int64_t)blockIdx.x * RPB + rr;
+    xs[rr][cc] = (n < rows) ? X[n * L + cc] : 0.0;
+    __syncthreads();
+    double a = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < L; ++j) a += xs[rr][j] * zs[j][cc];
+    if (n < rows) X[n * L + cc] = a;
+    if (Qout && n < rows_pad) Qout[n * L + cc] = (n < rows) ? (float)a : 0.f;
+}
+void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,
+                                int64_t rows_pad) {
+    const int64_t span = Qout ? rows_pad : rows;
+    if (L == 32) hipLaunchKernelGGL((k_apply_right<32>), dim3((unsigned)((span + 7) / 8)), dim3(256), 0, st, X, rows, Z, Qout, rows_pad);
+    else hipLaunchKernelGGL((k_apply_right<64>), dim3((unsigned)((span + 3) / 4)), dim3(256), 0, st, X, rows, Z, Qout, rows_pad);
+}
+
+// out[n][kc] = sum_j X[row(n)][j] Z[j][kc];  one thread per output element
+__global__ __launch_bounds__(256) void k_rightmul(const float* __restrict__ X, const int64_t* __restrict__ row_ids,
+                                                  int64_t nrows, int L, const double* __restrict__ Z, int K,
+                                                  double* __restrict__ out64, float* __restrict__ out32) {
+    extern __shared__ double zsm[];
+    for (int e = threadIdx.x; e < L * K; e += 256) zsm[e] = Z[e];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nrows * K) return;
+    const int64_t n = t / K;
+    const int kc = (int)(t - n * K);
+    const int64_t src = row_ids ? row_ids[n] : n;
+    const float* x = X + src * L;
+    double a = 0.0;
+    for (int j = 0; j < L; ++j) a += (double)x[j] * zsm[j * K + kc];
+    if (out64) out64[t] = a;
+    if (out32) out32[t] = (float)a;
+}
+void launch_rightmul_f32(hipStream_t st, const float* X, int64_t rows, int L, const double* Z, int K, double* out64,
+                         float* out32) {
+    const int64_t total = rows * K;
+    hipLaunchKernelGGL(k_rightmul, dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X,
+                       (const int64_t*)nullptr, rows, L, Z, K, out64, out32);
+}
+void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
+                                const double* Z, int K, float* out32) {
+    const int64_t total = nrows * K;
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_rightmul, dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X, row_ids,
+                       nrows, L, Z, K, (double*)nullptr, out32);
+}
+
+constexpr int kColsumRowsPerBlock = 2048;
+int64_t colsum_num_parts(int64_t rows) { return (rows + kColsumRowsPerBlock - 1) / kColsumRowsPerBlock; }
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t rows, int L, double* __restrict__ part) {
+    __shared__ double red[256];
+    const int cc = threadIdx.x % L, rg = threadIdx.x / L, nrg = 256 / L;
+    const int64_t r0 = (int64_t)blockIdx.x * kColsumRowsPerBlock;
+    const int64_t r1 = (r0 + kColsumRowsPerBlock < rows) ? r0 + kColsumRowsPerBlock : rows;
+    double a = 0.0;
+    for (int64_t n = r0 + rg; n < r1; n += nrg) a += (double)X[n * L + cc];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < nrg; ++g) a += red[g * L + cc];
+        part[(int64_t)blockIdx.x * L + cc] = a;
+    }
+}
+void launch_colsum_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part) {
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)colsum_num_parts(rows)), dim3(256), 0, st, X, rows, L, part);
+}
+
+// sign of the first element with maximal |x| per column; one block per column
+__global__ __launch_bounds__(256) void k_col_sign(const double* __restrict__ X, int64_t rows, int K, int* __restrict__ sign) {
+    __shared__ double bv[256];
+    __shared__ long long bi[256];
+    const int col = blockIdx.x;
+    double best = -1.0; long long idx = -1;
+    for (int64_t n = threadIdx.x; n < rows; n += 256) {
+        const double a = fabs(X[n * K + col]);
+        if (a > best) { best = a; idx = n; }
+    }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const double ob = bv[threadIdx.x + s]; const long long oi = bi[threadIdx.x + s];
+            if (ob > bv[threadIdx.x] || (ob == bv[threadIdx.x] && oi >= 0 && (bi[threadIdx.x] < 0 || oi < bi[threadIdx.x]))) {
+                bv[threadIdx.x] = ob; bi[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sign[col] = (bi[0] >= 0 && X[bi[0] * K + col] < 0.0) ? -1 : 1;
+}
+void launch_col_sign(hipStream_t st, const double* X, int64_t rows, int K, int* sign) {
+    hipLaunchKernelGGL(k_col_sign, dim3(K), dim3(256), 0, st, X, rows, K, sign);
+}
+__global__ void k_scale_cols(double* X64, float* X32, int64_t rows, int K, const int* sign) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * K) return;
+    const double v = X64[t] * (double)sign[t % K];
+    X64[t] = v;
+    if (X32) X32[t] = (float)v;
+}
+void launch_scale_cols(hipStream_t st, double* X64, float* X32, int64_t rows, int K, const int* sign) {
+    const int64_t total = rows * K;
+    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, X64, X32, rows, K, sign);
+}
+__global__ void k_f64_to_f32(const double* in, float* out, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) out[t] = (float)in[t];
+}
+void launch_f64_to_f32(hipStream_t st, const double* in, float* out, int64_t n) {
+    hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+}
+__global__ void k_fill_f32(float* p, int64_t n, float v) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) p[t] = v;
+}
+void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v) {
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}
+
+
+__global__ void k_expand_loadings(const float* __restrict__ load, const int64_t* __restrict__ rows, int64_t n_pca, int k,
+                                  int L, float* __restrict__ Tp) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_pca * k) return;
+    const int64_t a = t / k;
+    const int c = (int)(t - a * k);
+    Tp[rows[a] * L + c] = load[t];
+}
+void launch_expand_loadings(hipStream_t st, const float* load, const int64_t* rows, int64_t n_pca, int k, int L, float* Tp) {
+    const int64_t total = n_pca * k;
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_expand_loadings, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, load, rows, n_pca, k, L, Tp);
+}
+
+// one wave = 64 rows; lane = row; loops over the L columns (row stride L floats: L2-friendly, tiny kernel)
+__global__ __launch_bounds__(256) void k_scale_rows(float* __restrict__ X, int64_t M, int L, const float* __restrict__ r,
+                                                    const float* __restrict__ b, float* __restrict__ cpart) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (M + 63) / 64) return;
+    const int64_t i = wave * 64 + lane;
+    const bool live = i < M;
+    const float ri = live ? r[i] : 0.f, bi = live ? b[i] : 0.f;
+    for (int j = 0; j < L; ++j) {
+        const float x = live ? X[i * L + j] : 0.f;
+        if (live) X[i * L + j] = ri * x;
+        float cv = bi * x;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cv += __shfl_xor(cv, o);
+        if (lane == 0) cpart[wave * L + j] = cv;
+    }
+}
+void launch_scale_rows(hipStream_t st, float* X, int64_t M, int L, const float* r, const float* b, float* cpart) {
+    const int64_t waves = (M + 63) / 64;
+    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, X, M, L, r, b, cpart);
+}
+
+}  // namespace gpca

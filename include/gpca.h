@@ -1,0 +1,160 @@
+/*
+ * gpca.h -- C ABI of the MI355X-native randomized-PCA engine (libgpca.so).
+ *
+ * Drop-in boundary for ONE hot path of SauersML/genomic_pca: per-SNP standardisation fused into
+ * the randomized-SVD core.  Plain C types only: opaque handle, caller-owned host buffers,
+ * integer status codes, no exceptions, no C++/torch types.  A Rust host binds these with a
+ * 30-line `extern "C"` block.
+ *
+ * The reference's seam is a PULL model (the solver calls the accessor for f32 blocks):
+ *   trait PcaReadyGenotypeAccessor          /root/reference/src/prepare.rs:1838-2030
+ *   PCA::new / rfit / transform             /root/reference/src/main.rs:602,648-660
+ *   EigenSNPCoreAlgorithm::compute_pca      /root/reference/src/main.rs:359-366
+ * This ABI is a PUSH model: genotypes are uploaded once (1 B or 0.25 B per genotype), stay in
+ * HBM, and every pass over them runs on the device; the pull API survives as
+ * gpca_standardize_block() for boundary parity.
+ *
+ * Threading: a handle is single-owner (one host thread, one GPU).  Functions return
+ * GPCA_OK (0) or a negative gpca_status; gpca_last_error() gives the human string.
+ */
+#ifndef GPCA_H
+#define GPCA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define GPCA_API __attribute__((visibility("default")))
+#else
+#define GPCA_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPCA_VERSION 100 /* 0.1.0 */
+#define GPCA_MISSING_I8 (-127) /* bed_reader i8 missing code, prepare.rs:1224 */
+
+typedef struct gpca_handle gpca_handle;
+
+typedef enum gpca_status {
+    GPCA_OK = 0,
+    GPCA_ERR_BAD_ARG = -1,
+    GPCA_ERR_OOM = -2,
+    GPCA_ERR_HIP = -3,
+    GPCA_ERR_RCCL = -4,
+    /* replaces the hard error of prepare.rs:1909-1911, 1961-1963, 2008-2009 */
+    GPCA_ERR_MISSING_GENOTYPE = -5,
+    GPCA_ERR_NOT_CONVERGED = -6, /* sketch lost rank (CholQR pivot <= 0) */
+    GPCA_ERR_STATE = -7,         /* call order: e.g. rsvd before stats */
+    GPCA_ERR_NO_DEVICE = -8,
+    GPCA_ERR_INVALID_GENOTYPE = -9 /* a kept SNP holds a value outside {0,1,2} */
+} gpca_status;
+
+/* Arithmetic used by the two tall-skinny products. */
+typedef enum gpca_precision {
+    GPCA_PREC_F32_MFMA = 0, /* v_mfma_f32_32x32x2_f32, exact f32 FMA chains */
+    GPCA_PREC_I8_EXACT = 1  /* v_mfma_i32_32x32x32_i8 on fixed-point digits of the skinny operand */
+} gpca_precision;
+
+typedef struct gpca_config {
+    int32_t device;    /* HIP ordinal; -1 = current device */
+    int32_t precision; /* gpca_precision */
+    int32_t reserved[6];
+} gpca_config;
+
+/* SNP QC thresholds = MicroarrayDataPreparerConfig, main.rs:302-309 / prepare.rs:1281-1311,1363.
+ * Effective reference defaults (clap, main.rs:545-560): 0.98 / 0.01 / 1e-6.
+ * "no filtering" = {0, 0, 1.0}: only the nv==0, monomorphic (1e-9) and variance (1e-9) guards act. */
+typedef struct gpca_qc_config {
+    double min_snp_call_rate;   /* drop if n_valid/N <  this         prepare.rs:1283-1284 */
+    double min_snp_maf;         /* drop if min(p,1-p) < this         prepare.rs:1296-1299 */
+    double max_snp_hwe_p_value; /* if < 1: drop if HWE p <= this     prepare.rs:1306-1311 */
+} gpca_qc_config;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+GPCA_API int gpca_version(void);
+GPCA_API const char* gpca_status_string(int status);
+GPCA_API int gpca_create(const gpca_config* cfg, gpca_handle** out);
+GPCA_API int gpca_destroy(gpca_handle* h);
+GPCA_API const char* gpca_last_error(gpca_handle* h);
+
+/* ---- genotype residency (replaces IoService + bed_reader reads, prepare.rs:622-629,682-693,
+ *      and build_matrix's N x M f64, vcf.rs:317-345) ------------------------------------- */
+/* SNP-major int8 dosages (count of allele 1: 0/1/2, -127 missing); row i at snp_major + i*ld. */
+GPCA_API int gpca_upload_genotypes_i8(gpca_handle* h, const int8_t* snp_major, int64_t M, int64_t N, int64_t ld);
+/* PLINK .bed payload after the 3-byte magic: M rows of ceil(N/4) bytes, 2 bits/sample LSB-first;
+ * decoded on the device with count_a1 semantics (00->2, 10->1, 11->0, 01->missing). */
+GPCA_API int gpca_upload_bed2bit(gpca_handle* h, const uint8_t* bed_rows, int64_t M, int64_t N);
+/* Synthetic workload of SURVEY.md 8(d), generated on the device (bit-identical to
+ * oracle/gpca_oracle.c:orc_synth_genotypes).  thresh: host uint32 [M][P] = floor(p*2^32). */
+GPCA_API int gpca_synth_genotypes(gpca_handle* h, int64_t M, int64_t N, uint64_t seed, const uint32_t* thresh,
+                         int32_t P, int64_t snp_offset);
+GPCA_API int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t ld);
+GPCA_API int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N);
+
+/* ---- a1/a3: SNP QC + standardisation parameters (prepare.rs:1100-1422, 1641-1745) -------- */
+/* Any of mu/sigma/keep may be NULL.  mu, sigma are the f32 values the reference stores
+ * (prepare.rs:1313,1364); 0 for dropped SNPs. */
+GPCA_API int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* mu, float* sigma, uint8_t* keep);
+/* counts[i] = {n_valid, n_hom0, n_het, n_hom2}; reason[i]: 0 kept, 1 call-rate, 2 no valid,
+ * 3 MAF, 4 monomorphic, 5 HWE, 6 variance.  Either may be NULL. */
+GPCA_API int gpca_get_snp_qc_detail(gpca_handle* h, uint32_t* counts, uint8_t* reason);
+/* Caller-supplied parameters instead of gpca_snp_stats (e.g. LD-block restriction via keep). */
+GPCA_API int gpca_set_standardization(gpca_handle* h, const float* mu, const float* sigma, const uint8_t* keep);
+/* Host helper, same branches as prepare.rs:1641-1745. */
+GPCA_API double gpca_hwe_chi_squared_p_value(uint64_t n_hom1, uint64_t n_het, uint64_t n_hom2);
+
+/* ---- a2/a7: the pull API (prepare.rs:1838-2030) ------------------------------------------ */
+/* PcaSnpId = rank among kept SNPs; QcSampleId = sample column.  out: f32 [ns][nj], C order.
+ * Returns GPCA_ERR_MISSING_GENOTYPE if any requested genotype is -127 (message names the ids). */
+GPCA_API int gpca_standardize_block(gpca_handle* h, const int64_t* pca_snp_ids, int64_t ns,
+                           const int64_t* qc_sample_ids, int64_t nj, float* out);
+GPCA_API int64_t gpca_num_pca_snps(gpca_handle* h);   /* prepare.rs:2024-2026 */
+GPCA_API int64_t gpca_num_qc_samples(gpca_handle* h); /* prepare.rs:2027-2029 */
+/* original row (BIM index) of every PCA SNP, length gpca_num_pca_snps; prepare.rs:1833-1835 */
+GPCA_API int gpca_get_pca_snp_rows(gpca_handle* h, int64_t* rows);
+
+/* ---- a5/a6: randomized PCA (PCA::rfit main.rs:648-656; compute_pca main.rs:365) ---------- */
+/* l = k + oversample columns (<= 64); power_iters QR-stabilised iterations; Omega from
+ * Philox4x32-10 keyed by seed.  Requires stats.  Results stay on the device until fetched. */
+GPCA_API int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed);
+GPCA_API int gpca_get_scores(gpca_handle* h, float* out /* [N][k] */);       /* main.rs:389 */
+GPCA_API int gpca_get_scores_f64(gpca_handle* h, double* out /* [N][k] */);  /* main.rs:659 (f64 path) */
+GPCA_API int gpca_get_eigenvalues(gpca_handle* h, double* out /* [k] */);    /* main.rs:394 */
+GPCA_API int gpca_get_singular_values(gpca_handle* h, double* out /* [k+oversample] */);
+GPCA_API int gpca_get_loadings(gpca_handle* h, float* out /* [num_pca_snps][k] */); /* main.rs:407 */
+/* PCA::transform (main.rs:659) on the resident matrix: scores = A^T * loadings, f64 [N][k]. */
+GPCA_API int gpca_transform(gpca_handle* h, double* out);
+
+/* ---- e: SNP-row sharding across GPUs ------------------------------------------------------- */
+#define GPCA_UNIQUE_ID_BYTES 128
+GPCA_API int gpca_comm_get_unique_id(void* out_id /* GPCA_UNIQUE_ID_BYTES */);
+/* This handle holds rows [snp_offset, snp_offset + M) of a matrix sharded over `world` ranks.
+ * Creates an RCCL communicator; the N x l sketch and l x l Gram blocks are all-reduced. */
+GPCA_API int gpca_comm_init(gpca_handle* h, int32_t world, int32_t rank, const void* unique_id, int64_t snp_offset);
+/* Host-staged all-reduce hook (sum, in place, f64) used instead of RCCL when set: lets any
+ * transport (MPI, gloo) carry the exchange; also how the CPU tests exercise the N>1 path. */
+typedef int (*gpca_allreduce_fn)(void* user, double* host_buf, int64_t count);
+GPCA_API int gpca_set_allreduce_hook(gpca_handle* h, gpca_allreduce_fn fn, void* user, int32_t world,
+                            int32_t rank, int64_t snp_offset);
+
+/* ---- d: measurement ------------------------------------------------------------------------- */
+typedef struct gpca_kernel_timing {
+    char name[32];
+    int64_t launches;
+    double total_ms;   /* sum of HIP-event durations on the engine's stream */
+    double flops;      /* algorithmic (un-padded) flops summed over those launches */
+    double bytes;      /* algorithmic HBM bytes summed over those launches */
+} gpca_kernel_timing;
+/* Timings accumulated since the last gpca_reset_timings (events resolved lazily here). */
+GPCA_API int gpca_get_timings(gpca_handle* h, gpca_kernel_timing* out, int32_t cap, int32_t* n);
+GPCA_API int gpca_reset_timings(gpca_handle* h);
+GPCA_API int gpca_enable_timings(gpca_handle* h, int32_t on);
+GPCA_API int gpca_synchronize(gpca_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPCA_H */

@@ -1,0 +1,220 @@
+"""CPU oracle for the genomic_pca hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  Nothing under ``genomic_pca_amd/`` imports it; the product fails loudly without
+its HIP library.
+
+Two layers:
+  * ctypes bindings to ``oracle/gpca_oracle.c`` (the line-by-line restatement; citations there);
+  * numpy: exact f64 PCA via ``eigh`` of the N x N Gram of the standardised matrix -- the
+    pattern of the reference's own cross-check ``tests/pca.py:81-141`` but with the Rust
+    normalisation ``(g - mu) / sigma`` (``prepare.rs:1294,1357-1364,1948-1988``).
+
+Parity status: rSVD is "parity unpinned" (algorithm lives in the un-vendored ``efficient_pca``
+crate, ``Cargo.toml:30``; the reference holds no golden vectors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from fractions import Fraction
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MISSING = -127  # prepare.rs:1224
+
+
+def build(force: bool = False) -> None:
+    need = force or any(
+        not os.path.exists(os.path.join(_HERE, f)) for f in ("liboracle_f64.so", "liboracle_f32.so")
+    )
+    if need:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+_libs: dict = {}
+
+
+def lib(real: str = "f64") -> C.CDLL:
+    if real not in _libs:
+        build()
+        L = C.CDLL(os.path.join(_HERE, f"liboracle_{real}.so"))
+        L.orc_hwe_p.restype = C.c_double
+        L.orc_hwe_p.argtypes = [C.c_uint64] * 3
+        L.orc_standardize_block.restype = C.c_int64
+        L.orc_rsvd.restype = C.c_int
+        L.orc_cholqr2.restype = C.c_int
+        L.orc_sizeof_real.restype = C.c_int
+        L.orc_num_threads.restype = C.c_int
+        _libs[real] = L
+    return _libs[real]
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _real_dtype(real: str):
+    return np.float64 if real == "f64" else np.float32
+
+
+# ----------------------------------------------------------------------------- philox / synth
+def philox(c, k) -> np.ndarray:
+    out = np.zeros(4, np.uint32)
+    lib().orc_philox(*[C.c_uint32(int(x)) for x in c], *[C.c_uint32(int(x)) for x in k], _p(out, C.c_uint32))
+    return out
+
+
+def synth_genotypes(M: int, N: int, seed: int, thresh: np.ndarray, snp_offset: int = 0, ld: int | None = None) -> np.ndarray:
+    ld = ld or N
+    G = np.zeros((M, ld), np.int8)
+    thresh = np.ascontiguousarray(thresh, np.uint32)
+    lib().orc_synth_genotypes(_p(G, C.c_int8), C.c_int64(M), C.c_int64(N), C.c_int64(ld), C.c_int64(snp_offset),
+                              C.c_uint64(seed), _p(thresh, C.c_uint32), C.c_int(thresh.shape[1]))
+    return G
+
+
+def omega(M: int, l: int, seed: int, snp_offset: int = 0) -> np.ndarray:
+    Om = np.zeros((M, l), np.float64)
+    lib().orc_omega(_p(Om, C.c_double), C.c_int64(M), C.c_int(l), C.c_int64(snp_offset), C.c_uint64(seed))
+    return Om
+
+
+# ----------------------------------------------------------------------------- a1 / a3 / a2
+def hwe_p(n0: int, n1: int, n2: int) -> float:
+    """prepare.rs:1641-1745."""
+    return float(lib().orc_hwe_p(int(n0), int(n1), int(n2)))
+
+
+def snp_stats(G: np.ndarray, N: int | None = None, min_call_rate=0.98, min_maf=0.01, max_hwe_p=1e-6):
+    """prepare.rs:1216-1375 (two-pass f64).  G: int8 [M, ld] SNP-major.  Returns dict."""
+    G = np.ascontiguousarray(G, np.int8)
+    M, ld = G.shape
+    N = N or ld
+    mu = np.zeros(M, np.float32); sg = np.zeros(M, np.float32)
+    keep = np.zeros(M, np.uint8); reason = np.zeros(M, np.uint8)
+    counts = np.zeros((M, 4), np.uint32); s = np.zeros(M); ss = np.zeros(M)
+    lib().orc_snp_stats(_p(G, C.c_int8), C.c_int64(M), C.c_int64(N), C.c_int64(ld), C.c_double(min_call_rate),
+                        C.c_double(min_maf), C.c_double(max_hwe_p), _p(mu, C.c_float), _p(sg, C.c_float),
+                        _p(keep, C.c_uint8), _p(reason, C.c_uint8), _p(counts, C.c_uint32), _p(s, C.c_double),
+                        _p(ss, C.c_double))
+    return dict(mu=mu, sigma=sg, keep=keep, reason=reason, counts=counts, sum=s, ss=ss)
+
+
+def snp_sigma_exact(row: np.ndarray) -> tuple[float, float]:
+    """Exact-rational mean and sample s.d. of the valid genotypes of one SNP (python ints),
+    rounded once to f64 then f32 -- the mathematically exact value prepare.rs:1294-1364 approximates."""
+    v = [int(x) for x in row if int(x) != MISSING]
+    n = len(v)
+    s1 = sum(v); s2 = sum(x * x for x in v)
+    mean = Fraction(s1, n)
+    var = Fraction(n * s2 - s1 * s1, n * (n - 1)) if n >= 2 else Fraction(0)
+    return float(np.float32(float(mean))), float(np.float32(np.sqrt(float(var))))
+
+
+def standardize_block(G: np.ndarray, mu, sigma, snp_ids, sample_ids):
+    """prepare.rs:1884-2016.  Returns (block f32 [ns, nj], err) ; err = None or (snp_pos, sample_pos)."""
+    G = np.ascontiguousarray(G, np.int8)
+    snp_ids = np.ascontiguousarray(snp_ids, np.int64); sample_ids = np.ascontiguousarray(sample_ids, np.int64)
+    mu = np.ascontiguousarray(mu, np.float32); sigma = np.ascontiguousarray(sigma, np.float32)
+    out = np.zeros((len(snp_ids), len(sample_ids)), np.float32)
+    rc = lib().orc_standardize_block(_p(G, C.c_int8), C.c_int64(G.shape[1]), _p(mu, C.c_float), _p(sigma, C.c_float),
+                                     _p(snp_ids, C.c_int64), C.c_int64(len(snp_ids)), _p(sample_ids, C.c_int64),
+                                     C.c_int64(len(sample_ids)), _p(out, C.c_float))
+    if rc:
+        return out, divmod(rc - 1, len(sample_ids))
+    return out, None
+
+
+def scale_shift(mu, sigma, keep=None):
+    """r = 1/sigma, b = -mu * r in f32 (prepare.rs:1948-1949); zeros for dropped / sigma<1e-9 SNPs (:1899)."""
+    mu = np.asarray(mu, np.float32); sigma = np.asarray(sigma, np.float32)
+    ok = np.abs(sigma) >= np.float32(1e-9)
+    if keep is not None:
+        ok &= np.asarray(keep).astype(bool)
+    r = np.zeros_like(sigma); b = np.zeros_like(sigma)
+    r[ok] = np.float32(1.0) / sigma[ok]
+    b[ok] = -mu[ok] * r[ok]
+    return r, b
+
+
+# ----------------------------------------------------------------------------- a5 / a6
+def prod_AQ(G, N, r, b, Q, real="f64"):
+    G = np.ascontiguousarray(G, np.int8); dt = _real_dtype(real)
+    Q = np.ascontiguousarray(Q, dt); M, ld = G.shape; l = Q.shape[1]
+    T = np.zeros((M, l), dt)
+    ct = C.c_double if real == "f64" else C.c_float
+    lib(real).orc_prod_AQ(_p(G, C.c_int8), C.c_int64(M), C.c_int64(N), C.c_int64(ld), _p(np.ascontiguousarray(r, np.float32), C.c_float),
+                          _p(np.ascontiguousarray(b, np.float32), C.c_float), _p(Q, ct), C.c_int(l), _p(T, ct))
+    return T
+
+
+def prod_AtT(G, N, r, b, T, real="f64"):
+    G = np.ascontiguousarray(G, np.int8); dt = _real_dtype(real)
+    T = np.ascontiguousarray(T, dt); M, ld = G.shape; l = T.shape[1]
+    Y = np.zeros((N, l), np.float64)
+    ct = C.c_double if real == "f64" else C.c_float
+    lib(real).orc_prod_AtT(_p(G, C.c_int8), C.c_int64(M), C.c_int64(N), C.c_int64(ld), _p(np.ascontiguousarray(r, np.float32), C.c_float),
+                           _p(np.ascontiguousarray(b, np.float32), C.c_float), _p(T, ct), C.c_int(l), _p(Y, C.c_double))
+    return Y
+
+
+def cholqr2(Y, real="f64"):
+    Y = np.array(Y, np.float64, order="C", copy=True); N, l = Y.shape
+    dt = _real_dtype(real); Q = np.zeros((N, l), dt)
+    ct = C.c_double if real == "f64" else C.c_float
+    rc = lib(real).orc_cholqr2(_p(Y, C.c_double), C.c_int64(N), C.c_int(l), _p(Q, ct))
+    if rc:
+        raise np.linalg.LinAlgError(f"CholQR pivot {rc - 1} not positive")
+    return Q
+
+
+def rsvd(G, N, r, b, k, oversample=10, power_iters=2, seed=1, snp_offset=0, real="f64"):
+    """The restated randomized PCA (oracle/gpca_oracle.c:orc_rsvd).  Returns dict of f64 arrays."""
+    G = np.ascontiguousarray(G, np.int8); M, ld = G.shape
+    r = np.ascontiguousarray(r, np.float32); b = np.ascontiguousarray(b, np.float32)
+    l = k + oversample
+    scores = np.zeros((N, k)); ev = np.zeros(k); load = np.zeros((M, k)); sv = np.zeros(l)
+    rc = lib(real).orc_rsvd(_p(G, C.c_int8), C.c_int64(M), C.c_int64(N), C.c_int64(ld), _p(r, C.c_float), _p(b, C.c_float),
+                            C.c_int(k), C.c_int(oversample), C.c_int(power_iters), C.c_uint64(seed), C.c_int64(snp_offset),
+                            _p(scores, C.c_double), _p(ev, C.c_double), _p(load, C.c_double), _p(sv, C.c_double))
+    if rc:
+        raise np.linalg.LinAlgError(f"orc_rsvd failed rc={rc}")
+    return dict(scores=scores, eigenvalues=ev, loadings=load, singular_values=sv)
+
+
+def standardized_dense(G, N, r, b) -> np.ndarray:
+    """A[i, n] = g * r_i + b_i in f64 from the f32 r, b (M x N dense; small cases only)."""
+    return np.asarray(G[:, :N], np.float64) * np.asarray(r, np.float64)[:, None] + np.asarray(b, np.float64)[:, None]
+
+
+def exact_pca(G, N, r, b, k):
+    """Exact f64 PCA of X = A^T (samples x variants): eigh of the N x N Gram A^T A
+    (pattern of tests/pca.py:81-141).  scores = V * s, loadings = A V / s, eigenvalues = s^2/(N-1)."""
+    A = standardized_dense(G, N, r, b)
+    gram = A.T @ A
+    w, V = np.linalg.eigh(gram)
+    w = w[::-1][:k]; V = V[:, ::-1][:, :k]
+    s = np.sqrt(np.maximum(w, 0))
+    scores = V * s
+    load = (A @ V) / np.where(s > 0, s, 1)
+    sgn = np.sign(scores[np.abs(scores).argmax(axis=0), np.arange(k)])
+    return dict(scores=scores * sgn, eigenvalues=w / (N - 1), loadings=load * sgn, singular_values=s)
+
+
+def sign_align(X, ref):
+    """Flip columns of X to maximise agreement with ref."""
+    s = np.sign(np.sum(X * ref, axis=0)); s[s == 0] = 1
+    return X * s
+
+
+def max_abs_dpc(X, ref):
+    """BASELINE.json metric: max over PCs of max |unit-norm, sign-aligned PC difference|."""
+    Xn = X / np.linalg.norm(X, axis=0); Rn = ref / np.linalg.norm(ref, axis=0)
+    return float(np.max(np.abs(sign_align(Xn, Rn) - Rn)))
+
+
+def num_threads(real="f64") -> int:
+    return int(lib(real).orc_num_threads())

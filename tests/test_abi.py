@@ -1,0 +1,69 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/gpca.h declares (no compute)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gpca.h")).read()
+    return sorted(set(re.findall(r"GPCA_API[^;(]*?\b(gpca_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(gpca):
+    lib = gpca.load()
+    decl = _declared()
+    assert len(decl) >= 30
+    for name in decl:
+        assert hasattr(lib, name), f"libgpca.so does not export {name}"
+    from genomic_pca_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == decl, "ctypes prototypes and gpca.h disagree"
+
+
+def test_no_undeclared_exports(gpca):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", gpca.LIB_PATH], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and "gpca_" in l)
+    assert exported == _declared()
+
+
+def test_version_and_strings(gpca):
+    lib = gpca.load()
+    assert lib.gpca_version() == 100
+    assert lib.gpca_status_string(0) == b"ok"
+    assert b"missing genotype" in lib.gpca_status_string(-5)
+
+
+def test_fails_loudly_without_gpu(gpca):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(gpca.GpcaError) as e:
+        gpca.GpcaEngine()
+    assert e.value.status == -8 and "no CPU fallback" in str(e.value)
+
+
+def test_host_hwe_helper_matches_oracle(gpca, oracle):
+    for n in [(0, 0, 0), (10, 50, 40), (100, 0, 100), (25, 50, 25), (3, 0, 0), (1, 2, 400), (1234, 5000, 4100)]:
+        assert gpca.GpcaEngine.hwe_chi_squared_p_value(*n) == oracle.hwe_p(*n)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "genomic_pca_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_shard_rows_cover(gpca):
+    for M, W in [(1000000, 8), (1000, 3), (127, 4), (128, 2), (5, 8)]:
+        spans = [gpca.shard_rows(M, W, r) for r in range(W)]
+        assert spans[0][0] == 0 and spans[-1][1] == M
+        for a, b in zip(spans, spans[1:]):
+            assert a[1] == b[0]
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 2 * 128 or M < 128 * W

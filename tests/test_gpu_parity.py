@@ -1,0 +1,334 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
+seeded inputs.  Bars: bit-exact for integer/byte/index work and for the f32 standardise formula;
+1e-4 (north_star) for the floating-point randomized PCA, sign-aligned, against the oracle's f64
+restatement with the same seed."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_PC = 1e-4   # BASELINE.json: max|dPC| vs ref, unit-norm sign-aligned
+TOL_EV = 1e-4   # relative eigenvalue error
+
+
+def _make(gpca, oracle, engine, M, N, P, seed, fst=0.1, missing=0.0):
+    th = gpca.synth_thresholds(M, P, seed=seed, fst=fst)
+    engine.synth_genotypes(M, N, seed, th)
+    G = engine.download_genotypes_i8()
+    return th, G
+
+
+def test_native_library_is_the_one_loaded(gpca):
+    lib = gpca.load()
+    assert lib._name.endswith("genomic_pca_amd/libgpca.so")
+    maps = open("/proc/self/maps").read()
+    assert "libgpca.so" in maps
+
+
+@pytest.mark.parametrize("M,N,P", [(1000, 333, 3), (257, 256, 5), (64, 1000, 2), (4096, 64, 3), (3, 7, 2)])
+def test_synth_bit_exact(gpca, oracle, engine, M, N, P):
+    th, G = _make(gpca, oracle, engine, M, N, P, seed=42)
+    assert np.array_equal(G, oracle.synth_genotypes(M, N, 42, th))
+    assert set(np.unique(G)) <= {0, 1, 2}
+
+
+def test_synth_shard_offset(gpca, oracle, engine):
+    M, N, P, off = 300, 130, 3, 777
+    th = gpca.synth_thresholds(M, P, seed=7, snp_offset=off)
+    engine.synth_genotypes(M, N, 7, th, snp_offset=off)
+    assert np.array_equal(engine.download_genotypes_i8(), oracle.synth_genotypes(M, N, 7, th, snp_offset=off))
+
+
+def test_upload_roundtrip_ragged(gpca, engine):
+    rng = np.random.default_rng(0)
+    for M, N in [(5, 1), (17, 255), (33, 257), (2, 1024)]:
+        G = rng.integers(0, 3, size=(M, N), dtype=np.int8)
+        engine.upload_genotypes_i8(G)
+        assert engine.dims() == (M, N)
+        assert np.array_equal(engine.download_genotypes_i8(), G)
+    # strided source (ld > N)
+    big = rng.integers(0, 3, size=(9, 700), dtype=np.int8)
+    engine.upload_genotypes_i8(big[:, :300])
+    assert np.array_equal(engine.download_genotypes_i8(), big[:, :300])
+
+
+def _inject(G, rng, frac_missing=0.01):
+    G = G.copy()
+    m = rng.random(G.shape) < frac_missing
+    G[m] = -127
+    return G
+
+
+@pytest.mark.parametrize("M,N", [(2000, 500), (300, 1023), (129, 64), (50, 2049)])
+def test_snp_stats_parity(gpca, oracle, engine, M, N):
+    rng = np.random.default_rng(M + N)
+    th = gpca.synth_thresholds(M, 3, seed=3, fst=0.1)
+    G = oracle.synth_genotypes(M, N, 3, th)
+    G = _inject(G, rng, 0.02)
+    G[0] = 0; G[1] = 2; G[2] = -127; G[3, : N // 2] = -127          # monomorphic / all-missing / low call rate
+    G[4] = np.where(np.arange(N) % 2 == 0, 0, 2)                     # no hets -> HWE failure
+    engine.upload_genotypes_i8(G)
+    for qc in [gpca.QcConfig.none(), gpca.QcConfig(), gpca.QcConfig(0.9, 0.05, 1e-3)]:
+        st = engine.snp_stats(qc)
+        counts, reason = engine.snp_qc_detail()
+        ref = oracle.snp_stats(G, N, qc.min_snp_call_rate, qc.min_snp_maf, qc.max_snp_hwe_p_value)
+        assert np.array_equal(counts, ref["counts"])                 # integers: bit-exact
+        assert np.array_equal(st["keep"], ref["keep"])
+        assert np.array_equal(reason, ref["reason"])
+        assert np.array_equal(st["mu"], ref["mu"])                   # exact integer sum / n, one rounding
+        # sigma: device forms SS exactly from integers; the reference's two-pass f64 agrees to <= 1 f32 ulp
+        d = np.abs(st["sigma"].astype(np.float64) - ref["sigma"].astype(np.float64))
+        assert np.all(d <= np.spacing(ref["sigma"]))
+        kept = np.nonzero(ref["keep"])[0]
+        for i in kept[:40]:
+            m, s = oracle.snp_sigma_exact(G[i, :N])
+            assert st["mu"][i] == np.float32(m) and st["sigma"][i] == np.float32(s)   # bit-exact vs exact rational
+        assert engine.num_pca_snps() == int(ref["keep"].sum())
+        assert np.array_equal(engine.pca_snp_rows(), kept)
+
+
+def test_snp_stats_weird_values(gpca, oracle, engine):
+    """Bytes outside {0,1,2,-127} take the byte-wise path and keep prepare.rs:1267-1279 semantics."""
+    rng = np.random.default_rng(5)
+    G = rng.integers(0, 3, size=(40, 300), dtype=np.int8)
+    G[3, 17] = 3; G[5, 0] = -1; G[7, 299] = 127; G[9, 100] = -128; G[11, 5] = 5; G[11, 6] = -127
+    engine.upload_genotypes_i8(G)
+    st = engine.snp_stats(gpca.QcConfig.none())
+    counts, reason = engine.snp_qc_detail()
+    ref = oracle.snp_stats(G, 300, 0.0, 0.0, 1.0)
+    assert np.array_equal(counts, ref["counts"]) and np.array_equal(st["keep"], ref["keep"])
+    assert np.array_equal(st["mu"], ref["mu"])
+    assert np.all(np.abs(st["sigma"] - ref["sigma"]) <= np.spacing(ref["sigma"]))
+    with pytest.raises(gpca.GpcaError) as e:
+        engine.rsvd(2, 2, 1, 1)
+    assert e.value.status in (-5, -9)
+
+
+def test_standardize_block_bit_exact(gpca, oracle, engine):
+    M, N = 600, 257
+    th, G = _make(gpca, oracle, engine, M, N, 3, seed=9)
+    st = engine.snp_stats(gpca.QcConfig(0.0, 0.05, 1.0))
+    rows = engine.pca_snp_rows()
+    acc = gpca.MicroarrayGenotypeAccessor(engine)
+    assert acc.num_pca_snps() == len(rows) and acc.num_qc_samples() == N
+    rng = np.random.default_rng(1)
+    for ns, nj in [(1, 1), (7, 257), (len(rows), 3), (200, 100)]:
+        sid = rng.permutation(len(rows))[:ns]
+        cid = rng.permutation(N)[:nj]
+        out = acc.get_standardized_snp_sample_block(sid, cid)
+        ref, err = oracle.standardize_block(G, st["mu"], st["sigma"], rows[sid], cid)
+        assert err is None and out.dtype == np.float32
+        assert np.array_equal(out, ref)                              # fma formula: bit-exact
+    assert acc.get_standardized_snp_sample_block([], [0, 1]).shape == (0, 2)   # prepare.rs:1848-1850
+    with pytest.raises(gpca.GpcaError):
+        acc.get_standardized_snp_sample_block([len(rows)], [0])
+
+
+def test_standardize_block_missing_is_hard_error(gpca, oracle, engine):
+    G = np.array([[0, 1, 2, 1, 0, 2], [0, 1, -127, 1, 2, 2], [1, 1, 0, 2, 0, 1]], np.int8)
+    engine.upload_genotypes_i8(G)
+    engine.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0))
+    with pytest.raises(gpca.GpcaError) as e:
+        engine.standardize_block([0, 1, 2], [0, 2, 4])
+    assert e.value.status == -5
+    # message wording of prepare.rs:1910-1911
+    assert "Unexpected missing genotype (-127i8) in SnpBlockData for PCA SNP ID 1 (original BIM index 1), requested sample index 2" in e.value.message
+    assert np.array_equal(engine.standardize_block([0, 2], [0, 2, 4]),
+                          oracle.standardize_block(G, *[engine.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0))[k] for k in ("mu", "sigma")], [0, 2], [0, 2, 4])[0])
+    with pytest.raises(gpca.GpcaError) as e:     # rsvd refuses kept SNPs with missing genotypes, like the reference's accessor
+        engine.rsvd(1, 1, 1, 1)
+    assert e.value.status == -5
+
+
+def _rsvd_case(gpca, oracle, engine, M, N, P, k, seed, fst, oversample=10, q=2):
+    th, G = _make(gpca, oracle, engine, M, N, P, seed=seed, fst=fst)
+    st = engine.snp_stats(gpca.QcConfig.none())
+    ref_st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(ref_st["mu"], ref_st["sigma"], ref_st["keep"])
+    engine.rsvd(k, oversample, q, seed=seed)
+    R = oracle.rsvd(G, N, r, b, k, oversample, q, seed=seed)
+    return G, r, b, R
+
+
+@pytest.mark.parametrize("M,N,P,k", [(4096, 512, 12, 8), (20000, 1000, 16, 10), (3000, 1500, 10, 6), (999, 257, 8, 4)])
+def test_rsvd_parity(gpca, oracle, engine, M, N, P, k):
+    G, r, b, R = _rsvd_case(gpca, oracle, engine, M, N, P, k, seed=1, fst=0.2)
+    ev = engine.eigenvalues(); sc = engine.scores(); sc64 = engine.scores(f64=True); ld = engine.loadings()
+    assert np.max(np.abs(ev - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+    assert oracle.max_abs_dpc(sc64, R["scores"]) < TOL_PC
+    assert oracle.max_abs_dpc(sc.astype(np.float64), R["scores"]) < TOL_PC
+    assert oracle.max_abs_dpc(ld.astype(np.float64), R["loadings"]) < TOL_PC
+    # absolute scale too (scores = V s, loadings unit norm)
+    al = oracle.sign_align(sc64, R["scores"])
+    assert np.max(np.abs(al - R["scores"])) < 1e-4 * np.max(np.abs(R["scores"]))
+    assert np.allclose(np.linalg.norm(ld.astype(np.float64), axis=0), 1.0, atol=1e-5)
+    # sign convention: largest |score| of each PC is positive
+    assert np.all(sc64[np.abs(sc64).argmax(axis=0), np.arange(k)] > 0)
+    sv = engine.singular_values()
+    assert np.allclose(sv[:k] ** 2 / (N - 1), ev, rtol=1e-12)
+    assert np.all(np.diff(sv) <= 1e-9 * sv[0])
+
+
+def test_rsvd_l64_path(gpca, oracle, engine):
+    """k = 40 -> l = 50 -> two 32-column MFMA tiles (config C5's shape class)."""
+    G, r, b, R = _rsvd_case(gpca, oracle, engine, 6000, 700, 48, 40, seed=3, fst=0.3)
+    ev = engine.eigenvalues()
+    assert np.max(np.abs(ev - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+    # the trailing PCs of this small case sit in the noise bulk: compare the structured ones
+    assert oracle.max_abs_dpc(engine.scores(f64=True)[:, :20], R["scores"][:, :20]) < TOL_PC
+
+
+def test_rsvd_vs_exact_pca(gpca, oracle, engine):
+    """Converged answer: exact f64 PCA (reference's own cross-check pattern, tests/pca.py:81-141)."""
+    G, r, b, R = _rsvd_case(gpca, oracle, engine, 8000, 400, 8, 6, seed=2, fst=0.3)
+    E = oracle.exact_pca(G, 400, r, b, 6)
+    assert np.max(np.abs(engine.eigenvalues() - E["eigenvalues"]) / E["eigenvalues"]) < 1e-3
+    assert oracle.max_abs_dpc(engine.scores(f64=True), E["scores"]) < 2e-2
+
+
+def test_rsvd_with_qc_dropped_snps(gpca, oracle, engine):
+    M, N = 3000, 400
+    th = gpca.synth_thresholds(M, 6, seed=4, fst=0.2)
+    G = oracle.synth_genotypes(M, N, 4, th)
+    G[::7] = 0                                   # monomorphic rows are dropped by QC
+    G[5::11, :3] = -127                          # low call rate rows dropped at 0.999
+    engine.upload_genotypes_i8(G)
+    qc = gpca.QcConfig(0.999, 0.02, 1e-6)
+    st = engine.snp_stats(qc)
+    ref = oracle.snp_stats(G, N, qc.min_snp_call_rate, qc.min_snp_maf, qc.max_snp_hwe_p_value)
+    assert np.array_equal(st["keep"], ref["keep"]) and 0 < ref["keep"].sum() < M
+    r, b = oracle.scale_shift(ref["mu"], ref["sigma"], ref["keep"])
+    engine.rsvd(5, 10, 2, seed=8)
+    R = oracle.rsvd(G, N, r, b, 5, 10, 2, seed=8)
+    kept = np.nonzero(ref["keep"])[0]
+    ld = engine.loadings()
+    assert ld.shape == (len(kept), 5)            # D x K over PCA SNPs only (main.rs:407)
+    assert oracle.max_abs_dpc(ld.astype(np.float64), R["loadings"][kept]) < TOL_PC
+    assert oracle.max_abs_dpc(engine.scores(f64=True), R["scores"]) < TOL_PC
+    assert np.max(np.abs(engine.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+
+
+def test_transform_matches_projection(gpca, oracle, engine):
+    """PCA::transform (main.rs:659): scores = standardised X * rotation."""
+    G, r, b, R = _rsvd_case(gpca, oracle, engine, 5000, 300, 8, 5, seed=6, fst=0.3)
+    ld = engine.loadings().astype(np.float64)
+    tr = engine.transform()
+    A = oracle.standardized_dense(G, 300, r, b)
+    ref = A.T @ ld
+    assert np.max(np.abs(tr - ref)) < 1e-4 * np.max(np.abs(ref))
+    # and it is the rSVD's own scores up to one more power-iteration's worth of convergence
+    assert oracle.max_abs_dpc(tr, engine.scores(f64=True)) < 1e-2
+
+
+def test_pca_class_mirror(gpca, oracle):
+    """PCA::new / rfit / transform call pattern of main.rs:602,648-660 (x = samples x variants)."""
+    M, N = 2500, 200
+    th = gpca.synth_thresholds(M, 6, seed=12, fst=0.3)
+    G = oracle.synth_genotypes(M, N, 12, th)
+    x = G.T.astype(np.float64)                                  # build_matrix orientation (vcf.rs:329-342)
+    model = gpca.PCA()
+    model.rfit(x, 4, 10, 1, None)
+    pcs = model.transform(x)
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r, b, 4, 10, 2, seed=1)
+    A = oracle.standardized_dense(G, N, r, b)
+    ref = A.T @ R["loadings"]
+    assert pcs.shape == (N, 4)
+    assert oracle.max_abs_dpc(pcs, ref) < TOL_PC
+    with pytest.raises(ValueError):
+        gpca.PCA().rfit(x, 0)                                    # main.rs:607-609
+    with pytest.raises(ValueError):
+        gpca.PCA().rfit(x[:1], 2)                                # main.rs:614-616
+    model.rfit(x[:, :3], 10, 10, 1)                              # k clamped to min(n, m) (main.rs:621-628)
+    assert model.transform().shape == (N, 3)
+
+
+def test_eigensnp_mirror(gpca, oracle, engine):
+    M, N = 3000, 256
+    th, G = _make(gpca, oracle, engine, M, N, 8, seed=21, fst=0.3)
+    engine.snp_stats(gpca.QcConfig())
+    acc = gpca.MicroarrayGenotypeAccessor(engine)
+    cfg = gpca.EigenSNPCoreAlgorithmConfig(target_num_global_pcs=5)
+    out, diag = gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, [gpca.LdBlockSpecification("1:1-500000000", list(range(acc.num_pca_snps())))])
+    assert out.final_sample_principal_component_scores.shape == (N, 5) and out.final_sample_principal_component_scores.dtype == np.float32
+    assert out.final_principal_component_eigenvalues.shape == (5,) and out.final_principal_component_eigenvalues.dtype == np.float64
+    assert out.final_snp_principal_component_loadings.shape == (acc.num_pca_snps(), 5)
+    ref = oracle.snp_stats(G, N, 0.98, 0.01, 1e-6)
+    r, b = oracle.scale_shift(ref["mu"], ref["sigma"], ref["keep"])
+    R = oracle.rsvd(G, N, r, b, 5, 10, 2, seed=2025)
+    assert oracle.max_abs_dpc(out.final_sample_principal_component_scores.astype(np.float64), R["scores"]) < TOL_PC
+
+
+def test_errors_and_state(gpca, engine):
+    with pytest.raises(gpca.GpcaError) as e:
+        engine.snp_stats()
+    assert e.value.status == -7
+    engine.upload_genotypes_i8(np.random.default_rng(0).integers(0, 3, size=(50, 40), dtype=np.int8))
+    with pytest.raises(gpca.GpcaError) as e:
+        engine.rsvd(2)
+    assert e.value.status == -7                   # stats first
+    engine.snp_stats()
+    with pytest.raises(gpca.GpcaError):
+        engine.rsvd(0)                            # main.rs:607-609
+    with pytest.raises(gpca.GpcaError):
+        engine.rsvd(60, 10)                       # l > 64
+    with pytest.raises(gpca.GpcaError):
+        engine.rsvd(35, 10)                       # l > N
+    with pytest.raises(ValueError):
+        engine.upload_genotypes_i8(np.zeros((3, 3), np.float32))
+
+
+def test_allreduce_hook_two_shards_one_gpu(gpca, oracle):
+    """N>1 exchange step on one GPU: two engines each hold a row shard; the host hook sums their sketches.
+    Sharded result must equal the unsharded one (same Omega rows via snp_offset)."""
+    import threading
+    M, N, P, k = 4000, 384, 8, 6
+    th = gpca.synth_thresholds(M, P, seed=31, fst=0.3)
+    G = oracle.synth_genotypes(M, N, 31, th)
+    full = gpca.GpcaEngine(); full.upload_genotypes_i8(G); full.snp_stats(); full.rsvd(k, 10, 2, seed=5)
+    ref_scores, ref_ev, ref_ld = full.scores(f64=True), full.eigenvalues(), full.loadings(); full.close()
+    world = 2
+    spans = [gpca.shard_rows(M, world, r) for r in range(world)]
+    barrier = threading.Barrier(world); bufs = [None] * world; res = [None] * world
+
+    def run(rank):
+        a, b_ = spans[rank]
+        e = gpca.GpcaEngine(); e.upload_genotypes_i8(G[a:b_]); e.snp_stats()
+
+        def hook(buf):
+            bufs[rank] = buf.copy(); barrier.wait()
+            buf[:] = sum(bufs[r] for r in range(world)); barrier.wait()
+        e.set_allreduce_hook(hook, world, rank, a)
+        e.rsvd(k, 10, 2, seed=5)
+        res[rank] = (e.scores(f64=True), e.eigenvalues(), e.loadings()); e.close()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])   # replicated results identical
+    assert np.max(np.abs(res[0][1] - ref_ev) / ref_ev) < 1e-6
+    assert oracle.max_abs_dpc(res[0][0], ref_scores) < 1e-5
+    ld = np.concatenate([res[0][2], res[1][2]], axis=0)
+    assert oracle.max_abs_dpc(ld.astype(np.float64), ref_ld.astype(np.float64)) < 1e-5
+
+
+def test_rccl_world1(gpca, oracle, engine):
+    """RCCL path with a 1-rank communicator: same answer as no communicator."""
+    M, N = 2000, 300
+    th, G = _make(gpca, oracle, engine, M, N, 6, seed=13, fst=0.3)
+    engine.snp_stats(); engine.rsvd(4, 10, 2, seed=1)
+    ev0, sc0 = engine.eigenvalues(), engine.scores(f64=True)
+    uid = gpca.GpcaEngine.comm_unique_id()
+    assert len(uid) == 128
+    engine.comm_init(1, 0, uid, 0)
+    engine.rsvd(4, 10, 2, seed=1)
+    assert np.array_equal(engine.eigenvalues(), ev0) and np.array_equal(engine.scores(f64=True), sc0)
+
+
+def test_timings_exposed(gpca, oracle, engine):
+    th, G = _make(gpca, oracle, engine, 3000, 512, 4, seed=2)
+    engine.snp_stats(fetch=False); engine.reset_timings()
+    engine.rsvd(10, 10, 2, seed=1)
+    t = engine.timings()
+    assert t["gemm_GQ"]["launches"] == 3 and t["gemm_GtT"]["launches"] == 3
+    assert t["gemm_GQ"]["flops"] == pytest.approx(3 * 2.0 * 3000 * 512 * 20)
+    assert t["gemm_GQ"]["total_ms"] > 0
