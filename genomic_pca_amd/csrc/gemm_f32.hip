@@ -1,0 +1,336 @@
+// The two tall-skinny products of the randomized PCA on v_mfma_f32_32x32x2_f32 (exact f32 FMA chains).
+//
+//   K1  k_gq_f32 :  T[M][L]  = r o (G Q) + b s^T          contraction over samples  (2*M*N*l flop / M*N bytes)
+//   K2  k_gtt_f32:  Y^T tiles = (r o T)^T G               contraction over SNPs     (2*M*N*l flop / M*N bytes)
+//
+// Arithmetic intensity 2*l = 60 flop/B >> the gfx950 ridge (~20 flop/B): MFMA-fp32 bound.  Measured facts the
+// structure is built on (scripts/kbench/kbench_gtt.hip, MI355X):
+//   * a bare 32x32x2 f32 MFMA loop runs 154 TF (98 %); ANY VALU instruction issued between the MFMAs costs
+//     MFMA time (f32 MFMA shares the f32 lanes): 1 dependent v_cvt_f32_ubyte per MFMA -> 115-133 TF.
+//     => the int8 dosages are converted in a block before the MFMA block, two per instruction, with
+//        v_cvt_pk_f32_fp8: bytes 0/1/2 read as fp8-e4m3 subnormals are exactly g * 2^-9; the 2^9 is multiplied
+//        back in the epilogue (exact), so results equal the plain int->float path bit for bit.
+//   * one wave per SIMD with all loads of the next step in flight behind the current step's 64-128 MFMAs beats
+//     two waves per SIMD; loads use buffer descriptors with SGPR offsets (no per-lane address VALU), the
+//     skinny operand is stored blocked so that a lane fetches its 8/16 k-steps with 16-byte loads, and the
+//     double buffer is a branch-free 2x unrolled swap (no v_mov).
+//   Result: 140 TF (89 % of the 157 TF MFMA-f32 peak) on the padded shape.
+//
+// G is read straight from HBM into registers: each byte feeds exactly one MFMA, so LDS staging would add
+// traffic without reuse.  Rows of G/T are zero-padded to a multiple of 128 and samples to a multiple of 256,
+// so the main loops carry no predicates.
+//
+// Blocked layouts (written by the producing kernels, see blocked_* helpers in kernels.h):
+//   Qb  [chunk = s/32][lt][lane = 32*h + c][u = 0..15]   = Q[32*chunk + 16*h + u][32*lt + c]
+//   Tb  [group = i/16][lt][lane = 32*h + c][u = 0..7]    = T'[16*group + 2*u + h][32*lt + c]
+#include "kernels.h"
+
+namespace gpca {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define GPCA_RSRC_FLAGS 0x00020000
+constexpr float kFp8Unscale = 512.0f;   // 2^9: bytes {0,1,2} as fp8-e4m3 subnormals are g * 2^-9
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, GPCA_RSRC_FLAGS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1.  MFMA A = 32 SNP rows x 2 samples (lane l: row l&31, k = l>>5), B = 2 samples x 32 columns of Q.
+// The grid is a fixed set of resident waves (GqPlan), one per SIMD; wave w owns a contiguous, balanced range
+// of 32-row units and processes it in groups of R = 8/4/2/1 row tiles.  Per group the wave walks the samples
+// in chunks of 32: lane (c, h) loads the 16 bytes [s0+16h, s0+16h+16) of row c of each tile; byte u is the A
+// operand of k-step u; the lane's 16 Q values of the chunk (one 64-byte run of Qb) are the B operands.
+// ------------------------------------------------------------------------------------------------
+GqPlan gq_plan(int64_t Mpad, int waves_target) {
+    GqPlan p;
+    p.units = Mpad / 32;
+    int64_t w = waves_target < 4 ? 4 : waves_target;
+    if (w > p.units) w = p.units;
+    w = (w + 3) / 4 * 4;
+    p.waves = w;
+    return p;
+}
+
+template <int R, int LT>
+struct GqBuf { i32x4 g[R]; i32x4 q0[LT], q1[LT], q2[LT], q3[LT]; };
+
+template <int R, int LT>
+__device__ __forceinline__ void gq_load(GqBuf<R, LT>& b, __amdgpu_buffer_rsrc_t rg, const uint32_t (&gvo)[R], uint32_t s0,
+                                        __amdgpu_buffer_rsrc_t rq, uint32_t qvo, uint32_t qoff) {
+#pragma unroll
+    for (int t = 0; t < R; ++t) b.g[t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], s0, 0);
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) {
+        b.q0[lt] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, qoff + lt * 4096, 0);
+        b.q1[lt] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo + 16, qoff + lt * 4096, 0);
+        b.q2[lt] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo + 32, qoff + lt * 4096, 0);
+        b.q3[lt] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo + 48, qoff + lt * 4096, 0);
+    }
+}
+
+template <int R, int LT>
+__device__ __forceinline__ void gq_compute(const GqBuf<R, LT>& b, f32x16 (&acc)[R][LT]) {
+    float av[R][16];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[t][v], false);
+            const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[t][v], true);
+            av[t][4 * v + 0] = lo[0]; av[t][4 * v + 1] = lo[1]; av[t][4 * v + 2] = hi[0]; av[t][4 * v + 3] = hi[1];
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt) {
+            // (element picked with plain constant subscripts: `v[u & 3]` made hipcc 7.2 narrow the 16-byte loads to
+            //  one dword and feed element 0 to all four k-steps)
+            const float qv = __builtin_bit_cast(float, u < 4 ? b.q0[lt][u] : u < 8 ? b.q1[lt][u - 4] : u < 12 ? b.q2[lt][u - 8] : b.q3[lt][u - 12]);
+#pragma unroll
+            for (int t = 0; t < R; ++t) acc[t][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][u], qv, acc[t][lt], 0, 0, 0);
+        }
+}
+
+template <int R, int LT>
+__device__ __forceinline__ void gq_group(const int8_t* __restrict__ G, int64_t ldg, int64_t nchunks,
+                                         const float* __restrict__ Qb, const float* __restrict__ rv,
+                                         const float* __restrict__ bv, const float (&sj)[LT], float* __restrict__ Tout,
+                                         float* __restrict__ Tb, float (&csum)[LT], int64_t row0, int c, int h, int lane) {
+    constexpr int L = 32 * LT;
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + row0 * ldg);
+    uint32_t gvo[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)((32 * t + c) * ldg + 16 * h);
+    const uint32_t qvo = (uint32_t)(lane * 64);
+    constexpr uint32_t QCH = LT * 4096;   // bytes of Qb per 32-sample chunk
+
+    f32x16 acc[R][LT];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
+
+    GqBuf<R, LT> A, B;
+    gq_load<R, LT>(A, rg, gvo, 0u, make_rsrc(Qb), qvo, 0u);
+    // chunks are processed in pairs; nchunks is even (samples padded to a multiple of 64 for this loop)
+    for (int64_t ch = 0; ch < nchunks; ch += 2) {
+        const __amdgpu_buffer_rsrc_t rq = make_rsrc(reinterpret_cast<const char*>(Qb) + ch * QCH);
+        const uint32_t s0 = (uint32_t)(ch * 32);
+        const uint32_t nx = (ch + 2 < nchunks) ? 2u : 0u;   // last pair prefetches its own first chunk (unused)
+        gq_load<R, LT>(B, rg, gvo, s0 + 32u, rq, qvo, QCH);
+        __builtin_amdgcn_sched_barrier(0);
+        gq_compute<R, LT>(A, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gq_load<R, LT>(A, rg, gvo, s0 + 32u * nx, rq, qvo, QCH * nx);
+        __builtin_amdgcn_sched_barrier(0);
+        gq_compute<R, LT>(B, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // epilogue: D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Pad rows have r = b = 0.
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float ri = rv[row], bi = bv[row];
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt) {
+                const float tv = ri * (acc[t][lt][e] * kFp8Unscale) + bi * sj[lt];
+                if (Tb) {   // power iteration: T' = r o T in the blocked layout K2 reads, plus c = b^T T
+                    csum[lt] += bi * tv;
+                    Tb[blocked_t_index(row, 32 * lt + c, LT)] = ri * tv;
+                } else {
+                    Tout[row * L + 32 * lt + c] = tv;
+                }
+            }
+        }
+    }
+}
+
+template <int LT>
+__global__ __launch_bounds__(256, 1) void k_gq_f32(const int8_t* __restrict__ G, int64_t ldg, int64_t units,
+                                                    int64_t nchunks, const float* __restrict__ Qb,
+                                                    const float* __restrict__ rv, const float* __restrict__ bv,
+                                                    const float* __restrict__ sv, float* __restrict__ Tout,
+                                                    float* __restrict__ Tb, float* __restrict__ cpart) {
+    constexpr int L = 32 * LT;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    int64_t u = (units * wave) / waves;                 // balanced contiguous ranges of 32-row units
+    const int64_t u_end = (units * (wave + 1)) / waves;
+
+    float csum[LT], sj[LT];
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) { csum[lt] = 0.f; sj[lt] = sv[32 * lt + c]; }
+    if (LT == 1) {
+        for (; u + 8 <= u_end; u += 8) gq_group<8, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane);
+    }
+    for (; u + 4 <= u_end; u += 4) gq_group<4, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane);
+    if (u + 2 <= u_end) { gq_group<2, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane); u += 2; }
+    if (u + 1 <= u_end) { gq_group<1, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane); u += 1; }
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) {
+        const float o = csum[lt] + __shfl_xor(csum[lt], 32);
+        if (h == 0) cpart[wave * L + 32 * lt + c] = o;
+    }
+}
+
+void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const float* Qb, int L,
+                   const float* r, const float* b, const float* s, float* Tout, float* Tb, float* cpart) {
+    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
+    const int64_t nchunks = (N + 63) / 64 * 2;   // 32-sample chunks, even count (Npad is a multiple of 256 >= this)
+    if (L == 32)
+        hipLaunchKernelGGL((k_gq_f32<1>), grid, blk, 0, st, G, ldg, plan.units, nchunks, Qb, r, b, s, Tout, Tb, cpart);
+    else
+        hipLaunchKernelGGL((k_gq_f32<2>), grid, blk, 0, st, G, ldg, plan.units, nchunks, Qb, r, b, s, Tout, Tb, cpart);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2.  D = Y^T tile: A = T'^T (32 columns j x 2 SNPs), B = G (2 SNPs x 32 samples).  Lane (c, h) loads the
+// 8 bytes [n0+8c, n0+8c+8) of SNP row m+2u+h: one wave-load = 2 rows x 256 contiguous bytes.  Byte t feeds
+// accumulator tile t, whose MFMA column c is sample n0 + 8c + t.  A wave owns one 256-sample block and a
+// contiguous range of SNP rows (groups of 16 = 8 k-steps; the lane's 8 T' values of a group are one 32-byte
+// run of Tb); partial Y^T tiles go to Ypart and are summed in f64 by k_reduce_y (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------------
+GttPlan gtt_plan(int64_t Mpad, int64_t Npad, int L, int target_waves) {
+    GttPlan p;
+    p.nblocks_n = Npad / kSamplePad;
+    int64_t W = target_waves / p.nblocks_n;
+    if (W < 1) W = 1;
+    const int64_t maxW = Mpad / 32;
+    if (W > maxW) W = maxW;
+    int64_t rpw = (Mpad + W - 1) / W;
+    rpw = (rpw + 31) / 32 * 32;          // even number of 16-row groups per wave (Mpad is a multiple of 128)
+    W = (Mpad + rpw - 1) / rpw;
+    p.W = (int)W;
+    p.rows_per_wave = rpw;
+    const int64_t ngroups = (p.nblocks_n + 3) / 4;
+    p.grid = ngroups * W;
+    (void)L;
+    return p;
+}
+
+template <int LT>
+struct GttBuf { i32x2 g[8]; i32x4 t0[LT], t1[LT]; };
+
+template <int LT>
+__device__ __forceinline__ void gtt_load(GttBuf<LT>& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off,
+                                         uint32_t ldg, __amdgpu_buffer_rsrc_t rt, uint32_t tvo, uint32_t toff) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b.g[u] = __builtin_amdgcn_raw_buffer_load_b64(rg, gvo, row_off + (uint32_t)(2 * u) * ldg, 0);
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) {
+        b.t0[lt] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, toff + lt * 2048, 0);
+        b.t1[lt] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo + 16, toff + lt * 2048, 0);
+    }
+}
+
+template <int LT>
+__device__ __forceinline__ void gtt_compute(const GttBuf<LT>& b, f32x16 (&acc)[8][LT]) {
+    float bv[8][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][0], false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][0], true);
+        const f32x2 p2 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][1], false), p3 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][1], true);
+        bv[u][0] = p0[0]; bv[u][1] = p0[1]; bv[u][2] = p1[0]; bv[u][3] = p1[1];
+        bv[u][4] = p2[0]; bv[u][5] = p2[1]; bv[u][6] = p3[0]; bv[u][7] = p3[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt) {
+            const float ta = __builtin_bit_cast(float, u < 4 ? b.t0[lt][u] : b.t1[lt][u - 4]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta, bv[u][t], acc[t][lt], 0, 0, 0);
+        }
+}
+
+template <int LT>
+__global__ __launch_bounds__(256, 1) void k_gtt_f32(const int8_t* __restrict__ G, int64_t ldg, int64_t Mpad,
+                                                     int64_t Npad, const float* __restrict__ Tb,
+                                                     float* __restrict__ Ypart, int64_t ngroups, int64_t rows_per_wave) {
+    constexpr int L = 32 * LT;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ngroup = blockIdx.x % ngroups;
+    const int64_t wchunk = blockIdx.x / ngroups;
+    const int64_t nblock = ngroup * 4 + wv;
+    const int64_t n0 = nblock * kSamplePad;
+    if (n0 >= Npad) return;
+    const int64_t m_begin = wchunk * rows_per_wave;
+    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
+    const int64_t groups = (m_end - m_begin) >> 4;   // even: Mpad and rows_per_wave are multiples of 32
+
+    f32x16 acc[8][LT];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
+
+    const uint32_t gvo = (uint32_t)(h * ldg + 8 * c);
+    const uint32_t tvo = (uint32_t)(lane * 32);
+    constexpr uint32_t TGR = LT * 2048;                       // bytes of Tb per 16-row group
+    const int8_t* gp = G + m_begin * ldg + n0;
+    const char* tp = reinterpret_cast<const char*>(Tb) + (m_begin >> 4) * TGR;
+    GttBuf<LT> A, B;
+    gtt_load<LT>(A, make_rsrc(gp), gvo, 0u, (uint32_t)ldg, make_rsrc(tp), tvo, 0u);
+    for (int64_t g = 0; g < groups; g += 2) {
+        // descriptors are re-based every pair of groups, so the 32-bit offsets stay < 48 * ldg
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(gp + g * 16 * ldg);
+        const __amdgpu_buffer_rsrc_t rt = make_rsrc(tp + g * TGR);
+        const uint32_t nx = (g + 2 < groups) ? 2u : 0u;       // last pair prefetches its own first group (unused)
+        gtt_load<LT>(B, rg, gvo, 16u * (uint32_t)ldg, (uint32_t)ldg, rt, tvo, TGR);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt_compute<LT>(A, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt_load<LT>(A, rg, gvo, 16u * nx * (uint32_t)ldg, (uint32_t)ldg, rt, tvo, TGR * nx);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt_compute<LT>(B, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h (+32 lt), col = c -> sample n0 + 8c + t.
+    // regs e..e+3 are 4 consecutive j: one 16-byte store per (tile, quad).  (The 2^9 of the fp8 trick is applied
+    // by k_reduce_y.)
+    float* yp = Ypart + (wchunk * Npad) * L;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int64_t n = n0 + 8 * c + t;
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                const int j = 32 * lt + 8 * (e >> 2) + 4 * h;
+                float4 o;
+                o.x = acc[t][lt][e]; o.y = acc[t][lt][e + 1]; o.z = acc[t][lt][e + 2]; o.w = acc[t][lt][e + 3];
+                *reinterpret_cast<float4*>(yp + n * L + j) = o;
+            }
+    }
+}
+
+void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const float* Tb, int L,
+                    float* Ypart, const GttPlan& plan) {
+    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    const dim3 grid((unsigned)plan.grid), blk(256);
+    if (L == 32)
+        hipLaunchKernelGGL((k_gtt_f32<1>), grid, blk, 0, st, G, ldg, Mpad, Npad, Tb, Ypart, ngroups, plan.rows_per_wave);
+    else
+        hipLaunchKernelGGL((k_gtt_f32<2>), grid, blk, 0, st, G, ldg, Mpad, Npad, Tb, Ypart, ngroups, plan.rows_per_wave);
+}
+
+}  // namespace gpca

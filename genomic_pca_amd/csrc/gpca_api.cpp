@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -59,7 +60,7 @@ struct gpca_handle {
     std::string err;
 
     // genotypes
-    int64_t M = 0, N = 0, ldg = 0;
+    int64_t M = 0, N = 0, ldg = 0, Mpad = 0;   // Mpad = round_up(M, 128): zero rows, so the GEMM loops carry no predicates
     int8_t* dG = nullptr;
 
     // stats
@@ -75,12 +76,14 @@ struct gpca_handle {
     // rsvd workspace / results
     int k = 0, l = 0, L = 0;
     bool have_rsvd = false;
-    float *dQ = nullptr, *dT = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
-    double *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
+    float *dQ = nullptr, *dT = nullptr, *dTb = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
+    double *d_scratch64 = nullptr, *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
     double* d_scores64 = nullptr; float* d_scores32 = nullptr; float* d_load32 = nullptr; int* d_sign = nullptr;
-    size_t cap_Q = 0, cap_T = 0, cap_Ypart = 0, cap_cpart = 0, cap_Y = 0, cap_part64 = 0, cap_scores = 0, cap_load = 0;
+    size_t cap_Q = 0, cap_T = 0, cap_Tb = 0, cap_Ypart = 0, cap_cpart = 0, cap_Y = 0, cap_part64 = 0, cap_scores = 0, cap_load = 0;
     std::vector<double> eig, sv;
     GttPlan plan{};
+    GqPlan gqplan{};
+    int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
 
     // comm
     int world = 1, rank = 0;
@@ -175,6 +178,9 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (dev >= ndev) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: device ordinal out of range"); }
     h->device = dev;
     h->precision = cfg ? cfg->precision : GPCA_PREC_F32_MFMA;
+    // tuning knobs (resident-wave targets of the two GEMM grids); defaults are the tuned values
+    if (const char* e = getenv("GPCA_GQ_WAVES")) h->gq_waves_target = std::max(4, atoi(e));
+    if (const char* e = getenv("GPCA_GTT_WAVES")) h->gtt_waves_target = std::max(4, atoi(e));
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
         delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
     }
@@ -196,10 +202,10 @@ static void free_stats(gpca_handle* h) {
     h->have_stats = false; h->n_pca = 0; h->pca_rows.clear();
 }
 static void free_ws(gpca_handle* h) {
-    dfree(h->dQ); dfree(h->dT); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
+    dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
-    dfree(h->d_load32); dfree(h->d_sign);
-    h->cap_Q = h->cap_T = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
+    dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
+    h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
     h->have_rsvd = false;
 }
 
@@ -227,8 +233,9 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return fail(h, GPCA_ERR_BAD_ARG, "genotype matrix must have M > 0 SNPs and N > 0 samples");
     HIPCHK(hipSetDevice(h->device));
     free_stats(h); free_ws(h); dfree(h->dG);
-    h->M = M; h->N = N; h->ldg = round_up(N, kSamplePad);
-    HIPCHK(hipMalloc((void**)&h->dG, (size_t)M * (size_t)h->ldg));
+    h->M = M; h->N = N; h->ldg = round_up(N, kSamplePad); h->Mpad = round_up(M, kGQRowsPerWave);
+    HIPCHK(hipMalloc((void**)&h->dG, (size_t)h->Mpad * (size_t)h->ldg));
+    if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG + (size_t)M * (size_t)h->ldg, 0, (size_t)(h->Mpad - M) * (size_t)h->ldg, h->st));
     return GPCA_OK;
 }
 
@@ -284,13 +291,14 @@ extern "C" int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N) {
 
 // ---- a1 ---------------------------------------------------------------------------------------------------
 static int alloc_stats(gpca_handle* h) {
-    const size_t M = (size_t)h->M;
+    const size_t M = (size_t)h->Mpad;   // pad rows: r = b = 0
     if (h->d_mu) return GPCA_OK;
     HIPCHK(hipMalloc((void**)&h->d_mu, M * 4)); HIPCHK(hipMalloc((void**)&h->d_sigma, M * 4));
     HIPCHK(hipMalloc((void**)&h->d_r, M * 4)); HIPCHK(hipMalloc((void**)&h->d_b, M * 4));
     HIPCHK(hipMalloc((void**)&h->d_keep, M)); HIPCHK(hipMalloc((void**)&h->d_reason, M));
     HIPCHK(hipMalloc((void**)&h->d_counts, M * 16)); HIPCHK(hipMalloc((void**)&h->d_flags, 16));
-    HIPCHK(hipMemset(h->d_counts, 0, M * 16));
+    HIPCHK(hipMemsetAsync(h->d_counts, 0, M * 16, h->st)); HIPCHK(hipMemsetAsync(h->d_r, 0, M * 4, h->st)); HIPCHK(hipMemsetAsync(h->d_b, 0, M * 4, h->st));
+    HIPCHK(hipMemsetAsync(h->d_mu, 0, M * 4, h->st)); HIPCHK(hipMemsetAsync(h->d_sigma, 0, M * 4, h->st)); HIPCHK(hipMemsetAsync(h->d_keep, 0, M, h->st));
     return GPCA_OK;
 }
 
@@ -347,10 +355,11 @@ extern "C" int gpca_set_standardization(gpca_handle* h, const float* mu, const f
     // a stats pass supplies the missing/invalid flags for the rows the caller keeps
     if (!h->have_stats) { gpca_qc_config none{0.0, 0.0, 1.0}; CHK(gpca_snp_stats(h, &none, nullptr, nullptr, nullptr)); }
     const size_t M = (size_t)h->M;
+    HIPCHK(hipStreamSynchronize(h->st));   // blocking copies below run on the null stream
     HIPCHK(hipMemcpy(h->d_mu, mu, M * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_sigma, sigma, M * 4, hipMemcpyHostToDevice));
     if (keep) HIPCHK(hipMemcpy(h->d_keep, keep, M, hipMemcpyHostToDevice));
-    else HIPCHK(hipMemset(h->d_keep, 1, M));
+    else HIPCHK(hipMemsetAsync(h->d_keep, 1, M, h->st));
     launch_set_scale(h->st, h->M, h->d_mu, h->d_sigma, h->d_keep, h->d_r, h->d_b);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->st));
@@ -559,7 +568,7 @@ static void jacobi_eigh(std::vector<double>& A, std::vector<double>& V, std::vec
 
 // ---- rsvd stages -----------------------------------------------------------------------------------------------
 static int stage_sum_c(gpca_handle* h, int64_t parts) {
-    launch_sum_partials_f32(h->st, h->d_cpart, parts, h->L, h->d_c);
+    launch_sum_partials_f32(h->st, h->d_cpart, parts, h->L, h->d_c, h->d_scratch64);
     HIPCHK(hipGetLastError());
     return GPCA_OK;
 }
@@ -569,7 +578,7 @@ static int stage_AtT(gpca_handle* h) {
     const double elems = (double)h->M * (double)h->N;
     {
         ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, elems);
-        launch_gtt_f32(h->st, h->dG, h->ldg, h->M, h->ldg, h->dT, h->L, h->dYpart, h->plan);
+        launch_gtt_f32(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTb, h->L, h->dYpart, h->plan);
     }
     HIPCHK(hipGetLastError());
     launch_reduce_y(h->st, h->dYpart, h->plan.W, h->ldg, h->N, h->L, h->d_c, h->dY);
@@ -582,10 +591,10 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     const double elems = (double)h->M * (double)h->N;
     {
         ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, elems);
-        launch_gq_f32(h->st, h->dG, h->ldg, h->M, h->ldg, h->dQ, h->L, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+        launch_gq_f32(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQ, h->L, h->d_r, h->d_b, h->d_s32, h->dT, scale_out ? h->dTb : nullptr, h->d_cpart);
     }
     HIPCHK(hipGetLastError());
-    if (scale_out) CHK(stage_sum_c(h, gq_num_parts(h->M)));
+    if (scale_out) CHK(stage_sum_c(h, h->gqplan.waves));
     return GPCA_OK;
 }
 
@@ -597,7 +606,7 @@ static int stage_orth(gpca_handle* h) {
         const int64_t parts = gram_num_parts(h->N);
         launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
         HIPCHK(hipGetLastError());
-        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW);
+        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(W.data(), h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
@@ -613,10 +622,10 @@ static int stage_orth(gpca_handle* h) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->st));  // X (host) is reused next round
     }
-    const int64_t parts = colsum_num_parts(h->ldg);
-    launch_colsum_f32(h->st, h->dQ, h->ldg, L, h->d_part64);
+    const int64_t parts = colsum_num_parts(h->N);
+    launch_colsum_f64(h->st, h->dY, h->N, L, h->d_part64);   // dY now holds the orthonormal basis in f64
     HIPCHK(hipGetLastError());
-    launch_sum_partials_f64(h->st, h->d_part64, parts, L, h->d_s64);
+    launch_sum_partials_f64(h->st, h->d_part64, parts, L, h->d_s64, h->d_scratch64);
     HIPCHK(hipGetLastError());
     launch_f64_to_f32(h->st, h->d_s64, h->d_s32, L);
     HIPCHK(hipGetLastError());
@@ -626,11 +635,14 @@ static int stage_orth(gpca_handle* h) {
 static int ensure_workspace(gpca_handle* h) {
     const int L = h->L;
     const int64_t Npad = h->ldg, M = h->M, N = h->N;
-    h->plan = gtt_plan(M, Npad, L, 2048);
+    h->plan = gtt_plan(h->Mpad, Npad, L, h->gtt_waves_target);
+    h->gqplan = gq_plan(h->Mpad, h->gq_waves_target);
     CHK(ensure(h, h->dQ, h->cap_Q, (size_t)Npad * L));
-    CHK(ensure(h, h->dT, h->cap_T, (size_t)M * L));
+    CHK(ensure(h, h->dT, h->cap_T, (size_t)h->Mpad * L));
+    CHK(ensure(h, h->dTb, h->cap_Tb, (size_t)h->Mpad * L));
+    if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dT + (size_t)M * L, 0, (size_t)(h->Mpad - M) * L * 4, h->st));
     CHK(ensure(h, h->dYpart, h->cap_Ypart, (size_t)h->plan.W * (size_t)Npad * L));
-    const int64_t cparts = std::max(gq_num_parts(M), omega_num_parts(M));
+    const int64_t cparts = std::max(h->gqplan.waves, omega_num_parts(h->Mpad));
     CHK(ensure(h, h->d_cpart, h->cap_cpart, (size_t)cparts * L));
     CHK(ensure(h, h->dY, h->cap_Y, (size_t)N * L));
     const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L});
@@ -639,6 +651,7 @@ static int ensure_workspace(gpca_handle* h) {
         HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));
         HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, 64 * 64 * 8));
         HIPCHK(hipMalloc((void**)&h->dZ, 64 * 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
+        HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
     }
     size_t cap2 = h->cap_scores;
     CHK(ensure(h, h->d_scores64, h->cap_scores, (size_t)N * h->k));
@@ -671,10 +684,10 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     // 1. sketch: T' = r o Omega, c = b^T Omega;  Y = A^T Omega;  Q = orth(Y)
     {
         ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
-        launch_omega(h->st, h->M, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart);
+        launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart);
     }
     HIPCHK(hipGetLastError());
-    CHK(stage_sum_c(h, omega_num_parts(h->M)));
+    CHK(stage_sum_c(h, omega_num_parts(h->Mpad)));
     CHK(stage_AtT(h));
     CHK(stage_orth(h));
     // 2. power iterations
@@ -689,7 +702,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         const int64_t parts = gram_num_parts(h->M);
         launch_gram_f32(h->st, h->dT, h->M, L, h->d_part64);
         HIPCHK(hipGetLastError());
-        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW);
+        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
         HIPCHK(hipGetLastError());
         CHK(allreduce_f64(h, h->dW, (int64_t)L * L));
     }
@@ -705,7 +718,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     std::vector<double> Z((size_t)L * k, 0.0);
     for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Z[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
     HIPCHK(hipMemcpyAsync(h->dZ, Z.data(), sizeof(double) * L * k, hipMemcpyHostToDevice, h->st));
-    launch_rightmul_f32(h->st, h->dQ, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);
+    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);   // dY = Q in f64
     HIPCHK(hipGetLastError());
     launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
     HIPCHK(hipGetLastError());
@@ -792,12 +805,12 @@ int transform_impl(gpca_handle* h, double* out) {
     HIPCHK(hipSetDevice(h->device));
     const int L = h->L, k = h->k;
     // T' = r o U (zero rows for dropped SNPs), c = b^T U
-    HIPCHK(hipMemsetAsync(h->dT, 0, (size_t)h->M * L * 4, h->st));
+    HIPCHK(hipMemsetAsync(h->dT, 0, (size_t)h->Mpad * L * 4, h->st));
     launch_expand_loadings(h->st, h->d_load32, h->d_pca_rows, h->n_pca, k, L, h->dT);
     HIPCHK(hipGetLastError());
-    launch_scale_rows(h->st, h->dT, h->M, L, h->d_r, h->d_b, h->d_cpart);
+    launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dTb, h->d_cpart);
     HIPCHK(hipGetLastError());
-    CHK(stage_sum_c(h, omega_num_parts(h->M)));
+    CHK(stage_sum_c(h, omega_num_parts(h->Mpad)));
     CHK(stage_AtT(h));
     std::vector<double> Y((size_t)h->N * L);
     HIPCHK(hipMemcpyAsync(Y.data(), h->dY, (size_t)h->N * L * 8, hipMemcpyDeviceToHost, h->st));

@@ -12,6 +12,20 @@ constexpr int kGQRowsPerWave = 128;   // SNP rows per wave in the G Q kernel (R 
 
 struct QcParams { double min_call_rate, min_maf, max_hwe_p; };
 
+// Blocked layouts of the skinny GEMM operands (gemm_f32.hip): a lane's 8 / 16 k-steps are contiguous.
+//   Tb [group = row/16][lt][lane = 32*(row&1) + col%32][u = (row%16)/2]      (8 floats per lane)
+//   Qb [chunk = n/32][lt][lane = 32*((n%32)/16) + col%32][u = n%16]           (16 floats per lane)
+__host__ __device__ inline int64_t blocked_t_index(int64_t row, int col, int LT) {
+    const int64_t group = row >> 4;
+    const int w = (int)(row & 15), lt = col >> 5, cc = col & 31;
+    return ((group * LT + lt) * 64 + ((w & 1) * 32 + cc)) * 8 + (w >> 1);
+}
+__host__ __device__ inline int64_t blocked_q_index(int64_t n, int col, int LT) {
+    const int64_t chunk = n >> 5;
+    const int w = (int)(n & 31), lt = col >> 5, cc = col & 31;
+    return ((chunk * LT + lt) * 64 + ((w >> 4) * 32 + cc)) * 16 + (w & 15);
+}
+
 void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset,
                   uint64_t seed, const uint32_t* d_thresh, int P);
 void launch_bed_decode(hipStream_t st, const uint8_t* bed, int64_t bytes_per_row, int8_t* G, int64_t M,
@@ -29,42 +43,45 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
                               const float* sigma, const int64_t* rows, int64_t ns, const int64_t* cols,
                               int64_t nj, float* out, unsigned long long* err_idx);
 
-// sketch operand: Tp[i][j] = r_i * Omega[i][j] (j < l, else 0); cpart[wave][j] = sum_i b_i Omega[i][j]
-int64_t omega_num_parts(int64_t M);
-void launch_omega(hipStream_t st, int64_t M, int l, int L, int64_t snp_offset, uint64_t seed,
-                  const float* r, const float* b, float* Tp, float* cpart);
+// sketch operand: Tb (blocked, all Mpad rows) = r_i * Omega[i][j] (j < l, else 0); cpart[wave][j] = sum_i b_i Omega[i][j]
+int64_t omega_num_parts(int64_t Mpad);
+void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
+                  const float* r, const float* b, float* Tb, float* cpart);
 
-// K1: T = r o (G Q) + b s^T   (scale_out: write r o T instead, plus cpart = per-wave sum_i b_i T_ij)
-int64_t gq_num_parts(int64_t M);
-void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Q,
-                   int L, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                   int scale_out);
-// K2: Ypart[w][n][j] = sum over the wave's SNP rows of G[i][n] * Tp[i][j]
+// K1: T = r o (G Q) + b s^T.  Tb != NULL: write r o T blocked into Tb and cpart[wave][j] = sum_i b_i T_ij
+// (power iteration); Tb == NULL: write T row-major into Tout (projection B = A Q).  Qb is the blocked basis.
+struct GqPlan { int64_t units; int64_t waves; };   // 32-row units of the padded matrix; resident waves (multiple of 4)
+GqPlan gq_plan(int64_t Mpad, int waves_target);
+void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const float* Qb,
+                   int L, const float* r, const float* b, const float* s, float* Tout, float* Tb, float* cpart);
+// K2: Ypart[w][n][j] = 2^-9 * sum over the wave's SNP rows of G[i][n] * T'[i][j]   (T' blocked in Tb)
 struct GttPlan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; };
-GttPlan gtt_plan(int64_t M, int64_t Npad, int L, int target_waves);
-void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Tp,
+GttPlan gtt_plan(int64_t Mpad, int64_t Npad, int L, int target_waves);
+void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const float* Tb,
                     int L, float* Ypart, const GttPlan& plan);
-// Y[n][j] = c[j] + sum_w Ypart[w][n][j]   (f64 sum), n < N
+// Y[n][j] = c[j] + 2^9 * sum_w Ypart[w][n][j]   (f64 sum), n < N
 void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, int64_t N, int L, const double* c,
                      double* Y);
 
 // generic tall-skinny helpers
-void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out);
-void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out);
+// scratch: >= 64 * E doubles (kSumScratchElems covers E <= 4096)
+constexpr int64_t kSumScratchElems = 64 * 4096;
+void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out, double* scratch);
+void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out, double* scratch);
 int64_t gram_num_parts(int64_t rows);
 void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part);
 void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part);
-// X[n][:] <- X[n][:] * Z  (Z: [L][L] f64, in place); optionally also Qout f32 [rows_pad][L] (pad rows zeroed)
-void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,
+// X[n][:] <- X[n][:] * Z  (Z: [L][L] f64, in place); optionally also the blocked f32 basis Qb (rows_pad rows, pad rows zeroed)
+void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qb,
                                 int64_t rows_pad);
 // out[n][kc] = sum_j X[n][j] Z[j][kc]   (Z: [L][K] f64)
-void launch_rightmul_f32(hipStream_t st, const float* X, int64_t rows, int L, const double* Z, int K, double* out64,
+void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
                          float* out32);
 // rows gathered through an index list (loadings of kept SNPs)
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
                                 const double* Z, int K, float* out32);
 int64_t colsum_num_parts(int64_t rows);
-void launch_colsum_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part);
+void launch_colsum_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part);
 // sign[c] = sign of the first element of column c with maximal |x|
 void launch_col_sign(hipStream_t st, const double* X, int64_t rows, int K, int* sign);
 void launch_scale_cols(hipStream_t st, double* X64, float* X32, int64_t rows, int K, const int* sign);
@@ -73,7 +90,8 @@ void launch_f64_to_f32(hipStream_t st, const double* in, float* out, int64_t n);
 void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v);
 // Tp[rows[a]][c] = load[a][c] for c < k (other entries untouched: caller zero-fills Tp first)
 void launch_expand_loadings(hipStream_t st, const float* load, const int64_t* rows, int64_t n_pca, int k, int L, float* Tp);
-// in place X[i][:] <- r_i X[i][:]; cpart[wave][j] = sum over the wave's 64 rows of b_i X[i][j] (omega_num_parts(M) waves)
-void launch_scale_rows(hipStream_t st, float* X, int64_t M, int L, const float* r, const float* b, float* cpart);
+// Tb (blocked, all Mpad rows) = r_i X[i][:]; cpart[wave][j] = sum over the wave's 64 rows of b_i X[i][j] (omega_num_parts(Mpad) waves)
+void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, int L, const float* r, const float* b,
+                       float* Tb, float* cpart);
 
 }  // namespace gpca

@@ -287,11 +287,11 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
 // Box-Muller pairs in f64 (bit-compatible recipe with oracle/gpca_oracle.c:omega4).
 // One wave = 64 rows; writes Tp = r o Omega and the wave's partial of c = b^T Omega.
 // ------------------------------------------------------------------------------------------------
-int64_t omega_num_parts(int64_t M) { return (M + 63) / 64; }
+int64_t omega_num_parts(int64_t Mpad) { return (Mpad + 63) / 64; }
 
-__global__ __launch_bounds__(256) void k_omega(int64_t M, int l, int L, int64_t snp_offset, uint64_t seed,
+__global__ __launch_bounds__(256) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
                                                const float* __restrict__ r, const float* __restrict__ b,
-                                               float* __restrict__ Tp, float* __restrict__ cpart) {
+                                               float* __restrict__ Tb, float* __restrict__ cpart) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
@@ -299,9 +299,10 @@ __global__ __launch_bounds__(256) void k_omega(int64_t M, int l, int L, int64_t 
     const bool live = i < M;
     const float ri = live ? r[i] : 0.f, bi = live ? b[i] : 0.f;
     const uint64_t gi = (uint64_t)(i + snp_offset);
+    const int LT = L >> 5;
     for (int jq = 0; jq < L / 4; ++jq) {
         double z[4] = {0, 0, 0, 0};
-        if (4 * jq < l) {
+        if (4 * jq < l && live) {
             philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)jq, GPCA_STREAM_OMEGA,
                                          (uint32_t)seed, (uint32_t)(seed >> 32));
             const double sc = 1.0 / 4294967296.0, twopi = 6.283185307179586476925286766559;
@@ -311,267 +312,25 @@ __global__ __launch_bounds__(256) void k_omega(int64_t M, int l, int L, int64_t 
             z[0] = r0 * cos(twopi * u1); z[1] = r0 * sin(twopi * u1);
             z[2] = r1 * cos(twopi * u3); z[3] = r1 * sin(twopi * u3);
         }
-        float4 tv;
-        float zf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) zf[t] = (4 * jq + t < l) ? (float)z[t] : 0.f;
-        tv.x = ri * zf[0]; tv.y = ri * zf[1]; tv.z = ri * zf[2]; tv.w = ri * zf[3];
-        if (live) *reinterpret_cast<float4*>(Tp + i * L + 4 * jq) = tv;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float cv = bi * zf[t];
+            const float zf = (4 * jq + t < l) ? (float)z[t] : 0.f;
+            if (i < Mpad) Tb[blocked_t_index(i, 4 * jq + t, LT)] = ri * zf;
+            float cv = bi * zf;
 #pragma unroll
             for (int o2 = 32; o2 > 0; o2 >>= 1) cv += __shfl_xor(cv, o2);
             if (lane == 0) red[wv][4 * jq + t] = cv;
         }
     }
     __syncthreads();
-    if (lane < L && wave < (M + 63) / 64) cpart[wave * L + lane] = red[wv][lane];
+    if (lane < L && wave < (Mpad + 63) / 64) cpart[wave * L + lane] = red[wv][lane];
 }
 
-void launch_omega(hipStream_t st, int64_t M, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
-                  const float* b, float* Tp, float* cpart) {
-    const int64_t waves = omega_num_parts(M);
-    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, M, l, L, snp_offset, seed, r, b, Tp,
+void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
+                  const float* b, float* Tb, float* cpart) {
+    const int64_t waves = omega_num_parts(Mpad);
+    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
                        cpart);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1: T[M][L] = r o (G Q) + b s^T            (MFMA-fp32 bound: 2*M*N*l flop on M*N bytes)
-//
-// v_mfma_f32_32x32x2_f32: A = 32 SNP rows x 2 samples (one f32 per lane: lane l -> row l&31, k = l>>5),
-// B = 2 samples x 32 columns of Q, D = 32x32 f32 in 16 VGPRs.  A wave owns R*32 SNP rows and walks
-// the sample axis in chunks of 32: each lane loads 16 B of its row (16 consecutive samples of half h),
-// byte u of that load is the A operand of k-step u (v_cvt_f32_ubyteN), and the Q fragment of k-step u
-// (rows s0+16h+u) is shared by the wave's R row tiles.  Next chunk's loads are issued before the
-// current chunk's 16*R MFMAs (register double buffer).
-// ------------------------------------------------------------------------------------------------
-int64_t gq_num_parts(int64_t M) { return (M + kGQRowsPerWave - 1) / kGQRowsPerWave; }
-
-template <int R, int LT>
-__global__ __launch_bounds__(256, (LT == 1 ? 2 : 1)) void k_gq_f32(
-    const int8_t* __restrict__ G, int64_t ldg, int64_t M, int64_t Npad, const float* __restrict__ Q,
-    const float* __restrict__ rv, const float* __restrict__ bv, const float* __restrict__ sv, float* __restrict__ Tout,
-    float* __restrict__ cpart, int scale_out) {
-    constexpr int L = 32 * LT;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t row0 = wave * (32 * R);
-    if (row0 >= M) return;
-
-    const char* gp[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-        int64_t row = row0 + 32 * t + c;
-        row = row < M ? row : M - 1;
-        gp[t] = reinterpret_cast<const char*>(G) + row * ldg + 16 * h;
-    }
-    const float* qp = Q + (int64_t)(16 * h) * L + c;
-
-    f32x16 acc[R][LT];
-#pragma unroll
-    for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
-
-    uint4 ga[R], gb[R];
-    float qa[16][LT], qb[16][LT];
-#pragma unroll
-    for (int t = 0; t < R; ++t) ga[t] = *reinterpret_cast<const uint4*>(gp[t]);
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-#pragma unroll
-        for (int lt = 0; lt < LT; ++lt) qa[u][lt] = qp[(int64_t)u * L + 32 * lt];
-
-    for (int64_t s0 = 0; s0 < Npad; s0 += 32) {
-        const int64_t s1 = (s0 + 32 < Npad) ? s0 + 32 : s0;  // last iteration re-loads the same chunk (unused)
-#pragma unroll
-        for (int t = 0; t < R; ++t) gb[t] = *reinterpret_cast<const uint4*>(gp[t] + s1);
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int lt = 0; lt < LT; ++lt) qb[u][lt] = qp[(s1 + u) * L + 32 * lt];
-
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                const unsigned w = (u < 4) ? ga[t].x : (u < 8) ? ga[t].y : (u < 12) ? ga[t].z : ga[t].w;
-                const float a = (float)((w >> (8 * (u & 3))) & 0xffu);
-#pragma unroll
-                for (int lt = 0; lt < LT; ++lt)
-                    acc[t][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qa[u][lt], acc[t][lt], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < R; ++t) ga[t] = gb[t];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int lt = 0; lt < LT; ++lt) qa[u][lt] = qb[u][lt];
-    }
-
-    // epilogue: D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float csum[LT];
-#pragma unroll
-    for (int lt = 0; lt < LT; ++lt) csum[lt] = 0.f;
-    float sj[LT];
-#pragma unroll
-    for (int lt = 0; lt < LT; ++lt) sj[lt] = sv[32 * lt + c];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (row < M) {
-                const float ri = rv[row], bi = bv[row];
-#pragma unroll
-                for (int lt = 0; lt < LT; ++lt) {
-                    const float tv = ri * acc[t][lt][e] + bi * sj[lt];
-                    csum[lt] += bi * tv;
-                    Tout[row * L + 32 * lt + c] = scale_out ? ri * tv : tv;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int lt = 0; lt < LT; ++lt) {
-        const float o = csum[lt] + __shfl_xor(csum[lt], 32);
-        if (h == 0) cpart[wave * L + 32 * lt + c] = o;
-    }
-}
-
-void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Q, int L,
-                   const float* r, const float* b, const float* s, float* Tout, float* cpart, int scale_out) {
-    const int64_t waves = gq_num_parts(M);
-    const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
-    if (L == 32)
-        hipLaunchKernelGGL((k_gq_f32<4, 1>), grid, blk, 0, st, G, ldg, M, Npad, Q, r, b, s, Tout, cpart, scale_out);
-    else
-        hipLaunchKernelGGL((k_gq_f32<4, 2>), grid, blk, 0, st, G, ldg, M, Npad, Q, r, b, s, Tout, cpart, scale_out);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2: Ypart[w][n][j] = sum_{i in wave's rows} G[i][n] * Tp[i][j]      (MFMA-fp32 bound)
-//
-// D = Y^T tile: A = Tp^T (32 columns j x 2 SNPs), B = G (2 SNPs x 32 samples).  Each lane loads 8 B of
-// SNP row (m + 2u + h) at sample n0 + 8c: a wave-load covers 2 rows x 256 contiguous bytes.  Byte t of
-// that load feeds accumulator tile t, whose MFMA column c is sample n0 + 8c + t.  A wave owns one
-// 256-sample block and a contiguous range of SNP rows; partial Y^T tiles go to Ypart and are summed
-// in f64 by k_reduce_y (deterministic, no atomics).
-// ------------------------------------------------------------------------------------------------
-GttPlan gtt_plan(int64_t M, int64_t Npad, int L, int target_waves) {
-    GttPlan p;
-    p.nblocks_n = Npad / kSamplePad;
-    int64_t W = target_waves / p.nblocks_n;
-    if (W < 1) W = 1;
-    const int64_t maxW = (M + 15) / 16;
-    if (W > maxW) W = maxW;
-    int64_t rpw = (M + W - 1) / W;
-    rpw = (rpw + 15) / 16 * 16;
-    W = (M + rpw - 1) / rpw;
-    p.W = (int)W;
-    p.rows_per_wave = rpw;
-    const int64_t ngroups = (p.nblocks_n + 3) / 4;
-    p.grid = ngroups * W;
-    (void)L;
-    return p;
-}
-
-template <int LT>
-__global__ __launch_bounds__(256, (LT == 1 ? 2 : 1)) void k_gtt_f32(const int8_t* __restrict__ G, int64_t ldg, int64_t M,
-                                                                    int64_t Npad, const float* __restrict__ Tp,
-                                                                    float* __restrict__ Ypart, int64_t ngroups,
-                                                                    int64_t rows_per_wave) {
-    constexpr int L = 32 * LT;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t ngroup = blockIdx.x % ngroups;
-    const int64_t wchunk = blockIdx.x / ngroups;
-    const int64_t nblock = ngroup * 4 + wv;
-    const int64_t n0 = nblock * kSamplePad;
-    if (n0 >= Npad) return;
-    const int64_t m_begin = wchunk * rows_per_wave;
-    const int64_t m_end = (m_begin + rows_per_wave < M) ? m_begin + rows_per_wave : M;
-
-    f32x16 acc[8][LT];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
-
-    const char* gbase = reinterpret_cast<const char*>(G) + n0 + 8 * c;
-    const float* tbase = Tp + c;
-
-    uint2 ga[8], gb[8];
-    float ta[8][LT], tb[8][LT];
-    auto load = [&](int64_t m, uint2(&g)[8], float(&tt)[8][LT]) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t row = m + 2 * u + h;
-            const bool ok = row < m_end;
-            const int64_t rc = ok ? row : (M - 1);
-            g[u] = *reinterpret_cast<const uint2*>(gbase + rc * ldg);
-#pragma unroll
-            for (int lt = 0; lt < LT; ++lt) {
-                const float v = tbase[rc * L + 32 * lt];
-                tt[u][lt] = ok ? v : 0.f;
-            }
-        }
-    };
-    load(m_begin, ga, ta);
-    for (int64_t m = m_begin; m < m_end; m += 16) {
-        const int64_t mn = (m + 16 < m_end) ? m + 16 : m;
-        load(mn, gb, tb);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const unsigned w = (t < 4) ? ga[u].x : ga[u].y;
-                const float bval = (float)((w >> (8 * (t & 3))) & 0xffu);
-#pragma unroll
-                for (int lt = 0; lt < LT; ++lt)
-                    acc[t][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[u][lt], bval, acc[t][lt], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            ga[u] = gb[u];
-#pragma unroll
-            for (int lt = 0; lt < LT; ++lt) ta[u][lt] = tb[u][lt];
-        }
-    }
-    // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h (+32 lt), col = c -> sample n0 + 8c + t
-    float* yp = Ypart + (wchunk * Npad) * L;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int64_t n = n0 + 8 * c + t;
-#pragma unroll
-        for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-            for (int e = 0; e < 16; e += 4) {
-                // regs e..e+3 are 4 consecutive j: one 16-byte store
-                const int j = 32 * lt + 8 * (e >> 2) + 4 * h;
-                float4 o;
-                o.x = acc[t][lt][e]; o.y = acc[t][lt][e + 1]; o.z = acc[t][lt][e + 2]; o.w = acc[t][lt][e + 3];
-                *reinterpret_cast<float4*>(yp + n * L + j) = o;
-            }
-    }
-}
-
-void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t M, int64_t Npad, const float* Tp, int L,
-                    float* Ypart, const GttPlan& plan) {
-    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
-    const dim3 grid((unsigned)plan.grid), blk(256);
-    if (L == 32)
-        hipLaunchKernelGGL((k_gtt_f32<1>), grid, blk, 0, st, G, ldg, M, Npad, Tp, Ypart, ngroups, plan.rows_per_wave);
-    else
-        hipLaunchKernelGGL((k_gtt_f32<2>), grid, blk, 0, st, G, ldg, M, Npad, Tp, Ypart, ngroups, plan.rows_per_wave);
 }
 
 __global__ __launch_bounds__(256) void k_reduce_y(const float* __restrict__ Ypart, int W, int64_t Npad, int64_t N, int L,
@@ -581,8 +340,9 @@ __global__ __launch_bounds__(256) void k_reduce_y(const float* __restrict__ Ypar
     const int j = (int)(e % L);
     double a = cvec[j];
     const int64_t stride = Npad * L;
-    for (int w = 0; w < W; ++w) a += (double)Ypart[w * stride + e];
-    Y[e] = a;
+    double sacc = 0.0;
+    for (int w = 0; w < W; ++w) sacc += (double)Ypart[w * stride + e];
+    Y[e] = a + 512.0 * sacc;   // 2^9 of the fp8-subnormal dosage trick (gemm_f32.hip), exact
 }
 void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, int64_t N, int L, const double* c, double* Y) {
     const int64_t total = N * L;
@@ -592,25 +352,48 @@ void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, in
 // ------------------------------------------------------------------------------------------------
 // Small helpers (HBM/latency bound, negligible next to K1/K2).
 // ------------------------------------------------------------------------------------------------
+// out[e] = sum_p part[p][e] in f64, deterministic (fixed summation tree), two stages so that thousands of
+// parts do not serialise behind one block's load latency: stage 1 = S slices of the part axis, stage 2 = S -> 1.
 template <typename T>
 __global__ __launch_bounds__(256) void k_sum_partials(const T* __restrict__ part, int64_t P, int64_t E,
-                                                      double* __restrict__ out) {
-    // one block per 64 outputs; 4 waves stride over P, LDS combine in fixed order -> deterministic
+                                                      double* __restrict__ out, int S) {
     __shared__ double red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + lane;
-    double a = 0.0;
-    if (e < E)
-        for (int64_t p = wv; p < P; p += 4) a += (double)part[p * E + e];
-    red[wv][lane] = a;
+    const int s = blockIdx.y;
+    const int64_t per = (P + S - 1) / S;
+    const int64_t p0 = s * per, p1 = (p0 + per < P) ? p0 + per : P;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (e < E) {
+        int64_t p = p0 + wv;
+        for (; p + 12 < p1; p += 16) {
+            a0 += (double)part[p * E + e]; a1 += (double)part[(p + 4) * E + e];
+            a2 += (double)part[(p + 8) * E + e]; a3 += (double)part[(p + 12) * E + e];
+        }
+        for (; p < p1; p += 4) a0 += (double)part[p * E + e];
+    }
+    red[wv][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (wv == 0 && e < E) out[e] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (wv == 0 && e < E) out[(int64_t)s * E + e] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
-void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out) {
-    hipLaunchKernelGGL((k_sum_partials<float>), dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, part, P, E, out);
+static int sum_slices(int64_t P) { int64_t s = (P + 63) / 64; return (int)(s < 1 ? 1 : (s > 64 ? 64 : s)); }
+template <typename T>
+static void launch_sum_partials_t(hipStream_t st, const T* part, int64_t P, int64_t E, double* out, double* scratch) {
+    const int S = sum_slices(P);
+    const dim3 blk(256);
+    if (S == 1) {
+        hipLaunchKernelGGL((k_sum_partials<T>), dim3((unsigned)((E + 63) / 64), 1), blk, 0, st, part, P, E, out, 1);
+    } else {
+        hipLaunchKernelGGL((k_sum_partials<T>), dim3((unsigned)((E + 63) / 64), S), blk, 0, st, part, P, E, scratch, S);
+        hipLaunchKernelGGL((k_sum_partials<double>), dim3((unsigned)((E + 63) / 64), 1), blk, 0, st, (const double*)scratch,
+                           (int64_t)S, E, out, 1);
+    }
 }
-void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out) {
-    hipLaunchKernelGGL((k_sum_partials<double>), dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, part, P, E, out);
+void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out, double* scratch) {
+    launch_sum_partials_t<float>(st, part, P, E, out, scratch);
+}
+void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out, double* scratch) {
+    launch_sum_partials_t<double>(st, part, P, E, out, scratch);
 }
 
 // Gram: part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c]  (f64 accumulate)
@@ -672,7 +455,7 @@ __global__ __launch_bounds__(256) void k_apply_right(double* __restrict__ X, int
 #pragma unroll 8
     for (int j = 0; j < L; ++j) a += xs[rr][j] * zs[j][cc];
     if (n < rows) X[n * L + cc] = a;
-    if (Qout && n < rows_pad) Qout[n * L + cc] = (n < rows) ? (float)a : 0.f;
+    if (Qout && n < rows_pad) Qout[blocked_q_index(n, cc, L >> 5)] = (n < rows) ? (float)a : 0.f;
 }
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,
                                 int64_t rows_pad) {
@@ -682,7 +465,8 @@ void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, 
 }
 
 // out[n][kc] = sum_j X[row(n)][j] Z[j][kc];  one thread per output element
-__global__ __launch_bounds__(256) void k_rightmul(const float* __restrict__ X, const int64_t* __restrict__ row_ids,
+template <typename TX>
+__global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, const int64_t* __restrict__ row_ids,
                                                   int64_t nrows, int L, const double* __restrict__ Z, int K,
                                                   double* __restrict__ out64, float* __restrict__ out32) {
     extern __shared__ double zsm[];
@@ -693,29 +477,29 @@ __global__ __launch_bounds__(256) void k_rightmul(const float* __restrict__ X, c
     const int64_t n = t / K;
     const int kc = (int)(t - n * K);
     const int64_t src = row_ids ? row_ids[n] : n;
-    const float* x = X + src * L;
+    const TX* x = X + src * L;
     double a = 0.0;
     for (int j = 0; j < L; ++j) a += (double)x[j] * zsm[j * K + kc];
     if (out64) out64[t] = a;
     if (out32) out32[t] = (float)a;
 }
-void launch_rightmul_f32(hipStream_t st, const float* X, int64_t rows, int L, const double* Z, int K, double* out64,
+void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
                          float* out32) {
     const int64_t total = rows * K;
-    hipLaunchKernelGGL(k_rightmul, dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X,
+    hipLaunchKernelGGL((k_rightmul<double>), dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X,
                        (const int64_t*)nullptr, rows, L, Z, K, out64, out32);
 }
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
                                 const double* Z, int K, float* out32) {
     const int64_t total = nrows * K;
     if (total == 0) return;
-    hipLaunchKernelGGL(k_rightmul, dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X, row_ids,
+    hipLaunchKernelGGL((k_rightmul<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X, row_ids,
                        nrows, L, Z, K, (double*)nullptr, out32);
 }
 
-constexpr int kColsumRowsPerBlock = 2048;
+constexpr int kColsumRowsPerBlock = 256;
 int64_t colsum_num_parts(int64_t rows) { return (rows + kColsumRowsPerBlock - 1) / kColsumRowsPerBlock; }
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t rows, int L, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ X, int64_t rows, int L, double* __restrict__ part) {
     __shared__ double red[256];
     const int cc = threadIdx.x % L, rg = threadIdx.x / L, nrg = 256 / L;
     const int64_t r0 = (int64_t)blockIdx.x * kColsumRowsPerBlock;
@@ -729,7 +513,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int
         part[(int64_t)blockIdx.x * L + cc] = a;
     }
 }
-void launch_colsum_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part) {
+void launch_colsum_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part) {
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)colsum_num_parts(rows)), dim3(256), 0, st, X, rows, L, part);
 }
 
@@ -800,27 +584,30 @@ void launch_expand_loadings(hipStream_t st, const float* load, const int64_t* ro
     hipLaunchKernelGGL(k_expand_loadings, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, load, rows, n_pca, k, L, Tp);
 }
 
-// one wave = 64 rows; lane = row; loops over the L columns (row stride L floats: L2-friendly, tiny kernel)
-__global__ __launch_bounds__(256) void k_scale_rows(float* __restrict__ X, int64_t M, int L, const float* __restrict__ r,
-                                                    const float* __restrict__ b, float* __restrict__ cpart) {
+// one wave = 64 rows; lane = row; loops over the L columns (tiny kernel: transform path only)
+__global__ __launch_bounds__(256) void k_scale_rows(const float* __restrict__ X, int64_t M, int64_t Mpad, int L,
+                                                    const float* __restrict__ r, const float* __restrict__ b,
+                                                    float* __restrict__ Tb, float* __restrict__ cpart) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wave >= (M + 63) / 64) return;
+    if (wave >= (Mpad + 63) / 64) return;
     const int64_t i = wave * 64 + lane;
     const bool live = i < M;
     const float ri = live ? r[i] : 0.f, bi = live ? b[i] : 0.f;
+    const int LT = L >> 5;
     for (int j = 0; j < L; ++j) {
         const float x = live ? X[i * L + j] : 0.f;
-        if (live) X[i * L + j] = ri * x;
+        if (i < Mpad) Tb[blocked_t_index(i, j, LT)] = ri * x;
         float cv = bi * x;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cv += __shfl_xor(cv, o);
         if (lane == 0) cpart[wave * L + j] = cv;
     }
 }
-void launch_scale_rows(hipStream_t st, float* X, int64_t M, int L, const float* r, const float* b, float* cpart) {
-    const int64_t waves = (M + 63) / 64;
-    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, X, M, L, r, b, cpart);
+void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, int L, const float* r, const float* b,
+                       float* Tb, float* cpart) {
+    const int64_t waves = (Mpad + 63) / 64;
+    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, X, M, Mpad, L, r, b, Tb, cpart);
 }
 
 }  // namespace gpca
