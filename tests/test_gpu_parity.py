@@ -332,3 +332,97 @@ def test_timings_exposed(gpca, oracle, engine):
     assert t["gemm_GQ"]["launches"] == 3 and t["gemm_GtT"]["launches"] == 3
     assert t["gemm_GQ"]["flops"] == pytest.approx(3 * 2.0 * 3000 * 512 * 20)
     assert t["gemm_GQ"]["total_ms"] > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/make_golden.py)
+# ------------------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_golden_synth_fixture(gpca, oracle, engine):
+    z = np.load(os.path.join(GOLD, "synth_2048x192.npz"))
+    G = z["G"]; M, N = G.shape; k = int(z["k"]); seed = int(z["seed"])
+    engine.synth_genotypes(M, N, seed, z["thresh"])
+    assert np.array_equal(engine.download_genotypes_i8(), G)            # generator: bit-exact vs the pinned bytes
+    st = engine.snp_stats(gpca.QcConfig.none())
+    counts, _ = engine.snp_qc_detail()
+    assert np.array_equal(counts, z["counts"]) and np.array_equal(st["mu"], z["mu"]) and np.array_equal(st["keep"], z["keep"])
+    assert np.all(np.abs(st["sigma"] - z["sigma"]) <= np.spacing(z["sigma"]))
+    engine.rsvd(k, 10, 2, seed=seed)
+    assert np.max(np.abs(engine.eigenvalues() - z["eigenvalues"]) / z["eigenvalues"]) < TOL_EV
+    assert oracle.max_abs_dpc(engine.scores(f64=True), z["scores"]) < TOL_PC
+    assert oracle.max_abs_dpc(engine.loadings().astype(np.float64), z["loadings"]) < TOL_PC
+
+
+def test_bed2bit_decode_reference_fixture(gpca, oracle, engine):
+    """PLINK 2-bit decode on a slice of the reference's own data/chr22_subset50.bed (64 samples),
+    count_a1 semantics of prepare.rs:622-629; byte layout per the reference's tests/disk.py:89-135."""
+    z = np.load(os.path.join(GOLD, "chr22_subset50_slice.npz"))
+    rows = z["bed_rows"]; n = int(z["n_samples"]); ref = z["dosage_count_a1"]
+    engine.upload_bed2bit(rows, n)
+    assert engine.dims() == (rows.shape[0], n)
+    assert np.array_equal(engine.download_genotypes_i8(), ref)
+    for qc in (gpca.QcConfig.none(), gpca.QcConfig()):
+        st = engine.snp_stats(qc)
+        counts, reason = engine.snp_qc_detail()
+        o = oracle.snp_stats(ref, n, qc.min_snp_call_rate, qc.min_snp_maf, qc.max_snp_hwe_p_value)
+        assert np.array_equal(counts, o["counts"]) and np.array_equal(st["keep"], o["keep"]) and np.array_equal(reason, o["reason"])
+        assert np.array_equal(st["mu"], o["mu"]) and np.all(np.abs(st["sigma"] - o["sigma"]) <= np.spacing(o["sigma"]))
+    # synthetic ragged BED: N not a multiple of 4, all four codes present
+    rng = np.random.default_rng(3)
+    for n2 in (1, 5, 63, 130, 257):
+        b = rng.integers(0, 256, size=(37, (n2 + 3) // 4), dtype=np.uint8)
+        lut = np.array([2, -127, 1, 0], np.int8)
+        exp = np.empty((37, b.shape[1] * 4), np.int8)
+        for s in range(4):
+            exp[:, s::4] = lut[(b >> (2 * s)) & 3]
+        engine.upload_bed2bit(b, n2)
+        assert np.array_equal(engine.download_genotypes_i8(), exp[:, :n2])
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1] at full size (1M SNPs x 10k samples): size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties(gpca, oracle):
+    M, N, k, seed = 1_000_000, 10_000, 20, 1
+    th = gpca.synth_thresholds(M, 3, seed=seed)
+    with gpca.GpcaEngine() as e:
+        e.synth_genotypes(M, N, seed, th)
+        st = e.snp_stats(gpca.QcConfig.none())
+        counts, _ = e.snp_qc_detail()
+        # (1) generator + stats: spot rows against the oracle (same global row index -> same bytes)
+        rows = np.array([0, 1, 65535, 65536, 123457, 777777, M - 1])
+        for i in rows:
+            g_row = oracle.synth_genotypes(1, N, seed, th[i:i + 1], snp_offset=int(i))
+            o = oracle.snp_stats(g_row, N, 0.0, 0.0, 1.0)
+            assert np.array_equal(counts[i], o["counts"][0]) and st["mu"][i] == o["mu"][0]
+            assert abs(float(st["sigma"][i]) - float(o["sigma"][0])) <= np.spacing(o["sigma"][0])
+            blk = e.standardize_block([int(np.searchsorted(e.pca_snp_rows(), i))], np.arange(0, N, 997))
+            ref, err = oracle.standardize_block(g_row, o["mu"], o["sigma"], [0], np.arange(0, N, 997))
+            assert err is None and np.array_equal(blk, ref)
+        assert counts[:, 0].min() == N and int(st["keep"].sum()) == M         # no missing, everything kept
+        # checksum of checksums: total allele count = sum of row sums
+        tot = int(counts[:, 2].astype(np.int64).sum() + 2 * counts[:, 3].astype(np.int64).sum())
+        assert tot == int(np.rint((st["mu"].astype(np.float64) * N).sum()))
+        e.rsvd(k, 10, 2, seed=seed)
+        sc = e.scores(f64=True); ev = e.eigenvalues(); sv = e.singular_values(); ld = e.loadings()
+        # (2) scores = V * s with orthonormal V; loadings orthonormal
+        gram = sc.T @ sc
+        assert np.allclose(np.diag(gram), sv[:k] ** 2, rtol=1e-6)
+        off = gram - np.diag(np.diag(gram))
+        assert np.max(np.abs(off)) < 1e-6 * sv[0] ** 2
+        lg = ld.astype(np.float64).T @ ld.astype(np.float64)
+        assert np.max(np.abs(lg - np.eye(k))) < 1e-4
+        assert np.allclose(ev, sv[:k] ** 2 / (N - 1), rtol=1e-12) and np.all(np.diff(ev) <= 0)
+        # (3) the standardised matrix is row-centred: every PC is orthogonal to the all-ones sample vector
+        assert np.max(np.abs(sc.sum(axis=0))) < 1e-6 * np.abs(sc).sum(axis=0).max()
+        # (4) idempotence: same seed -> bitwise same answer; 3 populations -> exactly 2 structured eigenvalues
+        e.rsvd(k, 10, 2, seed=seed)
+        assert np.array_equal(e.eigenvalues(), ev) and np.array_equal(e.scores(f64=True), sc)
+        assert ev[1] > 20 * ev[2]
+        # (5) PCA::transform consistency: A^T U = V s up to convergence of the trailing (noise) PCs
+        tr = e.transform()
+        assert oracle.max_abs_dpc(tr[:, :2], sc[:, :2]) < 1e-4
