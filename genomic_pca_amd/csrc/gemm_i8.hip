@@ -1,0 +1,396 @@
+// Exact-integer variants of the two tall-skinny products on v_mfma_i32_32x32x32_i8 (GPCA_PREC_I8_EXACT).
+//
+// The dosage bytes 0/1/2 ARE the int8 MFMA operand -- no conversion instruction at all -- and the skinny f32/f64
+// operand X (Q or T') is split per column into kDigits = 4 signed base-128 digits of a fixed-point value
+//     x_int = rint(x / colmax_j * S),  S = 0.49 * 128^4,   x_int = sum_d digit_d * 128^d,  digit_d in [-64, 63]
+// (resolution colmax * 7.6e-9, finer than f32's 6e-8).  Every digit plane is one int8 MFMA with exact i32
+// accumulation (|acc| <= 128 * K < 2^31 for K <= 1.6e7), planes are recombined exactly in f64
+// (|sum| <= K * 2^28 < 2^53) and scaled once.  Consequences: the products are exact for the quantised operand,
+// bitwise independent of the grid partition, and need 4 x 32-cycle MFMAs per 1 KiB of G instead of
+// 16 x 64-cycle f32 MFMAs -> ~10x less matrix-core time per byte, so both kernels are HBM-bound
+// (1 B per genotype per pass; roofline = 8 TB/s).
+//
+//   K1  k_gq_i8 :  T = r o (G Q) + b s^T      A = G tile (32 SNPs x 32 samples: 16 B per lane straight from the row),
+//                                             B = digit plane of Q (blocked [chunk][d][lane][16 B])
+//   K2  k_gtt_i8:  Y^T tiles = T'^T G         A = digit plane of T' (blocked [k-block][d][lane][16 B]),
+//                                             B = G^T tile: each lane loads 16 rows x 4 B and transposes the 16x4
+//                                             byte block in registers (32 v_perm_b32) into 4 k-contiguous operands
+#include "kernels.h"
+#include <cstdlib>
+
+namespace gpca {
+
+// cache policy of the once-read genotype stream: 0 = default, 2 = non-temporal (GPCA_STREAM_NT=1)
+static const bool g_stream_nt = [] { const char* e = getenv("GPCA_STREAM_NT"); return e && atoi(e) != 0; }();
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define GPCA_RSRC_FLAGS 0x00020000
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc8(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, GPCA_RSRC_FLAGS);
+}
+
+__device__ __forceinline__ double combine_digits(const i32x16 (&a)[kDigits], int e) {
+    // exact: each |a| < 2^31, weights are powers of two, total < 2^53
+    return (double)a[0][e] + 128.0 * (double)a[1][e] + 16384.0 * (double)a[2][e] + 2097152.0 * (double)a[3][e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------
+// G is loaded a 128-sample super-chunk at a time: the four 32-byte pieces of a row's 128-byte line are requested
+// back to back (one L1 miss + three hits) instead of one per compute phase (four L2->L1 line fills, which made
+// the L2->L1 path, not HBM, the limit: 3.7 TB/s).  Q digit planes (L2-resident, full-line reads) ride a 4-stage ring.
+template <int R>
+struct Gq8G { i32x4 g[4][R]; };
+struct Gq8Q { i32x4 q[kDigits]; };
+
+template <int R, int AUX>
+__device__ __forceinline__ void gq8_load_g(Gq8G<R>& b, __amdgpu_buffer_rsrc_t rg, const uint32_t (&gvo)[R], uint32_t s0) {
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b.g[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], s0 + 32u * j, AUX);
+}
+__device__ __forceinline__ void gq8_load_q(Gq8Q& b, __amdgpu_buffer_rsrc_t rq, uint32_t qvo, uint32_t qoff) {
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) b.q[d] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, qoff + d * 1024, 0);
+}
+template <int R>
+__device__ __forceinline__ void gq8_compute(const i32x4 (&g)[R], const Gq8Q& q, i32x16 (&acc)[R][kDigits]) {
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+        for (int t = 0; t < R; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(g[t], q.q[d], acc[t][d], 0, 0, 0);
+}
+
+template <int R, int AUX>
+__device__ __forceinline__ void gq8_group(const int8_t* __restrict__ G, int64_t ldg, int64_t nsuper,
+                                          const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          float& csum, int64_t row0, int c, int h, int lane) {
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
+    uint32_t gvo[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)((32 * t + c) * ldg + 16 * h);
+    const uint32_t qvo = (uint32_t)(lane * 16);
+    constexpr uint32_t QCH = kDigits * 1024;   // bytes of digit planes per 32-sample chunk
+
+    i32x16 acc[R][kDigits];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    // nsuper (128-sample super-chunks) is even: samples are padded to a multiple of 256
+    Gq8G<R> GA, GB;
+    Gq8Q Q0, Q1, Q2, Q3;
+    {
+        const __amdgpu_buffer_rsrc_t rq0 = make_rsrc8(Qd);
+        gq8_load_g<R, AUX>(GA, rg, gvo, 0u);
+        gq8_load_q(Q0, rq0, qvo, 0u); gq8_load_q(Q1, rq0, qvo, QCH); gq8_load_q(Q2, rq0, qvo, 2 * QCH);
+    }
+#define GQ8_PHASE(GCUR, J, QCUR, QNEXT, QNEXT_OFF)                         \
+    gq8_load_q(QNEXT, rq, qvo, (QNEXT_OFF));                                \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    gq8_compute<R>(GCUR.g[J], QCUR, acc);                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int64_t sc = 0; sc < nsuper; sc += 2) {
+        const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd + sc * 4 * QCH);
+        const uint32_t s0 = (uint32_t)(sc * 128);
+        const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;   // the last trip re-loads its own data (unused)
+        gq8_load_g<R, AUX>(GB, rg, gvo, s0 + 128u);
+        GQ8_PHASE(GA, 0, Q0, Q3, 3 * QCH)
+        GQ8_PHASE(GA, 1, Q1, Q0, 4 * QCH)
+        GQ8_PHASE(GA, 2, Q2, Q1, 5 * QCH)
+        GQ8_PHASE(GA, 3, Q3, Q2, 6 * QCH)
+        gq8_load_g<R, AUX>(GA, rg, gvo, s0 + 256u * more);
+        GQ8_PHASE(GB, 0, Q0, Q3, 7 * QCH)
+        GQ8_PHASE(GB, 1, Q1, Q0, 8 * QCH * more)
+        GQ8_PHASE(GB, 2, Q2, Q1, 8 * QCH * more + QCH)
+        GQ8_PHASE(GB, 3, Q3, Q2, 8 * QCH * more + 2 * QCH)
+    }
+#undef GQ8_PHASE
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float ri = rv[row], bi = bv[row];
+            const float gq = (float)(combine_digits(acc[t], e) * qs);
+            const float tv = ri * gq + bi * sj;
+            csum += bi * tv;
+            Tout[row * 32 + c] = scale_out ? ri * tv : tv;
+        }
+    }
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256, 1) void k_gq_i8(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nsuper,
+                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
+                                                   const float* __restrict__ rv, const float* __restrict__ bv,
+                                                   const float* __restrict__ sv, float* __restrict__ Tout,
+                                                   float* __restrict__ cpart, int scale_out) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    int64_t u = (units * wave) / waves;
+    const int64_t u_end = (units * (wave + 1)) / waves;
+    float csum = 0.f;
+    const float sj = sv[c];
+    const double qs = qscale[c];
+    for (; u + 4 <= u_end; u += 4) gq8_group<4, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane);
+    if (u + 2 <= u_end) { gq8_group<2, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 2; }
+    if (u + 1 <= u_end) { gq8_group<1, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 1; }
+    const float o = csum + __shfl_xor(csum, 32);
+    if (h == 0) cpart[wave * 32 + c] = o;
+}
+
+void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
+                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
+                  int scale_out) {
+    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
+    const int64_t nsuper = (N + 255) / 256 * 2;   // 128-sample super-chunks, even count (= Npad / 128)
+    if (g_stream_nt) hipLaunchKernelGGL((k_gq_i8<2>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out);
+    else hipLaunchKernelGGL((k_gq_i8<0>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2
+// ------------------------------------------------------------------------------------------------
+Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves) {
+    Gtt8Plan p;
+    p.nblocks_n = Npad / 128;
+    int64_t W = target_waves / p.nblocks_n;
+    if (W < 1) W = 1;
+    const int64_t maxW = Mpad / 128;
+    if (W > maxW) W = maxW;
+    int64_t rpw = (Mpad + W - 1) / W;
+    rpw = (rpw + 127) / 128 * 128;       // k-blocks per wave: multiple of 4 (Mpad is a multiple of 128)
+    W = (Mpad + rpw - 1) / rpw;
+    p.W = (int)W;
+    p.rows_per_wave = rpw;
+    p.grid = ((p.nblocks_n + 3) / 4) * W;
+    return p;
+}
+
+struct Gtt8Buf { int g[16]; i32x4 t[kDigits]; };
+
+template <int AUX>
+__device__ __forceinline__ void gtt8_load(Gtt8Buf& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off, uint32_t ldg,
+                                          __amdgpu_buffer_rsrc_t rt, uint32_t tvo, uint32_t toff) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b.g[i] = __builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ldg, AUX);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) b.t[d] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, toff + d * 1024, 0);
+}
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi: 4..7, lo: 0..3}
+__device__ __forceinline__ int permb(int hi, int lo, unsigned sel) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, sel); }
+
+__device__ __forceinline__ void gtt8_compute(const Gtt8Buf& b, i32x16 (&acc)[4][kDigits]) {
+    // 16 rows x 4 samples of bytes -> 4 operands of 16 k-contiguous bytes (operand t = sample byte t of rows 0..15)
+    i32x4 bt[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int r0 = b.g[4 * w], r1 = b.g[4 * w + 1], r2 = b.g[4 * w + 2], r3 = b.g[4 * w + 3];
+        const int x0 = permb(r1, r0, 0x05010400u), x1 = permb(r1, r0, 0x07030602u);   // [r0.b0 r1.b0 r0.b1 r1.b1], [..b2 ..b3]
+        const int y0 = permb(r3, r2, 0x05010400u), y1 = permb(r3, r2, 0x07030602u);
+        bt[0][w] = permb(y0, x0, 0x05040100u);   // [r0.b0 r1.b0 r2.b0 r3.b0]
+        bt[1][w] = permb(y0, x0, 0x07060302u);   // byte 1 of rows 4w..4w+3
+        bt[2][w] = permb(y1, x1, 0x05040100u);
+        bt[3][w] = permb(y1, x1, 0x07060302u);
+    }
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.t[d], bt[t], acc[t][d], 0, 0, 0);
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G, int64_t ldg, int64_t Mpad, int64_t Npad,
+                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
+                                                    int64_t ngroups, int64_t rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ngroup = blockIdx.x % ngroups;
+    const int64_t wchunk = blockIdx.x / ngroups;
+    const int64_t nblock = ngroup * 4 + wv;
+    const int64_t n0 = nblock * 128;
+    if (n0 >= Npad) return;
+    const int64_t m_begin = wchunk * rows_per_wave;
+    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
+    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
+
+    i32x16 acc[4][kDigits];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    const uint32_t gvo = (uint32_t)(16 * h * ldg + 4 * c);
+    const uint32_t tvo = (uint32_t)(lane * 16);
+    constexpr uint32_t TKB = kDigits * 1024;                // bytes of digit planes per 32-row k-block
+    const int8_t* gp = G + m_begin * ldg + n0;
+    const int8_t* tp = Td + (m_begin >> 5) * TKB;
+    // 4-stage register ring over 32-row k-blocks (kblocks is a multiple of 4): 3 blocks in flight per wave
+    Gtt8Buf B0, B1, B2, B3;
+    {
+        const __amdgpu_buffer_rsrc_t rg0 = make_rsrc8(gp), rt0 = make_rsrc8(tp);
+        gtt8_load<AUX>(B0, rg0, gvo, 0u, (uint32_t)ldg, rt0, tvo, 0u);
+        gtt8_load<AUX>(B1, rg0, gvo, 32u * (uint32_t)ldg, (uint32_t)ldg, rt0, tvo, TKB);
+        gtt8_load<AUX>(B2, rg0, gvo, 64u * (uint32_t)ldg, (uint32_t)ldg, rt0, tvo, 2 * TKB);
+    }
+    for (int64_t kb = 0; kb < kblocks; kb += 4) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc8(gp + kb * 32 * ldg);   // re-based every trip: offsets stay < 256 * ldg
+        const __amdgpu_buffer_rsrc_t rt = make_rsrc8(tp + kb * TKB);
+        const uint32_t more = (kb + 4 < kblocks) ? 1u : 0u;
+        const uint32_t L32 = 32u * (uint32_t)ldg;
+        gtt8_load<AUX>(B3, rg, gvo, 3u * L32, (uint32_t)ldg, rt, tvo, 3 * TKB);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt8_compute(B0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt8_load<AUX>(B0, rg, gvo, 4u * L32 * more, (uint32_t)ldg, rt, tvo, 4 * TKB * more);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt8_compute(B1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt8_load<AUX>(B1, rg, gvo, (4u * more + 1u) * L32, (uint32_t)ldg, rt, tvo, (4 * more + 1) * TKB);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt8_compute(B2, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt8_load<AUX>(B2, rg, gvo, (4u * more + 2u) * L32, (uint32_t)ldg, rt, tvo, (4 * more + 2) * TKB);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt8_compute(B3, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h, col = c -> sample n0 + 4c + t.  Exact integers as f64.
+    double* yp = Ypart + (wchunk * Npad) * 32;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t n = n0 + 4 * c + t;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
+            double2 o;
+            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
+            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
+        }
+    }
+}
+
+void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
+                   double* Ypart, const Gtt8Plan& plan) {
+    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    if (g_stream_nt) hipLaunchKernelGGL((k_gtt_i8<2>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+    else hipLaunchKernelGGL((k_gtt_i8<0>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+}
+
+// Y[n][j] = c[j] + tscale[j] * sum_w Ypart[w][n][j]    (the integer sum is exact and order-independent)
+__global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
+                                                     const double* __restrict__ cvec, const double* __restrict__ tscale,
+                                                     double* __restrict__ Y) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * 32) return;
+    const int j = (int)(e & 31);
+    const int64_t stride = Npad * 32;
+    double s = 0.0;
+    for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
+    Y[e] = cvec[j] + tscale[j] * s;
+}
+void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
+                        const double* tscale, double* Y) {
+    const int64_t total = N * 32;
+    hipLaunchKernelGGL(k_reduce_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quantisation of the skinny operand: column abs-max -> scale; X[rows][32] -> digit planes
+// blocked [block = row/32][d][lane = 32*((row%32)/16) + col][j = row%16] (16 B per lane per plane).
+// ------------------------------------------------------------------------------------------------
+constexpr int kAbsmaxRowsPerBlock = 1024;
+int64_t absmax_num_parts(int64_t rows) { return (rows + kAbsmaxRowsPerBlock - 1) / kAbsmaxRowsPerBlock; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_absmax(const T* __restrict__ X, int64_t rows, double* __restrict__ part) {
+    __shared__ double red[256];
+    const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * kAbsmaxRowsPerBlock;
+    const int64_t r1 = (r0 + kAbsmaxRowsPerBlock < rows) ? r0 + kAbsmaxRowsPerBlock : rows;
+    double a = 0.0;
+    for (int64_t n = r0 + rg; n < r1; n += 8) { const double v = fabs((double)X[n * 32 + cc]); a = v > a ? v : a; }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < 8; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
+        part[(int64_t)blockIdx.x * 32 + cc] = a;
+    }
+}
+// scale[j] = colmax_j / S (multiplier back to real units), inv[j] = S / colmax_j; colmax 0 -> scale 0, inv 0
+__global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict__ part, int64_t P, double* __restrict__ scale,
+                                                       double* __restrict__ inv) {
+    __shared__ double red[1024];
+    const int cc = threadIdx.x & 31, pg = threadIdx.x >> 5;   // 32 part-groups
+    double a = 0.0;
+    for (int64_t p = pg; p < P; p += 32) { const double v = part[p * 32 + cc]; a = v > a ? v : a; }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (pg != 0) return;
+    for (int g = 1; g < 32; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
+    const double S = 0.49 * 268435456.0;   // 0.49 * 128^4
+    scale[cc] = a > 0.0 ? a / S : 0.0;
+    inv[cc] = a > 0.0 ? S / a : 0.0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64_t rows, int64_t rows_pad,
+                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk * 32 >= rows_pad) return;
+    const int cc = lane & 31, hh = lane >> 5;
+    const double sc = inv[cc];
+    unsigned w[kDigits][4];
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[d][q] = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t row = blk * 32 + 16 * hh + j;
+        const double x = row < rows ? (double)X[row * 32 + cc] : 0.0;
+        long long v = __double2ll_rn(x * sc);
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d) {
+            long long dg;
+            if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
+            w[d][j >> 2] |= ((unsigned)(dg & 0xff)) << (8 * (j & 3));
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d)
+        *reinterpret_cast<uint4*>(Xd + ((blk * kDigits + d) * 64 + lane) * 16) = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
+}
+
+template <typename T>
+static void quantize_t(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, double* part, double* scale, double* inv,
+                       int8_t* Xd) {
+    const int64_t P = absmax_num_parts(rows);
+    hipLaunchKernelGGL((k_col_absmax<T>), dim3((unsigned)P), dim3(256), 0, st, X, rows, part);
+    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv);
+    const int64_t blocks = rows_pad / 32;
+    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd);
+}
+void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
+                         double* inv, int8_t* Xd) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd); }
+void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
+                         double* inv, int8_t* Xd) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd); }
+
+}  // namespace gpca

@@ -83,6 +83,11 @@ struct gpca_handle {
     std::vector<double> eig, sv;
     GttPlan plan{};
     GqPlan gqplan{};
+    Gtt8Plan plan8{};
+    // exact-integer path
+    int8_t *dQd = nullptr, *dTd = nullptr;
+    double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
+    size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
     int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
 
     // comm
@@ -205,6 +210,8 @@ static void free_ws(gpca_handle* h) {
     dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
     dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
+    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
+    h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
     h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
     h->have_rsvd = false;
 }
@@ -576,6 +583,19 @@ static int stage_sum_c(gpca_handle* h, int64_t parts) {
 // Y = A^T T  (T' = r o T already in dT, c = b^T T in d_c), then the exchange step
 static int stage_AtT(gpca_handle* h) {
     const double elems = (double)h->M * (double)h->N;
+    if (h->precision == GPCA_PREC_I8_EXACT) {
+        // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64
+        launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd);
+        HIPCHK(hipGetLastError());
+        {
+            ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, elems);
+            launch_gtt_i8(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+        }
+        HIPCHK(hipGetLastError());
+        launch_reduce_y_i8(h->st, h->dYpart64, h->plan8.W, h->ldg, h->N, h->d_c, h->d_tscale, h->dY);
+        HIPCHK(hipGetLastError());
+        return allreduce_f64(h, h->dY, h->N * h->L);
+    }
     {
         ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, elems);
         launch_gtt_f32(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTb, h->L, h->dYpart, h->plan);
@@ -589,6 +609,15 @@ static int stage_AtT(gpca_handle* h) {
 // T = A Q (scale_out: r o T and c)
 static int stage_AQ(gpca_handle* h, int scale_out) {
     const double elems = (double)h->M * (double)h->N;
+    if (h->precision == GPCA_PREC_I8_EXACT) {
+        {
+            ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, elems);
+            launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+        }
+        HIPCHK(hipGetLastError());
+        if (scale_out) CHK(stage_sum_c(h, h->gqplan.waves));
+        return GPCA_OK;
+    }
     {
         ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, elems);
         launch_gq_f32(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQ, h->L, h->d_r, h->d_b, h->d_s32, h->dT, scale_out ? h->dTb : nullptr, h->d_cpart);
@@ -629,6 +658,10 @@ static int stage_orth(gpca_handle* h) {
     HIPCHK(hipGetLastError());
     launch_f64_to_f32(h->st, h->d_s64, h->d_s32, L);
     HIPCHK(hipGetLastError());
+    if (h->precision == GPCA_PREC_I8_EXACT) {   // digit planes of the basis for the int8 G Q product
+        launch_quantize_f64(h->st, h->dY, h->N, h->ldg, h->d_part64, h->d_qscale, h->d_qinv, h->dQd);
+        HIPCHK(hipGetLastError());
+    }
     return GPCA_OK;
 }
 
@@ -645,13 +678,23 @@ static int ensure_workspace(gpca_handle* h) {
     const int64_t cparts = std::max(h->gqplan.waves, omega_num_parts(h->Mpad));
     CHK(ensure(h, h->d_cpart, h->cap_cpart, (size_t)cparts * L));
     CHK(ensure(h, h->dY, h->cap_Y, (size_t)N * L));
-    const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L});
+    const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L, absmax_num_parts(h->Mpad) * (int64_t)32});
     CHK(ensure(h, h->d_part64, h->cap_part64, (size_t)p64));
     if (!h->d_c) {
         HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));
         HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, 64 * 64 * 8));
         HIPCHK(hipMalloc((void**)&h->dZ, 64 * 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
         HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
+    }
+    if (h->precision == GPCA_PREC_I8_EXACT) {
+        h->plan8 = gtt8_plan(h->Mpad, Npad, h->gtt_waves_target);
+        CHK(ensure(h, h->dQd, h->cap_Qd, (size_t)Npad * 32 * kDigits));
+        CHK(ensure(h, h->dTd, h->cap_Td, (size_t)h->Mpad * 32 * kDigits));
+        CHK(ensure(h, h->dYpart64, h->cap_Ypart64, (size_t)h->plan8.W * (size_t)Npad * 32));
+        if (!h->d_qscale) {
+            HIPCHK(hipMalloc((void**)&h->d_qscale, 32 * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, 32 * 8));
+            HIPCHK(hipMalloc((void**)&h->d_tscale, 32 * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, 32 * 8));
+        }
     }
     size_t cap2 = h->cap_scores;
     CHK(ensure(h, h->d_scores64, h->cap_scores, (size_t)N * h->k));
@@ -674,7 +717,8 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     if (h->flags & 1u) return fail(h, GPCA_ERR_MISSING_GENOTYPE,
         "Unexpected missing genotype (-127i8) in a PCA SNP. This should have been filtered by QC.");  // prepare.rs:1909-1911
     if (h->flags & 2u) return fail(h, GPCA_ERR_INVALID_GENOTYPE, "a PCA SNP holds a dosage outside {0,1,2}");
-    if (h->precision != GPCA_PREC_F32_MFMA) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: unsupported precision mode");
+    if (h->precision != GPCA_PREC_F32_MFMA && h->precision != GPCA_PREC_I8_EXACT) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: unsupported precision mode");
+    if (h->precision == GPCA_PREC_I8_EXACT && l > 32) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: GPCA_PREC_I8_EXACT supports k + oversample <= 32 (use GPCA_PREC_F32_MFMA)");
     HIPCHK(hipSetDevice(h->device));
     h->k = k; h->l = l; h->L = l <= 32 ? 32 : 64;
     h->have_rsvd = false;
@@ -684,7 +728,8 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     // 1. sketch: T' = r o Omega, c = b^T Omega;  Y = A^T Omega;  Q = orth(Y)
     {
         ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
-        launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart);
+        if (h->precision == GPCA_PREC_I8_EXACT) launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart, 0);
+        else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart);
     }
     HIPCHK(hipGetLastError());
     CHK(stage_sum_c(h, omega_num_parts(h->Mpad)));
@@ -808,7 +853,8 @@ int transform_impl(gpca_handle* h, double* out) {
     HIPCHK(hipMemsetAsync(h->dT, 0, (size_t)h->Mpad * L * 4, h->st));
     launch_expand_loadings(h->st, h->d_load32, h->d_pca_rows, h->n_pca, k, L, h->dT);
     HIPCHK(hipGetLastError());
-    launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dTb, h->d_cpart);
+    if (h->precision == GPCA_PREC_I8_EXACT) launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dT, h->d_cpart, 0);   // in place, row-major
+    else launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dTb, h->d_cpart);
     HIPCHK(hipGetLastError());
     CHK(stage_sum_c(h, omega_num_parts(h->Mpad)));
     CHK(stage_AtT(h));

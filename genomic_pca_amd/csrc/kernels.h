@@ -46,7 +46,7 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
 // sketch operand: Tb (blocked, all Mpad rows) = r_i * Omega[i][j] (j < l, else 0); cpart[wave][j] = sum_i b_i Omega[i][j]
 int64_t omega_num_parts(int64_t Mpad);
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
-                  const float* r, const float* b, float* Tb, float* cpart);
+                  const float* r, const float* b, float* Tb, float* cpart, int blocked = 1);
 
 // K1: T = r o (G Q) + b s^T.  Tb != NULL: write r o T blocked into Tb and cpart[wave][j] = sum_i b_i T_ij
 // (power iteration); Tb == NULL: write T row-major into Tout (projection B = A Q).  Qb is the blocked basis.
@@ -92,6 +92,25 @@ void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v);
 void launch_expand_loadings(hipStream_t st, const float* load, const int64_t* rows, int64_t n_pca, int k, int L, float* Tp);
 // Tb (blocked, all Mpad rows) = r_i X[i][:]; cpart[wave][j] = sum over the wave's 64 rows of b_i X[i][j] (omega_num_parts(Mpad) waves)
 void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, int L, const float* r, const float* b,
-                       float* Tb, float* cpart);
+                       float* Tb, float* cpart, int blocked = 1);
+
+
+// ---- exact-integer path (gemm_i8.hip), L = 32 only ----------------------------------------------------------
+constexpr int kDigits = 4;   // signed base-128 digits of the skinny operand
+void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
+                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
+                  int scale_out);
+struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; };
+Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves);
+void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
+                   double* Ypart, const Gtt8Plan& plan);
+void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
+                        const double* tscale, double* Y);
+int64_t absmax_num_parts(int64_t rows);
+// X [rows][32] row-major -> digit planes Xd [rows_pad/32][kDigits][64][16 B]; scale[j] = colmax_j / S, inv = 1/scale
+void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
+                         double* inv, int8_t* Xd);
+void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
+                         double* inv, int8_t* Xd);
 
 }  // namespace gpca

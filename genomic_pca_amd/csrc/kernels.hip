@@ -291,7 +291,7 @@ int64_t omega_num_parts(int64_t Mpad) { return (Mpad + 63) / 64; }
 
 __global__ __launch_bounds__(256) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
                                                const float* __restrict__ r, const float* __restrict__ b,
-                                               float* __restrict__ Tb, float* __restrict__ cpart) {
+                                               float* __restrict__ Tb, float* __restrict__ cpart, int blocked) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_omega(int64_t M, int64_t Mpad, int l, i
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float zf = (4 * jq + t < l) ? (float)z[t] : 0.f;
-            if (i < Mpad) Tb[blocked_t_index(i, 4 * jq + t, LT)] = ri * zf;
+            if (i < Mpad) Tb[blocked ? blocked_t_index(i, 4 * jq + t, LT) : i * L + 4 * jq + t] = ri * zf;
             float cv = bi * zf;
 #pragma unroll
             for (int o2 = 32; o2 > 0; o2 >>= 1) cv += __shfl_xor(cv, o2);
@@ -327,10 +327,10 @@ __global__ __launch_bounds__(256) void k_omega(int64_t M, int64_t Mpad, int l, i
 }
 
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
-                  const float* b, float* Tb, float* cpart) {
+                  const float* b, float* Tb, float* cpart, int blocked) {
     const int64_t waves = omega_num_parts(Mpad);
     hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
-                       cpart);
+                       cpart, blocked);
 }
 
 __global__ __launch_bounds__(256) void k_reduce_y(const float* __restrict__ Ypart, int W, int64_t Npad, int64_t N, int L,
@@ -587,7 +587,7 @@ void launch_expand_loadings(hipStream_t st, const float* load, const int64_t* ro
 // one wave = 64 rows; lane = row; loops over the L columns (tiny kernel: transform path only)
 __global__ __launch_bounds__(256) void k_scale_rows(const float* __restrict__ X, int64_t M, int64_t Mpad, int L,
                                                     const float* __restrict__ r, const float* __restrict__ b,
-                                                    float* __restrict__ Tb, float* __restrict__ cpart) {
+                                                    float* __restrict__ Tb, float* __restrict__ cpart, int blocked) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wave >= (Mpad + 63) / 64) return;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_scale_rows(const float* __restrict__ X,
     const int LT = L >> 5;
     for (int j = 0; j < L; ++j) {
         const float x = live ? X[i * L + j] : 0.f;
-        if (i < Mpad) Tb[blocked_t_index(i, j, LT)] = ri * x;
+        if (i < Mpad) Tb[blocked ? blocked_t_index(i, j, LT) : i * L + j] = ri * x;
         float cv = bi * x;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cv += __shfl_xor(cv, o);
@@ -605,9 +605,9 @@ __global__ __launch_bounds__(256) void k_scale_rows(const float* __restrict__ X,
     }
 }
 void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, int L, const float* r, const float* b,
-                       float* Tb, float* cpart) {
+                       float* Tb, float* cpart, int blocked) {
     const int64_t waves = (Mpad + 63) / 64;
-    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, X, M, Mpad, L, r, b, Tb, cpart);
+    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, X, M, Mpad, L, r, b, Tb, cpart, blocked);
 }
 
 }  // namespace gpca

@@ -426,3 +426,53 @@ def test_full_size_properties(gpca, oracle):
         # (5) PCA::transform consistency: A^T U = V s up to convergence of the trailing (noise) PCs
         tr = e.transform()
         assert oracle.max_abs_dpc(tr[:, :2], sc[:, :2]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# exact-integer GEMM path (GPCA_PREC_I8_EXACT): same parity bars
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def engine_i8(gpca):
+    from genomic_pca_amd import _lib
+    e = gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("M,N,P,k", [(4096, 512, 12, 8), (20000, 1000, 16, 10), (3000, 1500, 10, 6), (999, 257, 8, 4), (130, 70, 4, 3)])
+def test_rsvd_parity_i8(gpca, oracle, engine_i8, M, N, P, k):
+    G, r, b, R = _rsvd_case(gpca, oracle, engine_i8, M, N, P, k, seed=1, fst=0.2)
+    e = engine_i8
+    assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+    assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
+    assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]) < TOL_PC
+    al = oracle.sign_align(e.scores(f64=True), R["scores"])
+    assert np.max(np.abs(al - R["scores"])) < 1e-4 * np.max(np.abs(R["scores"]))
+
+
+def test_i8_matches_f32_and_is_partition_independent(gpca, oracle, engine, engine_i8, monkeypatch):
+    M, N = 6000, 640
+    th = gpca.synth_thresholds(M, 8, seed=5, fst=0.3)
+    G = oracle.synth_genotypes(M, N, 5, th)
+    out = {}
+    for name, e in (("f32", engine), ("i8", engine_i8)):
+        e.upload_genotypes_i8(G); e.snp_stats(); e.rsvd(6, 10, 2, seed=3)
+        out[name] = (e.eigenvalues(), e.scores(f64=True), e.transform())
+    assert np.max(np.abs(out["i8"][0] - out["f32"][0]) / out["f32"][0]) < 1e-5
+    assert oracle.max_abs_dpc(out["i8"][1], out["f32"][1]) < 1e-5
+    assert oracle.max_abs_dpc(out["i8"][2], out["f32"][2]) < 1e-5
+    # the integer GEMM partial sums are exact, so a different grid partition changes only the f32 partials of the
+    # centring term c = b^T T: results agree to ~1e-9 (the f32 path moves at ~1e-7)
+    from genomic_pca_amd import _lib
+    monkeypatch.setenv("GPCA_GQ_WAVES", "64"); monkeypatch.setenv("GPCA_GTT_WAVES", "96")
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e2:
+        e2.upload_genotypes_i8(G); e2.snp_stats(); e2.rsvd(6, 10, 2, seed=3)
+        assert np.max(np.abs(e2.eigenvalues() - out["i8"][0]) / out["i8"][0]) < 1e-8
+        assert oracle.max_abs_dpc(e2.scores(f64=True), out["i8"][1]) < 1e-8
+
+
+def test_i8_rejects_wide_sketch(gpca, engine_i8):
+    engine_i8.upload_genotypes_i8(np.random.default_rng(0).integers(0, 3, size=(500, 100), dtype=np.int8))
+    engine_i8.snp_stats()
+    with pytest.raises(gpca.GpcaError):
+        engine_i8.rsvd(30, 10)        # l = 40 > 32
