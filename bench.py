@@ -8,9 +8,11 @@ N = 1  : configs[1] = synthetic 1M SNPs x 10k samples int8, k = 20, fixed seed, 
 N > 1  : SNP-row shards, one rank per GPU (torch.distributed.run), weak scaling: every rank holds
          --snps rows; the N x l sketch is all-reduced with RCCL inside libgpca.so (f64).
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel, from HIP events recorded on the engine's
-own stream inside the timed region; `cpu_baseline` is the oracle's f32 restatement ("port") timed on this
-box's host cores on a bounded sample (N = 1 only).
+One JSON line on rank 0.  `value` is the default (fastest parity-green) path: exact-integer GEMMs, HBM-bound;
+`f32_mfma_path` is the same job on v_mfma_f32_32x32x2_f32 (north_star's MFMA-fp32 roofline).  `roofline` is for the
+dominant kernel, from HIP events recorded on the engine's own stream inside the timed region; `parity` is
+max|dPC| against the oracle on a small seeded case; `cpu_baseline` is the oracle's f32 restatement ("port")
+timed on this box's host cores on a bounded sample (N = 1 only).
 """
 import argparse
 import json
@@ -41,15 +43,69 @@ def cpu_baseline(N, k, oversample, q, seed, target_s=15.0):
         t0 = time.perf_counter()
         O.rsvd(G, N, r, b, k, oversample, q, seed=seed, real="f32")
         return time.perf_counter() - t0
-    Ms = 4000
+    Ms = 25000
     t = run(Ms)
     rate = Ms * N / t
-    Ms2 = int(min(max(rate * target_s / N, Ms), 400000))
-    if Ms2 > 2 * Ms:
+    Ms2 = int(min(max(rate * target_s / N, Ms), 1_000_000))   # ~target_s of CPU work, capped at 10 GB of genotypes
+    if Ms2 > 1.5 * Ms:
         t = run(Ms2); Ms = Ms2
     return {"value": Ms * N / t, "unit": "SNPs*samples/s", "cores": threads, "kind": "port",
             "sample": f"oracle/gpca_oracle.c REAL=float, {Ms} SNPs x {N} samples, k={k}, l={k + oversample}, q={q}, "
                       f"{t:.1f} s on {threads} OpenMP threads (CPU restatement, not the Rust/faer binary)"}
+
+
+def parity_check(g, precision, seed):
+    """max|dPC| of the measured path against the oracle's f64 restatement (same seed) on a small seeded case --
+    the second half of BASELINE.json's metric.  The oracle is only the checker here."""
+    from oracle import oracle as O
+    M, N, P, k = 20000, 1000, 16, 10
+    th = g.synth_thresholds(M, P, seed=seed, fst=0.2)
+    with g.GpcaEngine(precision=precision) as e:
+        e.synth_genotypes(M, N, seed, th)
+        G = e.download_genotypes_i8()
+        st = e.snp_stats(g.QcConfig.none())
+        e.rsvd(k, 10, 2, seed=seed)
+        r, b = O.scale_shift(st["mu"], st["sigma"], st["keep"])
+        R = O.rsvd(G, N, r, b, k, 10, 2, seed=seed)
+        return {"case": f"{M}x{N} k={k} vs oracle f64 (same seed)",
+                "max_abs_dPC_scores": O.max_abs_dpc(e.scores(f64=True), R["scores"]),
+                "max_abs_dPC_loadings": O.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]),
+                "max_rel_d_eigenvalue": float(np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"])),
+                "tolerance": 1e-4}
+
+
+def timed_run(eng, a, k, barrier, dist, torch):
+    for _ in range(a.warmup):
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+    eng.reset_timings()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, eng.timings()
+
+
+def roofline_of(timings, precision, steps):
+    gq, gt = timings.get("gemm_GQ"), timings.get("gemm_GtT")
+    dom_name, dom = max((("gemm_GQ", gq), ("gemm_GtT", gt)), key=lambda kv: kv[1]["total_ms"] if kv[1] else 0.0)
+    avg_ms = dom["total_ms"] / dom["launches"]
+    tflops = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+    gbs = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+    common = {"kernel": dom_name + ("_i8" if precision == "i8" else "_f32"), "avg_launch_ms": avg_ms, "launches": dom["launches"],
+              "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+              "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+              "all_kernels_ms_per_step": {n: t["total_ms"] / steps for n, t in timings.items()}}
+    if precision == "i8":   # exact-integer MFMA needs ~1/10 of the matrix-core time per byte: HBM-bound
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_TFLOPs_equivalent": tflops, **common}
+    return {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None, "hbm_GBs_algorithmic": gbs, **common}
 
 
 def main():
@@ -64,7 +120,9 @@ def main():
     ap.add_argument("--power-iters", type=int, default=2)
     ap.add_argument("--rfit-seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "i8"])
+    ap.add_argument("--no-second-path", action="store_true", help="skip the extra f32-MFMA measurement")
+    ap.add_argument("--precision", default="i8", choices=["f32", "i8"],
+                    help="i8 = exact-integer GEMMs (default, fastest parity-green path); f32 = v_mfma_f32_32x32x2_f32")
     a = ap.parse_args()
 
     import torch
@@ -73,9 +131,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    if world == 1 and a.gpus > 1:
+        sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -85,74 +142,67 @@ def main():
 
     M_local, N, k = a.snps, a.samples, a.components
     l = k + a.oversample
+    if a.precision == "i8" and l > 32:
+        a.precision = "f32"      # the exact-integer path covers l <= 32
     M_total = M_local * world
     snp_offset = rank * M_local
-    prec = g._lib.PREC_F32_MFMA if a.precision == "f32" else g._lib.PREC_I8_EXACT
-    eng = g.GpcaEngine(device=local_rank, precision=prec)
-    th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
-    eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
-    del th
-    t0 = time.perf_counter()
-    eng.snp_stats(g.QcConfig.none(), fetch=False)
-    t_stats = time.perf_counter() - t0
-    if world > 1:
-        uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
-        eng.comm_init(world, rank, uid, snp_offset)
+    PREC = {"f32": g._lib.PREC_F32_MFMA, "i8": g._lib.PREC_I8_EXACT}
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
-    eng.reset_timings()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    timings = eng.timings()
-    ev = eng.eigenvalues()
+    uid = None
+    results = {}
+    order = [a.precision] + ([] if (a.no_second_path or a.precision == "f32" or l > 32) else ["f32"])
+    th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
+    t_stats = None
+    for prec in order:
+        eng = g.GpcaEngine(device=local_rank, precision=PREC[prec])
+        eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
+        t0 = time.perf_counter()
+        eng.snp_stats(g.QcConfig.none(), fetch=False)
+        if t_stats is None:
+            t_stats = time.perf_counter() - t0
+        if world > 1:
+            uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
+            eng.comm_init(world, rank, uid, snp_offset)
+        dt, timings = timed_run(eng, a, k, barrier, dist, torch)
+        results[prec] = (dt, timings, eng.eigenvalues())
+        eng.close()
+    del th
 
     if rank == 0:
+        dt, timings, ev = results[a.precision]
         per_step = dt / a.steps
         value = M_total * N / per_step
-        gq, gt = timings.get("gemm_GQ"), timings.get("gemm_GtT")
-        dom_name, dom = max((("gemm_GQ", gq), ("gemm_GtT", gt)), key=lambda kv: kv[1]["total_ms"] if kv[1] else 0.0)
-        avg_ms = dom["total_ms"] / dom["launches"]
-        tflops = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "avg_launch_ms": avg_ms, "launches": dom["launches"],
-                    "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
-                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
-                    "hbm_GBs_algorithmic": dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9,
-                    "all_kernels_ms_per_step": {n: t["total_ms"] / a.steps for n, t in timings.items()}}
+        dtype = ("i8 (exact: int8 dosages x 4 signed 7-bit fixed-point digit planes of the skinny operand, i32 accumulate, "
+                 "f64 recombination; accuracy >= f32)") if a.precision == "i8" else "f32"
         out = {
-            "metric": "SNPs x samples / sec through rSVD at k=20", "value": value, "unit": "SNPs*samples/s",
+            "metric": "SNPs x samples / sec through rSVD at k=20; max|dPC| vs ref", "value": value, "unit": "SNPs*samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "f32" else "i8", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"synthetic {M_total} SNPs x {N} samples int8 genotypes (3 populations, F_ST 0.05), "
                                    f"k={k}, l={l}, q={a.power_iters}, seed={a.rfit_seed}, resident in HBM",
                        "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample,
-                       "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}"},
-            "roofline": roofline,
+                       "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}", "gemm_path": a.precision},
+            "roofline": roofline_of(timings, a.precision, a.steps),
             "snp_stats_s": t_stats,
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
+        if "f32" in results and a.precision != "f32":
+            dt2, tim2, ev2 = results["f32"]
+            out["f32_mfma_path"] = {"value": M_total * N / (dt2 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt2 / a.steps * 1e3,
+                                    "dtype": "f32", "roofline": roofline_of(tim2, "f32", a.steps),
+                                    "max_rel_d_eigenvalue_vs_default_path": float(np.max(np.abs(ev2 - ev) / ev))}
         if world == 1 and not a.no_cpu_baseline:
+            out["parity"] = parity_check(g, PREC[a.precision], a.rfit_seed)
             out["cpu_baseline"] = cpu_baseline(N, k, a.oversample, a.power_iters, a.rfit_seed)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -219,6 +219,8 @@ __global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G,
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
+    // (an XCD-aware block -> (row chunk, n-group) remap was measured: no gain -- the skinny operand is already
+    //  L2/MALL-served -- and its padded grid broke the all-blocks-resident property, so the plain mapping stays)
     const int64_t ngroup = blockIdx.x % ngroups;
     const int64_t wchunk = blockIdx.x / ngroups;
     const int64_t nblock = ngroup * 4 + wv;

@@ -27,9 +27,9 @@ if ks:
     rows = list(csv.DictReader(open(ks[0])))
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
         f.write(open(ks[0]).read())
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (5 timed + 1 warm-up step)", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (5 timed + 1 warm-up step per path; default = exact-integer path, then the f32-MFMA path)", "",
               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-    for r in rows[:14]:
+    for r in rows[:22]:
         lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
     lines.append("")
 pm = collections.defaultdict(lambda: collections.defaultdict(list))
