@@ -91,6 +91,22 @@ def timed_run(eng, a, k, barrier, dist, torch):
     return dt, eng.timings()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/*_pmc.json, produced by
+    scripts/gpu_profile.sh: separate rocprofv3 --pmc runs).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
+    for gfx950 wide coalesced reads (calibrated on k_snp_stats: 2 x 5120.1 MB = the 10 240 MB it streams)."""
+    import glob
+    key = {"gemm_GQ_i8": "gpca::k_gq_i8<0>", "gemm_GtT_i8": "gpca::k_gtt_i8<0>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
+           "gemm_GtT_f32": "gpca::k_gtt_f32<1>"}.get(kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not key or not files:
+        return None, None
+    d = json.load(open(files[-1])).get(key)
+    if not d or "FETCH_SIZE" not in d:
+        return None, None
+    return (2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024.0, os.path.basename(files[-1])
+
+
 def roofline_of(timings, precision, steps):
     gq, gt = timings.get("gemm_GQ"), timings.get("gemm_GtT")
     dom_name, dom = max((("gemm_GQ", gq), ("gemm_GtT", gt)), key=lambda kv: kv[1]["total_ms"] if kv[1] else 0.0)
@@ -101,11 +117,14 @@ def roofline_of(timings, precision, steps):
               "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
               "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
               "all_kernels_ms_per_step": {n: t["total_ms"] / steps for n, t in timings.items()}}
+    traffic, src = pmc_traffic(common["kernel"])
+    common["traffic_source"] = (f"profiles/{src}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch, separate rocprofv3 --pmc passes"
+                                if src else None)
     if precision == "i8":   # exact-integer MFMA needs ~1/10 of the matrix-core time per byte: HBM-bound
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_TFLOPs_equivalent": tflops, **common}
+                "traffic": traffic, "algorithmic_TFLOPs_equivalent": tflops, **common}
     return {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None, "hbm_GBs_algorithmic": gbs, **common}
+            "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "hbm_GBs_algorithmic": gbs, **common}
 
 
 def main():
