@@ -1,0 +1,166 @@
+"""`python -m genomic_pca_amd` -- the reference's CLI surface (main.rs:501-593) over the MI355X engine.
+
+Two workflows, dispatched on --eigensnp like main.rs:109-122:
+  * VCF  (run_vcf_workflow, main.rs:133-247):  --vcf-dir D -k K [--maf f] [--rfit-seed s] --out P
+        -> P.vcf.pca.tsv, P.eigenvalues.tsv (header only, as main.rs:676 leaves the vector empty;
+           --write-eigenvalues is an extension that fills it)
+  * BED  (run_eigensnp_rust_workflow, main.rs:250-442):  --eigensnp --bed-file B --ld-block-file L --out P [--eigensnp-*]
+        -> P.eigensnp.pca.tsv, P.eigenvalues.tsv, P.eigensnp.loadings.tsv
+EigenSNP's per-LD-block local stage is defined only in the un-vendored efficient_pca crate; this CLI runs the global
+randomized PCA over all SNPs that pass QC and fall in an LD block (identical to the reference's own README usage of a
+single genome-wide block).  The local-stage flags are accepted and ignored.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import io as gio
+from .engine import (EigenSNPCoreAlgorithm, EigenSNPCoreAlgorithmConfig, GpcaEngine, LdBlockSpecification,
+                     MicroarrayGenotypeAccessor, PCA, QcConfig)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog="genomic_pca", description="Genomic PCA Tool from VCF or BED/LD-block files.")
+    p.add_argument("-o", "--out", dest="output_prefix", required=True, help="Output file prefix.")
+    p.add_argument("-t", "--threads", type=int, default=None, help="accepted for compatibility (the GPU does the work)")
+    p.add_argument("--log-level", default="Info")
+    p.add_argument("-d", "--vcf-dir", default=None)
+    p.add_argument("-k", "--components", type=int, default=None)
+    p.add_argument("--maf", type=float, default=None)
+    p.add_argument("--rfit-seed", type=int, default=None)
+    p.add_argument("--eigensnp", action="store_true")
+    p.add_argument("--bed-file", default=None)
+    p.add_argument("--ld-block-file", default=None)
+    p.add_argument("--eigensnp-sample-keep-file", default=None)
+    # clap's effective defaults when --eigensnp is given (main.rs:545-588)
+    p.add_argument("--eigensnp-min-call-rate", type=float, default=0.98)
+    p.add_argument("--eigensnp-min-maf", type=float, default=0.01)
+    p.add_argument("--eigensnp-max-hwe-p", type=float, default=1e-6)
+    p.add_argument("--eigensnp-k-global", type=int, default=10)
+    p.add_argument("--eigensnp-components-per-block", type=int, default=7)
+    p.add_argument("--eigensnp-subset-factor", type=float, default=0.075)
+    p.add_argument("--eigensnp-min-subset-size", type=int, default=10000)
+    p.add_argument("--eigensnp-max-subset-size", type=int, default=40000)
+    p.add_argument("--eigensnp-global-oversampling", type=int, default=10)
+    p.add_argument("--eigensnp-global-power-iter", type=int, default=2)
+    p.add_argument("--eigensnp-local-oversampling", type=int, default=10)
+    p.add_argument("--eigensnp-local-power-iter", type=int, default=2)
+    p.add_argument("--eigensnp-seed", type=int, default=2025)
+    p.add_argument("--eigensnp-snp-strip-size", type=int, default=2000)
+    p.add_argument("--eigensnp-refine-passes", type=int, default=1)
+    p.add_argument("--eigensnp-collect-diagnostics", action="store_true")
+    # extensions
+    p.add_argument("--device", type=int, default=-1, help="HIP device ordinal")
+    p.add_argument("--write-eigenvalues", action="store_true", help="VCF workflow: fill P.eigenvalues.tsv (the reference leaves it header-only)")
+    return p
+
+
+def _log(msg: str):
+    print(f"[genomic_pca_amd] {msg}", file=sys.stderr, flush=True)
+
+
+def _ensure_parent(prefix: str):
+    parent = os.path.dirname(prefix)
+    if parent and not os.path.exists(parent):
+        os.makedirs(parent, exist_ok=True)                                         # main.rs:372-377
+
+
+def run_vcf_workflow(a) -> int:
+    if not a.vcf_dir or a.components is None:
+        raise SystemExit("error: --vcf-dir and --components are required unless --eigensnp is given")
+    t0 = time.time()
+    files = sorted(os.path.join(a.vcf_dir, f) for f in os.listdir(a.vcf_dir) if f.endswith(".vcf") or f.endswith(".vcf.gz"))
+    if not files:
+        raise SystemExit(f"No VCF files found in {a.vcf_dir}")                       # main.rs:153-155
+    maf = 0.01 if a.maf is None else a.maf
+    samples, ids, chunks = None, [], []
+    for f in files:
+        s, i, g = gio.read_vcf(f, maf)
+        if samples is None:
+            samples = s
+        elif s != samples:
+            raise SystemExit(f"Sample mismatch between VCF files: {f}")             # vcf.rs:78-95
+        ids += i
+        chunks.append(g)
+    G = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 0), np.int8)
+    _log(f"{len(files)} VCF files, {G.shape[0]} variants x {len(samples or [])} samples in {time.time() - t0:.2f}s")
+    if G.shape[0] == 0:
+        raise SystemExit("No variants available to build matrix.")                  # vcf.rs:321-323
+    model = PCA(device=a.device)
+    model.rfit(G.T, a.components, 10, a.rfit_seed, None)                            # main.rs:636-656 (x = samples x variants)
+    pcs = model.transform()
+    _ensure_parent(a.output_prefix)
+    gio.write_principal_components(a.output_prefix, "vcf.pca.tsv", samples, pcs)    # main.rs:231
+    gio.write_eigenvalues(a.output_prefix, model.explained_variance() if a.write_eigenvalues else [])   # main.rs:232, 676
+    _log(f"VCF workflow done in {time.time() - t0:.2f}s")
+    return 0
+
+
+def run_eigensnp_workflow(a) -> int:
+    if not a.bed_file or not a.ld_block_file:
+        raise SystemExit("error: --bed-file and --ld-block-file are required when --eigensnp is used")   # main.rs:296-301
+    t0 = time.time()
+    fs = gio.read_plink(a.bed_file)
+    eng = GpcaEngine(device=a.device)
+    sample_ids = fs.sample_ids
+    if a.eigensnp_sample_keep_file:                                                  # prepare.rs:1058-1096
+        keep_ids = set(gio.read_sample_keep_file(a.eigensnp_sample_keep_file))
+        cols = np.array([i for i, s in enumerate(fs.sample_ids) if s in keep_ids], np.int64)
+        if len(cols) == 0:
+            _log("No samples available after sample QC."); return 0
+        lut = np.array([2, -127, 1, 0], np.int8)
+        rows = np.asarray(fs.bed_rows)
+        G = lut[(rows[:, cols // 4] >> (2 * (cols % 4)).astype(np.uint8)) & 3]
+        eng.upload_genotypes_i8(np.ascontiguousarray(G))
+        sample_ids = [fs.sample_ids[i] for i in cols]
+    else:
+        eng.upload_bed2bit(np.asarray(fs.bed_rows), fs.n_samples)                    # decoded on the GPU
+    st = eng.snp_stats(QcConfig(a.eigensnp_min_call_rate, a.eigensnp_min_maf, a.eigensnp_max_hwe_p))
+    blocks = gio.parse_ld_block_file(a.ld_block_file)
+    keep, by_tag = gio.map_snps_to_ld_blocks(blocks, fs.chromosomes, fs.positions, st["keep"])
+    _log(f"{int(st['keep'].sum())} / {len(st['keep'])} SNPs passed QC; {int(keep.sum())} fall in {len(by_tag)} LD blocks")
+    if len(sample_ids) == 0 or int(keep.sum()) == 0:
+        _log("No samples or SNPs available for EigenSNP PCA after preparation.")     # main.rs:349-352
+        return 0
+    eng.set_standardization(st["mu"], st["sigma"], keep)
+    acc = MicroarrayGenotypeAccessor(eng)
+    rows = acc.original_indices_of_pca_snps()
+    row_to_id = {int(r): i for i, r in enumerate(rows)}
+    specs = [LdBlockSpecification(tag, [row_to_id[r] for r in rs]) for tag, rs in by_tag]
+    cfg = EigenSNPCoreAlgorithmConfig(
+        target_num_global_pcs=a.eigensnp_k_global, components_per_ld_block=a.eigensnp_components_per_block,
+        subset_factor_for_local_basis_learning=a.eigensnp_subset_factor,
+        min_subset_size_for_local_basis_learning=a.eigensnp_min_subset_size,
+        max_subset_size_for_local_basis_learning=a.eigensnp_max_subset_size,
+        global_pca_sketch_oversampling=a.eigensnp_global_oversampling,
+        global_pca_num_power_iterations=a.eigensnp_global_power_iter,
+        local_rsvd_sketch_oversampling=a.eigensnp_local_oversampling,
+        local_rsvd_num_power_iterations=a.eigensnp_local_power_iter, random_seed=a.eigensnp_seed,
+        snp_processing_strip_size=a.eigensnp_snp_strip_size, refine_pass_count=a.eigensnp_refine_passes,
+        collect_diagnostics=a.eigensnp_collect_diagnostics)
+    k = min(cfg.target_num_global_pcs, len(sample_ids), len(rows))
+    cfg.target_num_global_pcs = k
+    cfg.global_pca_sketch_oversampling = max(0, min(cfg.global_pca_sketch_oversampling, min(len(sample_ids), len(rows)) - k))
+    out, _ = EigenSNPCoreAlgorithm(cfg).compute_pca(acc, specs)
+    _ensure_parent(a.output_prefix)
+    gio.write_principal_components(a.output_prefix, "eigensnp.pca.tsv", sample_ids, out.final_sample_principal_component_scores)
+    gio.write_eigenvalues(a.output_prefix, out.final_principal_component_eigenvalues)
+    gio.write_loadings(a.output_prefix, [fs.variant_ids[r] for r in rows], [fs.chromosomes[r] for r in rows],
+                       [int(fs.positions[r]) for r in rows], out.final_snp_principal_component_loadings)
+    eng.close()
+    _log(f"EigenSNP workflow done in {time.time() - t0:.2f}s")
+    return 0
+
+
+def main(argv=None) -> int:
+    a = build_parser().parse_args(argv)
+    return run_eigensnp_workflow(a) if a.eigensnp else run_vcf_workflow(a)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,157 @@
+"""Host-side formats and the CLI surface.  Parsers/writers run on CPU; the two
+end-to-end workflows need the GPU."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from genomic_pca_amd import io as gio
+
+
+def test_ld_block_parsing_and_mapping(tmp_path):
+    p = tmp_path / "blocks.txt"
+    p.write_text("# comment\nchr\tstart\tend\nchromosome\tstart\tend\nchr1 100 200\nCHR1\t150\t400\n2 1 50 extra\nbad line\n\nX 5 9\n")
+    blocks = gio.parse_ld_block_file(str(p))
+    # prepare.rs:1575-1602: headers/comments skipped, tag auto = chr:start-end on the normalised name
+    assert blocks == [("1", 100, 200, "1:100-200"), ("1", 150, 400, "1:150-400"), ("2", 1, 50, "2:1-50"), ("x", 5, 9, "x:5-9")]
+    assert gio.normalize_chromosome_name("Chr22") == "22" and gio.normalize_chromosome_name("X") == "x"
+    chroms = ["1", "chr1", "1", "2", "2", "X", "3"]
+    pos = [100, 180, 300, 50, 51, 7, 7]
+    qc = np.array([1, 1, 1, 1, 1, 0, 1], np.uint8)
+    keep, by_tag = gio.map_snps_to_ld_blocks(blocks, chroms, pos, qc)
+    assert keep.tolist() == [1, 1, 1, 1, 0, 0, 0]          # 51 outside, X failed QC, chr3 has no block
+    # first matching block wins (prepare.rs:1447-1463): 180 is in both chr1 blocks -> the first; tags sorted
+    assert by_tag == [("1:100-200", [0, 1]), ("1:150-400", [2]), ("2:1-50", [3])]
+
+
+def test_writers_match_reference_format(tmp_path):
+    pre = str(tmp_path / "out" / "run")
+    os.makedirs(os.path.dirname(pre))
+    pcs = np.array([[1.23456789, -0.5], [2.0, 1e-7]], np.float32)
+    gio.write_principal_components(pre, "eigensnp.pca.tsv", ["s1", "s2", "s3"], pcs)
+    assert open(pre + ".eigensnp.pca.tsv").read() == "SampleID\tPC1\tPC2\ns1\t1.234568\t-0.500000\ns2\t2.000000\t0.000000\ns3\tNA\tNA\n"
+    gio.write_eigenvalues(pre, [])
+    assert open(pre + ".eigenvalues.tsv").read() == "PC\tEigenvalue\n"                 # main.rs:769-774
+    gio.write_eigenvalues(pre, [12.5, 0.1234567])
+    assert open(pre + ".eigenvalues.tsv").read() == "PC\tEigenvalue\n1\t12.500000\n2\t0.123457\n"
+    gio.write_loadings(pre, ["rs1", "rs2"], ["1", "2"], [10, 20], np.array([[0.5, -0.25], [0.125, 1.0]], np.float32))
+    assert open(pre + ".eigensnp.loadings.tsv").read() == \
+        "VariantID\tChrom\tPos\tPC1_loading\tPC2_loading\nrs1\t1\t10\t0.500000\t-0.250000\nrs2\t2\t20\t0.125000\t1.000000\n"
+    with pytest.raises(ValueError):
+        gio.write_loadings(pre, ["rs1"], ["1", "2"], [10, 20], np.zeros((2, 1), np.float32))
+
+
+def test_plink_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    G = rng.integers(0, 3, size=(50, 13), dtype=np.int8)
+    G[3, 4] = -127; G[7, 12] = -127
+    pre = str(tmp_path / "toy")
+    gio.write_plink(pre, G, [f"s{i}" for i in range(13)], [f"rs{i}" for i in range(50)], ["1"] * 50, list(range(100, 150)))
+    fs = gio.read_plink(pre + ".bed")
+    assert fs.n_samples == 13 and fs.bed_rows.shape == (50, 4) and fs.sample_ids[2] == "s2" and fs.positions[49] == 149
+    lut = np.array([2, -127, 1, 0], np.int8)                      # count_a1: 00->2, 01->missing, 10->1, 11->0
+    dec = np.empty((50, 16), np.int8)
+    for s in range(4):
+        dec[:, s::4] = lut[(np.asarray(fs.bed_rows) >> (2 * s)) & 3]
+    assert np.array_equal(dec[:, :13], G)
+    open(pre + ".bed", "r+b").write(b"\x6c\x1b\x00")              # sample-major magic is rejected
+    with pytest.raises(ValueError):
+        gio.read_plink(pre + ".bed")
+
+
+VCF_HEAD = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\tC\tD\n"
+
+
+def test_vcf_rules(tmp_path):
+    body = ("1\t100\t.\tA\tG\t.\t.\t.\tGT\t0/0\t0|1\t1/1\t0/1\n"          # kept: dosages 0,1,2,1
+            "1\t101\t.\tAT\tG\t.\t.\t.\tGT\t0/0\t0|1\t1/1\t0/1\n"         # REF not single base (vcf.rs:109-121)
+            "1\t102\t.\tA\tG,T\t.\t.\t.\tGT\t0/0\t0|1\t1/1\t0/1\n"        # multi-allelic
+            "1\t103\t.\tA\tG\t.\t.\t.\tGT\t0/0\t./.\t1/1\t0/1\n"          # missing GT drops the variant (vcf.rs:52-63)
+            "1\t104\t.\tA\tG\t.\t.\t.\tGT\t0/0\t0/2\t1/1\t0/1\n"          # allele 2
+            "1\t105\t.\tC\tT\t.\t.\t.\tGT:DP\t0/0:3\t0/0:4\t0/0:9\t0/0:1\n"  # MAF 0 < threshold (vcf.rs:244-266)
+            "2\t7\t.\tC\tT\t.\t.\t.\tDP:GT\t3:1|0\t4:0/0\t9:0/0\t1:1|1\n")   # GT not first in FORMAT
+    p = tmp_path / "a.vcf.gz"
+    with gzip.open(p, "wt") as f:
+        f.write(VCF_HEAD + body)
+    samples, ids, G = gio.read_vcf(str(p), 0.01)
+    assert samples == ["A", "B", "C", "D"]
+    assert ids == ["1:100:A:G", "2:7:C:T"]                          # id = chr:pos:ref:alt (vcf.rs:268-276)
+    assert G.tolist() == [[0, 1, 2, 1], [1, 0, 0, 2]]
+    _, ids2, _ = gio.read_vcf(str(p), 0.4)                          # MAF threshold
+    assert ids2 == ["1:100:A:G"]
+
+
+# ------------------------------------------------------------------------------------------------ GPU end-to-end
+def _read_tsv(path):
+    lines = open(path).read().rstrip("\n").split("\n")
+    return lines[0].split("\t"), [ln.split("\t") for ln in lines[1:]]
+
+
+@pytest.mark.gpu
+def test_cli_eigensnp_workflow(tmp_path, gpca, oracle):
+    from genomic_pca_amd.cli import main
+    M, N, P = 3000, 96, 6
+    th = gpca.synth_thresholds(M, P, seed=3, fst=0.3)
+    G = oracle.synth_genotypes(M, N, 3, th)
+    G[::50] = 0                                                    # monomorphic rows fail QC
+    pre = str(tmp_path / "cohort")
+    chroms = ["1"] * 2000 + ["chr2"] * 1000
+    pos = list(range(1, 2001)) + list(range(1, 1001))
+    gio.write_plink(pre, G, [f"id{i}" for i in range(N)], [f"rs{i}" for i in range(M)], chroms, pos)
+    ld = tmp_path / "ld.txt"
+    ld.write_text("chr\tstart\tend\n1 1 1500\n2 1 600\n")         # SNPs 1501..2000 of chr1 and 601.. of chr2 are unblocked
+    out = str(tmp_path / "res" / "run1")
+    assert main(["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--out", out, "--eigensnp-k-global", "4",
+                 "--eigensnp-max-hwe-p", "1.0", "--eigensnp-seed", "11"]) == 0
+    hdr, rows = _read_tsv(out + ".eigensnp.pca.tsv")
+    assert hdr == ["SampleID", "PC1", "PC2", "PC3", "PC4"] and len(rows) == N and rows[5][0] == "id5"
+    ehdr, erows = _read_tsv(out + ".eigenvalues.tsv")
+    assert ehdr == ["PC", "Eigenvalue"] and [r[0] for r in erows] == ["1", "2", "3", "4"]
+    lhdr, lrows = _read_tsv(out + ".eigensnp.loadings.tsv")
+    assert lhdr == ["VariantID", "Chrom", "Pos", "PC1_loading", "PC2_loading", "PC3_loading", "PC4_loading"]
+    # expected PCA SNP set: QC (call rate .98, MAF .01, HWE off) AND inside an LD block
+    st = oracle.snp_stats(G, N, 0.98, 0.01, 1.0)
+    inblock = np.array([(i < 1500) or (2000 <= i < 2600) for i in range(M)])
+    keep = st["keep"].astype(bool) & inblock
+    assert [r[0] for r in lrows] == [f"rs{i}" for i in np.nonzero(keep)[0]]
+    assert lrows[0][1] == "1" and lrows[-1][1] == "chr2"
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], keep)
+    R = oracle.rsvd(G, N, r, b, 4, 10, 2, seed=11)
+    sc = np.array([[float(x) for x in rw[1:]] for rw in rows])
+    ev = np.array([float(rw[1]) for rw in erows])
+    assert np.max(np.abs(ev - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
+    al = oracle.sign_align(sc, R["scores"])
+    assert np.max(np.abs(al - R["scores"])) < 2e-6 + 1e-4 * np.max(np.abs(R["scores"]))   # 6-decimal TSV rounding
+    ldv = np.array([[float(x) for x in rw[3:]] for rw in lrows])
+    assert np.max(np.abs(oracle.sign_align(ldv, R["loadings"][keep]) - R["loadings"][keep])) < 2e-6
+
+
+@pytest.mark.gpu
+def test_cli_vcf_workflow(tmp_path, gpca, oracle):
+    from genomic_pca_amd.cli import main
+    M, N = 400, 40
+    th = gpca.synth_thresholds(M, 4, seed=8, fst=0.3)
+    G = oracle.synth_genotypes(M, N, 8, th)
+    names = [f"S{i}" for i in range(N)]
+    gt = {0: "0/0", 1: "0|1", 2: "1/1"}
+    d = tmp_path / "vcfs"; d.mkdir()
+    for ci, (lo, hi) in enumerate([(0, 250), (250, 400)]):        # two chromosomes = two files, sorted by name
+        with gzip.open(d / f"chr{ci + 1}.vcf.gz", "wt") as f:
+            f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+            for i in range(lo, hi):
+                f.write(f"{ci + 1}\t{i + 1}\t.\tA\tC\t.\t.\t.\tGT\t" + "\t".join(gt[int(v)] for v in G[i]) + "\n")
+    out = str(tmp_path / "o" / "v")
+    assert main(["--vcf-dir", str(d), "-k", "3", "--maf", "0.05", "--rfit-seed", "1", "--out", out]) == 0
+    assert open(out + ".eigenvalues.tsv").read() == "PC\tEigenvalue\n"      # main.rs:676: empty vector -> header only
+    hdr, rows = _read_tsv(out + ".vcf.pca.tsv")
+    assert hdr == ["SampleID", "PC1", "PC2", "PC3"] and [r[0] for r in rows] == names
+    af = G.sum(axis=1) / (2 * N)
+    kept = np.minimum(af, 1 - af) >= 0.05
+    Gk = G[kept]
+    st = oracle.snp_stats(Gk, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(Gk, N, r, b, 3, 10, 2, seed=1)
+    ref = oracle.standardized_dense(Gk, N, r, b).T @ R["loadings"]
+    sc = np.array([[float(x) for x in rw[1:]] for rw in rows])
+    assert oracle.max_abs_dpc(sc, ref) < 1e-4
