@@ -96,7 +96,7 @@ def pmc_traffic(kernel):
     scripts/gpu_profile.sh: separate rocprofv3 --pmc runs).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950 wide coalesced reads (calibrated on k_snp_stats: 2 x 5120.1 MB = the 10 240 MB it streams)."""
     import glob
-    key = {"gemm_GQ_i8": "gpca::k_gq_i8<0>", "gemm_GtT_i8": "gpca::k_gtt_i8<0>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
+    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit", "gemm_GtT_2bit": "gpca::k_gtt_2bit", "gemm_GQ_i8": "gpca::k_gq_i8<0>", "gemm_GtT_i8": "gpca::k_gtt_i8<0>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
            "gemm_GtT_f32": "gpca::k_gtt_f32<1>"}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not key or not files:
@@ -107,19 +107,26 @@ def pmc_traffic(kernel):
     return (2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024.0, os.path.basename(files[-1])
 
 
-def roofline_of(timings, precision, steps):
+def roofline_of(timings, precision, steps, storage="int8"):
     gq, gt = timings.get("gemm_GQ"), timings.get("gemm_GtT")
     dom_name, dom = max((("gemm_GQ", gq), ("gemm_GtT", gt)), key=lambda kv: kv[1]["total_ms"] if kv[1] else 0.0)
     avg_ms = dom["total_ms"] / dom["launches"]
     tflops = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
     gbs = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-    common = {"kernel": dom_name + ("_i8" if precision == "i8" else "_f32"), "avg_launch_ms": avg_ms, "launches": dom["launches"],
+    common = {"kernel": dom_name + (("_2bit" if storage == "2bit" else "_i8") if precision == "i8" else "_f32"), "avg_launch_ms": avg_ms, "launches": dom["launches"],
               "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
               "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
               "all_kernels_ms_per_step": {n: t["total_ms"] / steps for n, t in timings.items()}}
     traffic, src = pmc_traffic(common["kernel"])
     common["traffic_source"] = (f"profiles/{src}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch, separate rocprofv3 --pmc passes"
                                 if src else None)
+    if precision == "i8" and storage == "2bit":
+        # 0.25 B per genotype: the exact-integer kernels become matrix-core bound (4 digit planes x 32-cycle int8 MFMAs
+        # per 1024 genotypes); peak = dense int8 MFMA rate, 2 x the ~2.5 PF bf16 peak (MI355X_MICROARCH.md)
+        ops = 2.0 * 32 * 4 * (dom["bytes"] / dom["launches"] * 4)          # executed int8 MACs x 2 per launch (4 planes, L = 32)
+        tops = ops / (avg_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": tops, "peak": 5000.0, "unit": "TOP/s (int8, executed digit-plane MFMAs)",
+                "frac": tops / 5000.0, "traffic": traffic, "hbm_GBs_algorithmic": gbs, "algorithmic_TFLOPs_equivalent": tflops, **common}
     if precision == "i8":   # exact-integer MFMA needs ~1/10 of the matrix-core time per byte: HBM-bound
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_TFLOPs_equivalent": tflops, **common}
@@ -140,6 +147,8 @@ def main():
     ap.add_argument("--rfit-seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-path", action="store_true", help="skip the extra f32-MFMA measurement")
+    ap.add_argument("--storage", default="int8", choices=["int8", "2bit"],
+                    help="HBM residency of the genotypes: int8 = 1 B/genotype (the BASELINE.json configs), 2bit = 0.25 B (exact path only)")
     ap.add_argument("--precision", default="i8", choices=["f32", "i8"],
                     help="i8 = exact-integer GEMMs (default, fastest parity-green path); f32 = v_mfma_f32_32x32x2_f32")
     a = ap.parse_args()
@@ -178,7 +187,8 @@ def main():
     th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
     t_stats = None
     for prec in order:
-        eng = g.GpcaEngine(device=local_rank, precision=PREC[prec])
+        store = g._lib.STORE_2BIT if (a.storage == "2bit" and prec == "i8") else g._lib.STORE_INT8
+        eng = g.GpcaEngine(device=local_rank, precision=PREC[prec], storage=store)
         eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
         t0 = time.perf_counter()
         eng.snp_stats(g.QcConfig.none(), fetch=False)
@@ -206,8 +216,9 @@ def main():
             "config": {"workload": f"synthetic {M_total} SNPs x {N} samples int8 genotypes (3 populations, F_ST 0.05), "
                                    f"k={k}, l={l}, q={a.power_iters}, seed={a.rfit_seed}, resident in HBM",
                        "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample,
-                       "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}", "gemm_path": a.precision},
-            "roofline": roofline_of(timings, a.precision, a.steps),
+                       "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}", "gemm_path": a.precision,
+                       "residency": a.storage if a.precision == "i8" else "int8"},
+            "roofline": roofline_of(timings, a.precision, a.steps, a.storage),
             "snp_stats_s": t_stats,
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }

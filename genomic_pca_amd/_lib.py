@@ -23,6 +23,8 @@ GPCA_ERR_INVALID_GENOTYPE = -9
 GPCA_UNIQUE_ID_BYTES = 128
 PREC_F32_MFMA = 0
 PREC_I8_EXACT = 1
+STORE_INT8 = 0
+STORE_2BIT = 1
 
 
 class GpcaLibraryError(RuntimeError):
@@ -37,7 +39,7 @@ class GpcaError(RuntimeError):
 
 
 class gpca_config(C.Structure):
-    _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("storage", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class gpca_qc_config(C.Structure):

@@ -313,6 +313,247 @@ void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad
     hipLaunchKernelGGL(k_reduce_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y);
 }
 
+// ================================================================================================
+// 2-bit resident genotypes (GPCA_STORE_2BIT): the same two products with the dosage codes decoded in the prologue.
+// G2 [Mpad][ld2]: 4 samples per byte (codes 0/1/2; 3 = missing, only in SNPs whose r = b = 0).  HBM traffic drops to
+// 0.25 B per genotype; the kernels become matrix-core / VALU bound.
+// ================================================================================================
+
+// 16 samples (one 32-bit word of 2-bit codes) -> 16 int8 bytes:  per output dword 5 VALU ops (bfe, 2 x (lshl_or, and))
+__device__ __forceinline__ i32x4 spread16(unsigned w) {
+    i32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned t = (w >> (8 * q)) & 0xffu;
+        t = (t | (t << 12)) & 0x000F000Fu;
+        t = (t | (t << 6)) & 0x03030303u;
+        o[q] = (int)t;
+    }
+    return o;
+}
+
+// ---- K1, packed.  A lane's 16-byte load = 64 consecutive samples of its SNP row (half h of a 128-sample block);
+// MFMA step s of block b contracts samples {128b + 64h + 16s + j}: the digit planes of Q are stored in that order
+// (quantize layout 1).  Four blocks (one 128-byte line of the row) are requested back to back.
+template <int R>
+struct Gq2G { i32x4 g[4][R]; };
+
+template <int R>
+__device__ __forceinline__ void gq2_load_g(Gq2G<R>& b, __amdgpu_buffer_rsrc_t rg, const uint32_t (&gvo)[R], uint32_t s0) {
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b.g[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], s0 + 32u * j, 0);
+}
+
+template <int R, int S>
+__device__ __forceinline__ void gq2_compute(const i32x4 (&g)[R], const Gq8Q& q, i32x16 (&acc)[R][kDigits]) {
+    i32x4 op[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) op[t] = spread16((unsigned)g[t][S]);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+        for (int t = 0; t < R; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], q.q[d], acc[t][d], 0, 0, 0);
+}
+
+template <int R>
+__device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
+                                          const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          float& csum, int64_t row0, int c, int h, int lane) {
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
+    uint32_t gvo[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)((32 * t + c) * ld2 + 16 * h);
+    const uint32_t qvo = (uint32_t)(lane * 16);
+    constexpr uint32_t QCH = kDigits * 1024;   // bytes of digit planes per MFMA step
+    const uint32_t nsteps = (uint32_t)(nsuper * 16);
+
+    i32x16 acc[R][kDigits];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    Gq2G<R> GA, GB;
+    Gq8Q Q0, Q1, Q2, Q3;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd);   // digit planes are < 2 GiB: one descriptor
+    gq2_load_g<R>(GA, rg, gvo, 0u);
+    gq8_load_q(Q0, rq, qvo, 0u); gq8_load_q(Q1, rq, qvo, QCH); gq8_load_q(Q2, rq, qvo, 2 * QCH);
+    // one phase = one MFMA step: prefetch the digit planes 3 steps ahead, decode R operands, R x 4 MFMAs
+#define GQ2_PHASE(GCUR, B, S, QCUR, QNEXT, STEP)                                            \
+    { const uint32_t nst_ = (STEP) + 3u;                                                     \
+      gq8_load_q(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    gq2_compute<R, S>(GCUR.g[B], QCUR, acc);                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define GQ2_BLOCK(GCUR, B, STEP0)                      \
+    GQ2_PHASE(GCUR, B, 0, Q0, Q3, (STEP0) + 0u)         \
+    GQ2_PHASE(GCUR, B, 1, Q1, Q0, (STEP0) + 1u)         \
+    GQ2_PHASE(GCUR, B, 2, Q2, Q1, (STEP0) + 2u)         \
+    GQ2_PHASE(GCUR, B, 3, Q3, Q2, (STEP0) + 3u)
+    for (int64_t sc = 0; sc < nsuper; sc += 2) {        // nsuper (512-sample super-chunks) is even
+        const uint32_t st0 = (uint32_t)(sc * 16);
+        const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;
+        gq2_load_g<R>(GB, rg, gvo, (uint32_t)((sc + 1) * 128));
+        GQ2_BLOCK(GA, 0, st0) GQ2_BLOCK(GA, 1, st0 + 4u) GQ2_BLOCK(GA, 2, st0 + 8u) GQ2_BLOCK(GA, 3, st0 + 12u)
+        gq2_load_g<R>(GA, rg, gvo, (uint32_t)((sc + 2 * more) * 128));
+        GQ2_BLOCK(GB, 0, st0 + 16u) GQ2_BLOCK(GB, 1, st0 + 20u) GQ2_BLOCK(GB, 2, st0 + 24u) GQ2_BLOCK(GB, 3, st0 + 28u)
+    }
+#undef GQ2_BLOCK
+#undef GQ2_PHASE
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float ri = rv[row], bi = bv[row];
+            const float gq = (float)(combine_digits(acc[t], e) * qs);
+            const float tv = ri * gq + bi * sj;
+            csum += bi * tv;
+            Tout[row * 32 + c] = scale_out ? ri * tv : tv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ G2, int64_t ld2, int64_t units, int64_t nsuper,
+                                                     const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
+                                                     const float* __restrict__ rv, const float* __restrict__ bv,
+                                                     const float* __restrict__ sv, float* __restrict__ Tout,
+                                                     float* __restrict__ cpart, int scale_out) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    int64_t u = (units * wave) / waves;
+    const int64_t u_end = (units * (wave + 1)) / waves;
+    float csum = 0.f;
+    const float sj = sv[c];
+    const double qs = qscale[c];
+    for (; u + 4 <= u_end; u += 4) gq2_group<4>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane);
+    if (u + 2 <= u_end) { gq2_group<2>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 2; }
+    if (u + 1 <= u_end) { gq2_group<1>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 1; }
+    const float o = csum + __shfl_xor(csum, 32);
+    if (h == 0) cpart[wave * 32 + c] = o;
+}
+
+void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+                    const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
+                    int scale_out) {
+    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
+    const int64_t nsuper = Npad / 512;   // Npad is a multiple of 1024 in 2-bit mode -> even
+    hipLaunchKernelGGL(k_gq_2bit, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out);
+}
+
+// ---- K2, packed.  Lane (c, h) loads ONE byte (4 samples) from each of its 16 SNP rows; the four waves of a workgroup
+// cover 128 adjacent bytes of every row.  Four rows are OR-ed into a dword, and operand t is (x >> 2t) & 0x03030303.
+struct Gtt2Buf { unsigned g[16]; i32x4 t[kDigits]; };
+
+__device__ __forceinline__ void gtt2_load(Gtt2Buf& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off, uint32_t ld2,
+                                          __amdgpu_buffer_rsrc_t rt, uint32_t tvo, uint32_t toff) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rg, gvo, row_off + (uint32_t)i * ld2, 0);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) b.t[d] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, toff + d * 1024, 0);
+}
+__device__ __forceinline__ void gtt2_compute(const Gtt2Buf& b, i32x16 (&acc)[4][kDigits]) {
+    unsigned x[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        x[w] = (b.g[4 * w] & 0xffu) | ((b.g[4 * w + 1] & 0xffu) << 8) | ((b.g[4 * w + 2] & 0xffu) << 16) | (b.g[4 * w + 3] << 24);
+    i32x4 bt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) bt[t][w] = (int)((x[w] >> (2 * t)) & 0x03030303u);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.t[d], bt[t], acc[t][d], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void k_gtt_2bit(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Mpad, int64_t Npad,
+                                                      const int8_t* __restrict__ Td, double* __restrict__ Ypart,
+                                                      int64_t ngroups, int64_t rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ngroup = blockIdx.x % ngroups;
+    const int64_t wchunk = blockIdx.x / ngroups;
+    const int64_t nblock = ngroup * 4 + wv;
+    const int64_t n0 = nblock * 128;
+    if (n0 >= Npad) return;
+    const int64_t m_begin = wchunk * rows_per_wave;
+    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
+    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
+
+    i32x16 acc[4][kDigits];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    const uint32_t gvo = (uint32_t)(16 * h * ld2 + c);
+    const uint32_t tvo = (uint32_t)(lane * 16);
+    constexpr uint32_t TKB = kDigits * 1024;
+    const uint8_t* gp = G2 + m_begin * ld2 + (n0 >> 2);
+    const int8_t* tp = Td + (m_begin >> 5) * TKB;
+    Gtt2Buf B0, B1, B2, B3;
+    {
+        const __amdgpu_buffer_rsrc_t rg0 = make_rsrc8(gp), rt0 = make_rsrc8(tp);
+        gtt2_load(B0, rg0, gvo, 0u, (uint32_t)ld2, rt0, tvo, 0u);
+        gtt2_load(B1, rg0, gvo, 32u * (uint32_t)ld2, (uint32_t)ld2, rt0, tvo, TKB);
+        gtt2_load(B2, rg0, gvo, 64u * (uint32_t)ld2, (uint32_t)ld2, rt0, tvo, 2 * TKB);
+    }
+    for (int64_t kb = 0; kb < kblocks; kb += 4) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc8(gp + kb * 32 * ld2);
+        const __amdgpu_buffer_rsrc_t rt = make_rsrc8(tp + kb * TKB);
+        const uint32_t more = (kb + 4 < kblocks) ? 1u : 0u;
+        const uint32_t L32 = 32u * (uint32_t)ld2;
+        gtt2_load(B3, rg, gvo, 3u * L32, (uint32_t)ld2, rt, tvo, 3 * TKB);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt2_compute(B0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt2_load(B0, rg, gvo, 4u * L32 * more, (uint32_t)ld2, rt, tvo, 4 * TKB * more);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt2_compute(B1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt2_load(B1, rg, gvo, (4u * more + 1u) * L32, (uint32_t)ld2, rt, tvo, (4 * more + 1) * TKB);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt2_compute(B2, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt2_load(B2, rg, gvo, (4u * more + 2u) * L32, (uint32_t)ld2, rt, tvo, (4 * more + 2) * TKB);
+        __builtin_amdgcn_sched_barrier(0);
+        gtt2_compute(B3, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    double* yp = Ypart + (wchunk * Npad) * 32;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t n = n0 + 4 * c + t;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
+            double2 o;
+            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
+            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
+        }
+    }
+}
+
+void launch_gtt_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td,
+                     double* Ypart, const Gtt8Plan& plan) {
+    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    hipLaunchKernelGGL(k_gtt_2bit, dim3((unsigned)plan.grid), dim3(256), 0, st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
+                       plan.rows_per_wave);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Quantisation of the skinny operand: column abs-max -> scale; X[rows][32] -> digit planes
 // blocked [block = row/32][d][lane = 32*((row%32)/16) + col][j = row%16] (16 B per lane per plane).
@@ -351,9 +592,11 @@ __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict_
     inv[cc] = a > 0.0 ? S / a : 0.0;
 }
 
+// layout 0: block = 32 consecutive rows, lane half hh, element j -> row 32*blk + 16*hh + j
+// layout 1 (packed K1): block = MFMA step (b, s) of a 128-row group -> row 128*(blk/4) + 64*hh + 16*(blk%4) + j
 template <typename T>
 __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64_t rows, int64_t rows_pad,
-                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd) {
+                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout) {
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk * 32 >= rows_pad) return;
@@ -366,7 +609,7 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
         for (int q = 0; q < 4; ++q) w[d][q] = 0u;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int64_t row = blk * 32 + 16 * hh + j;
+        const int64_t row = layout ? (blk >> 2) * 128 + 64 * hh + 16 * (blk & 3) + j : blk * 32 + 16 * hh + j;
         const double x = row < rows ? (double)X[row * 32 + cc] : 0.0;
         long long v = __double2ll_rn(x * sc);
 #pragma unroll
@@ -383,16 +626,16 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
 
 template <typename T>
 static void quantize_t(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, double* part, double* scale, double* inv,
-                       int8_t* Xd) {
+                       int8_t* Xd, int layout) {
     const int64_t P = absmax_num_parts(rows);
     hipLaunchKernelGGL((k_col_absmax<T>), dim3((unsigned)P), dim3(256), 0, st, X, rows, part);
     hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv);
     const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd);
+    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout);
 }
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd); }
+                         double* inv, int8_t* Xd, int layout) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout); }
 void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd); }
+                         double* inv, int8_t* Xd, int layout) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd, layout); }
 
 }  // namespace gpca

@@ -56,12 +56,16 @@ struct TimingRec { std::string name; hipEvent_t a, b; double flops, bytes; };
 struct gpca_handle {
     int device = 0;
     int precision = GPCA_PREC_F32_MFMA;
+    int storage = GPCA_STORE_INT8;
     hipStream_t st = nullptr;
     std::string err;
 
     // genotypes
     int64_t M = 0, N = 0, ldg = 0, Mpad = 0;   // Mpad = round_up(M, 128): zero rows, so the GEMM loops carry no predicates
-    int8_t* dG = nullptr;
+    int8_t* dG = nullptr;      // GPCA_STORE_INT8: [Mpad][ldg]
+    uint8_t* dG2 = nullptr;    // GPCA_STORE_2BIT: [Mpad][ld2], ld2 = ldg / 4, dosage codes (3 = missing)
+    int64_t ld2 = 0;
+    uint32_t pack_flags = 0;   // invalid genotypes seen while packing int8 input
 
     // stats
     bool have_stats = false;
@@ -183,6 +187,9 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (dev >= ndev) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: device ordinal out of range"); }
     h->device = dev;
     h->precision = cfg ? cfg->precision : GPCA_PREC_F32_MFMA;
+    h->storage = cfg ? cfg->storage : GPCA_STORE_INT8;
+    if (h->storage != GPCA_STORE_INT8 && h->storage != GPCA_STORE_2BIT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown storage mode"); }
+    if (h->storage == GPCA_STORE_2BIT && h->precision != GPCA_PREC_I8_EXACT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: GPCA_STORE_2BIT requires GPCA_PREC_I8_EXACT"); }
     // tuning knobs (resident-wave targets of the two GEMM grids); defaults are the tuned values
     if (const char* e = getenv("GPCA_GQ_WAVES")) h->gq_waves_target = std::max(4, atoi(e));
     if (const char* e = getenv("GPCA_GTT_WAVES")) h->gtt_waves_target = std::max(4, atoi(e));
@@ -223,7 +230,7 @@ extern "C" int gpca_destroy(gpca_handle* h) {
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    free_stats(h); free_ws(h); dfree(h->dG);
+    free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
     (void)hipStreamDestroy(h->st);
     delete h;
     return GPCA_OK;
@@ -239,16 +246,55 @@ extern "C" int gpca_synchronize(gpca_handle* h) {
 static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return fail(h, GPCA_ERR_BAD_ARG, "genotype matrix must have M > 0 SNPs and N > 0 samples");
     HIPCHK(hipSetDevice(h->device));
-    free_stats(h); free_ws(h); dfree(h->dG);
-    h->M = M; h->N = N; h->ldg = round_up(N, kSamplePad); h->Mpad = round_up(M, kGQRowsPerWave);
+    free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
+    h->M = M; h->N = N; h->Mpad = round_up(M, kGQRowsPerWave); h->pack_flags = 0;
+    if (h->storage == GPCA_STORE_2BIT) {
+        h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4;
+        HIPCHK(hipMalloc((void**)&h->dG2, (size_t)h->Mpad * (size_t)h->ld2));
+        if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG2 + (size_t)M * (size_t)h->ld2, 0, (size_t)(h->Mpad - M) * (size_t)h->ld2, h->st));
+        return GPCA_OK;
+    }
+    h->ldg = round_up(N, kSamplePad);
     HIPCHK(hipMalloc((void**)&h->dG, (size_t)h->Mpad * (size_t)h->ldg));
     if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG + (size_t)M * (size_t)h->ldg, 0, (size_t)(h->Mpad - M) * (size_t)h->ldg, h->st));
+    return GPCA_OK;
+}
+
+// 2-bit mode: int8 rows go through a scratch buffer of <= 256 MiB and are packed on the device
+static int64_t pack_chunk_rows(gpca_handle* h) {
+    int64_t r = ((int64_t)256 << 20) / h->ldg;
+    if (r < 1) r = 1;
+    return r < h->M ? r : h->M;
+}
+static int finish_pack_flags(gpca_handle* h, unsigned* d_flags) {
+    unsigned f = 0;
+    HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    h->pack_flags |= f;
     return GPCA_OK;
 }
 
 extern "C" int gpca_upload_genotypes_i8(gpca_handle* h, const int8_t* src, int64_t M, int64_t N, int64_t ld) {
     if (!h || !src || ld < N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_upload_genotypes_i8: bad arguments");
     CHK(alloc_genotypes(h, M, N));
+    if (h->storage == GPCA_STORE_2BIT) {
+        const int64_t cr = pack_chunk_rows(h);
+        int8_t* scratch = nullptr; unsigned* d_flags = nullptr;
+        HIPCHK(hipMalloc((void**)&scratch, (size_t)cr * (size_t)h->ldg));
+        hipError_t e = hipMalloc((void**)&d_flags, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 16, h->st);
+        if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, (size_t)cr * (size_t)h->ldg, h->st);
+        for (int64_t r0 = 0; r0 < M && e == hipSuccess; r0 += cr) {
+            const int64_t rows = std::min(cr, M - r0);
+            e = hipMemcpy2DAsync(scratch, (size_t)h->ldg, src + r0 * ld, (size_t)ld, (size_t)N, (size_t)rows, hipMemcpyHostToDevice, h->st);
+            if (e == hipSuccess) { launch_pack_i8(h->st, scratch, h->ldg, h->dG2 + (size_t)r0 * h->ld2, rows, N, h->ld2, d_flags); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipStreamSynchronize(h->st);   // the host source of the next chunk may be pageable
+        }
+        int rc = e == hipSuccess ? finish_pack_flags(h, d_flags) : GPCA_OK;
+        (void)hipFree(scratch); (void)hipFree(d_flags);
+        HIPCHK(e);
+        return rc;
+    }
     if (h->ldg != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ldg, h->st));
     HIPCHK(hipMemcpy2DAsync(h->dG, (size_t)h->ldg, src, (size_t)ld, (size_t)N, (size_t)M, hipMemcpyHostToDevice, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
@@ -262,7 +308,11 @@ extern "C" int gpca_upload_bed2bit(gpca_handle* h, const uint8_t* bed_rows, int6
     uint8_t* d_bed = nullptr;
     HIPCHK(hipMalloc((void**)&d_bed, (size_t)M * (size_t)bpr));
     hipError_t e = hipMemcpyAsync(d_bed, bed_rows, (size_t)M * (size_t)bpr, hipMemcpyHostToDevice, h->st);
-    if (e == hipSuccess) { launch_bed_decode(h->st, d_bed, bpr, h->dG, M, N, h->ldg); e = hipGetLastError(); }
+    if (e == hipSuccess) {
+        if (h->storage == GPCA_STORE_2BIT) launch_bed_to_codes(h->st, d_bed, bpr, h->dG2, M, N, h->ld2);   // stays 2-bit
+        else launch_bed_decode(h->st, d_bed, bpr, h->dG, M, N, h->ldg);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     (void)hipFree(d_bed);
     HIPCHK(e);
@@ -276,7 +326,21 @@ extern "C" int gpca_synth_genotypes(gpca_handle* h, int64_t M, int64_t N, uint64
     uint32_t* d_th = nullptr;
     HIPCHK(hipMalloc((void**)&d_th, (size_t)M * P * sizeof(uint32_t)));
     hipError_t e = hipMemcpyAsync(d_th, thresh, (size_t)M * P * sizeof(uint32_t), hipMemcpyHostToDevice, h->st);
-    if (e == hipSuccess) { launch_synth(h->st, h->dG, M, N, h->ldg, snp_offset, seed, d_th, P); e = hipGetLastError(); }
+    if (e == hipSuccess && h->storage == GPCA_STORE_2BIT) {
+        const int64_t cr = pack_chunk_rows(h);
+        int8_t* scratch = nullptr; unsigned* d_flags = nullptr;
+        e = hipMalloc((void**)&scratch, (size_t)cr * (size_t)h->ldg);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_flags, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 16, h->st);
+        for (int64_t r0 = 0; r0 < M && e == hipSuccess; r0 += cr) {
+            const int64_t rows = std::min(cr, M - r0);
+            launch_synth(h->st, scratch, rows, N, h->ldg, snp_offset + r0, seed, d_th + (size_t)r0 * P, P);
+            launch_pack_i8(h->st, scratch, h->ldg, h->dG2 + (size_t)r0 * h->ld2, rows, N, h->ld2, d_flags);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+        (void)hipFree(scratch); (void)hipFree(d_flags);
+    } else if (e == hipSuccess) { launch_synth(h->st, h->dG, M, N, h->ldg, snp_offset, seed, d_th, P); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     (void)hipFree(d_th);
     HIPCHK(e);
@@ -284,7 +348,17 @@ extern "C" int gpca_synth_genotypes(gpca_handle* h, int64_t M, int64_t N, uint64
 }
 
 extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t ld) {
-    if (!h || !out || !h->dG || ld < h->N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_download_genotypes_i8: bad arguments / nothing resident");
+    if (!h || !out || (!h->dG && !h->dG2) || ld < h->N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_download_genotypes_i8: bad arguments / nothing resident");
+    if (h->storage == GPCA_STORE_2BIT) {   // debug/test path: copy the packed rows and unpack on the host
+        HIPCHK(hipStreamSynchronize(h->st));
+        std::vector<uint8_t> row((size_t)h->ld2);
+        static const int8_t lut[4] = {0, 1, 2, -127};
+        for (int64_t i = 0; i < h->M; ++i) {
+            HIPCHK(hipMemcpy(row.data(), h->dG2 + (size_t)i * h->ld2, (size_t)h->ld2, hipMemcpyDeviceToHost));
+            for (int64_t n = 0; n < h->N; ++n) out[i * ld + n] = lut[(row[(size_t)(n >> 2)] >> (2 * (n & 3))) & 3];
+        }
+        return GPCA_OK;
+    }
     HIPCHK(hipMemcpy2D(out, (size_t)ld, h->dG, (size_t)h->ldg, (size_t)h->N, (size_t)h->M, hipMemcpyDeviceToHost));
     return GPCA_OK;
 }
@@ -325,7 +399,7 @@ static int refresh_pca_rows(gpca_handle* h) {
 
 extern "C" int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* mu, float* sigma, uint8_t* keep) {
     if (!h) return GPCA_ERR_BAD_ARG;
-    if (!h->dG) return fail(h, GPCA_ERR_STATE, "gpca_snp_stats: no genotypes resident");
+    if (!h->dG && !h->dG2) return fail(h, GPCA_ERR_STATE, "gpca_snp_stats: no genotypes resident");
     HIPCHK(hipSetDevice(h->device));
     CHK(alloc_stats(h));
     QcParams q{0.0, 0.0, 1.0};
@@ -333,12 +407,17 @@ extern "C" int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* m
     HIPCHK(hipMemsetAsync(h->d_flags, 0, 16, h->st));
     {
         ScopedTimer t(h, "snp_stats", 0.0, (double)h->M * (double)h->N);
-        launch_snp_stats(h->st, h->dG, h->M, h->N, h->ldg, q, h->d_mu, h->d_sigma, h->d_r, h->d_b, h->d_keep, h->d_reason,
-                         h->d_counts, h->d_flags);
+        if (h->storage == GPCA_STORE_2BIT)
+            launch_snp_stats_2bit(h->st, h->dG2, h->M, h->N, h->ld2, q, h->d_mu, h->d_sigma, h->d_r, h->d_b, h->d_keep, h->d_reason,
+                                  h->d_counts, h->d_flags);
+        else
+            launch_snp_stats(h->st, h->dG, h->M, h->N, h->ldg, q, h->d_mu, h->d_sigma, h->d_r, h->d_b, h->d_keep, h->d_reason,
+                             h->d_counts, h->d_flags);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&h->flags, h->d_flags, 4, hipMemcpyDeviceToHost, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
+    h->flags |= h->pack_flags;   // 2-bit mode: values outside {0,1,2,-127} were seen (and stored as missing) at upload
     CHK(refresh_pca_rows(h));
     h->have_stats = true; h->have_rsvd = false;
     if (mu) HIPCHK(hipMemcpy(mu, h->d_mu, (size_t)h->M * 4, hipMemcpyDeviceToHost));
@@ -357,7 +436,7 @@ extern "C" int gpca_get_snp_qc_detail(gpca_handle* h, uint32_t* counts, uint8_t*
 
 extern "C" int gpca_set_standardization(gpca_handle* h, const float* mu, const float* sigma, const uint8_t* keep) {
     if (!h || !mu || !sigma) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_standardization: mu and sigma are required");
-    if (!h->dG) return fail(h, GPCA_ERR_STATE, "gpca_set_standardization: no genotypes resident");
+    if (!h->dG && !h->dG2) return fail(h, GPCA_ERR_STATE, "gpca_set_standardization: no genotypes resident");
     HIPCHK(hipSetDevice(h->device));
     // a stats pass supplies the missing/invalid flags for the rows the caller keeps
     if (!h->have_stats) { gpca_qc_config none{0.0, 0.0, 1.0}; CHK(gpca_snp_stats(h, &none, nullptr, nullptr, nullptr)); }
@@ -443,7 +522,8 @@ extern "C" int gpca_standardize_block(gpca_handle* h, const int64_t* snp_ids, in
     if (e == hipSuccess) e = hipMemcpyAsync(d_cols, sample_ids, (size_t)nj * 8, hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_err, &err_idx, 8, hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess) {
-        launch_standardize_block(h->st, h->dG, h->ldg, h->d_mu, h->d_sigma, d_rows, ns, d_cols, nj, d_out, d_err);
+        if (h->storage == GPCA_STORE_2BIT) launch_standardize_block_2bit(h->st, h->dG2, h->ld2, h->d_mu, h->d_sigma, d_rows, ns, d_cols, nj, d_out, d_err);
+        else launch_standardize_block(h->st, h->dG, h->ldg, h->d_mu, h->d_sigma, d_rows, ns, d_cols, nj, d_out, d_err);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&err_idx, d_err, 8, hipMemcpyDeviceToHost, h->st);
@@ -588,8 +668,9 @@ static int stage_AtT(gpca_handle* h) {
         launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd);
         HIPCHK(hipGetLastError());
         {
-            ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, elems);
-            launch_gtt_i8(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+            ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
+            if (h->storage == GPCA_STORE_2BIT) launch_gtt_2bit(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+            else launch_gtt_i8(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
         }
         HIPCHK(hipGetLastError());
         launch_reduce_y_i8(h->st, h->dYpart64, h->plan8.W, h->ldg, h->N, h->d_c, h->d_tscale, h->dY);
@@ -611,8 +692,9 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     const double elems = (double)h->M * (double)h->N;
     if (h->precision == GPCA_PREC_I8_EXACT) {
         {
-            ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, elems);
-            launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+            ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
+            if (h->storage == GPCA_STORE_2BIT) launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+            else launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
         }
         HIPCHK(hipGetLastError());
         if (scale_out) CHK(stage_sum_c(h, h->gqplan.waves));
@@ -659,7 +741,7 @@ static int stage_orth(gpca_handle* h) {
     launch_f64_to_f32(h->st, h->d_s64, h->d_s32, L);
     HIPCHK(hipGetLastError());
     if (h->precision == GPCA_PREC_I8_EXACT) {   // digit planes of the basis for the int8 G Q product
-        launch_quantize_f64(h->st, h->dY, h->N, h->ldg, h->d_part64, h->d_qscale, h->d_qinv, h->dQd);
+        launch_quantize_f64(h->st, h->dY, h->N, h->ldg, h->d_part64, h->d_qscale, h->d_qinv, h->dQd, h->storage == GPCA_STORE_2BIT ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     return GPCA_OK;
@@ -705,7 +787,7 @@ static int ensure_workspace(gpca_handle* h) {
 
 extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed) {
     if (!h) return GPCA_ERR_BAD_ARG;
-    if (!h->dG) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: no genotypes resident");
+    if (!h->dG && !h->dG2) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: no genotypes resident");
     if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: run gpca_snp_stats or gpca_set_standardization first");
     if (k <= 0) return fail(h, GPCA_ERR_BAD_ARG, "Number of components (-k) must be > 0.");  // main.rs:607-609
     if (oversample < 0 || power_iters < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: negative oversample/power_iters");

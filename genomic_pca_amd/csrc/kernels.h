@@ -108,9 +108,26 @@ void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad
                         const double* tscale, double* Y);
 int64_t absmax_num_parts(int64_t rows);
 // X [rows][32] row-major -> digit planes Xd [rows_pad/32][kDigits][64][16 B]; scale[j] = colmax_j / S, inv = 1/scale
+// layout 0: 32 consecutive rows per block; layout 1: the MFMA-step order of the packed (2-bit) G Q kernel
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd);
+                         double* inv, int8_t* Xd, int layout = 0);
 void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd);
+                         double* inv, int8_t* Xd, int layout = 0);
+
+// ---- 2-bit resident genotypes (store2bit.hip, gemm_i8.hip) -----------------------------------------------------
+constexpr int64_t kSamplePad2bit = 1024;   // samples per row padded to this (ld2 = Npad / 4 bytes)
+void launch_bed_to_codes(hipStream_t st, const uint8_t* bed, int64_t bpr, uint8_t* G2, int64_t M, int64_t N, int64_t ld2);
+void launch_pack_i8(hipStream_t st, const int8_t* G8, int64_t ld8, uint8_t* G2, int64_t rows, int64_t N, int64_t ld2,
+                    unsigned* flags);
+void launch_snp_stats_2bit(hipStream_t st, const uint8_t* G2, int64_t M, int64_t N, int64_t ld2, QcParams qc, float* mu,
+                           float* sigma, float* r, float* b, uint8_t* keep, uint8_t* reason, uint32_t* counts, uint32_t* flags);
+void launch_standardize_block_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const float* mu, const float* sigma,
+                                   const int64_t* rows, int64_t ns, const int64_t* cols, int64_t nj, float* out,
+                                   unsigned long long* err_idx);
+void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+                    const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
+                    int scale_out);
+void launch_gtt_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td,
+                     double* Ypart, const Gtt8Plan& plan);
 
 }  // namespace gpca

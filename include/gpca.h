@@ -58,10 +58,18 @@ typedef enum gpca_precision {
     GPCA_PREC_I8_EXACT = 1  /* v_mfma_i32_32x32x32_i8 on fixed-point digits of the skinny operand */
 } gpca_precision;
 
+/* How the genotypes stay resident in HBM. */
+typedef enum gpca_storage {
+    GPCA_STORE_INT8 = 0, /* 1 B per genotype */
+    GPCA_STORE_2BIT = 1  /* 0.25 B per genotype (PLINK-like packing of dosage codes), decoded in the GEMM prologues;
+                            requires GPCA_PREC_I8_EXACT.  10M SNPs x 100k samples = 250 GB: fits one MI355X. */
+} gpca_storage;
+
 typedef struct gpca_config {
     int32_t device;    /* HIP ordinal; -1 = current device */
     int32_t precision; /* gpca_precision */
-    int32_t reserved[6];
+    int32_t storage;   /* gpca_storage */
+    int32_t reserved[5];
 } gpca_config;
 
 /* SNP QC thresholds = MicroarrayDataPreparerConfig, main.rs:302-309 / prepare.rs:1281-1311,1363.

@@ -476,3 +476,111 @@ def test_i8_rejects_wide_sketch(gpca, engine_i8):
     engine_i8.snp_stats()
     with pytest.raises(gpca.GpcaError):
         engine_i8.rsvd(30, 10)        # l = 40 > 32
+
+
+# ------------------------------------------------------------------------------------------------
+# 2-bit resident genotypes (GPCA_STORE_2BIT, decode in the GEMM prologues): same answers as int8 residency
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def engine_2bit(gpca):
+    from genomic_pca_amd import _lib
+    e = gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("M,N,P", [(1000, 333, 3), (257, 1025, 5), (64, 2100, 2), (4096, 64, 3), (3, 7, 2)])
+def test_2bit_synth_and_upload_roundtrip(gpca, oracle, engine_2bit, M, N, P):
+    th = gpca.synth_thresholds(M, P, seed=42)
+    engine_2bit.synth_genotypes(M, N, 42, th)
+    ref = oracle.synth_genotypes(M, N, 42, th)
+    assert np.array_equal(engine_2bit.download_genotypes_i8(), ref)
+    G = _inject(ref, np.random.default_rng(1), 0.03)
+    engine_2bit.upload_genotypes_i8(G)
+    assert np.array_equal(engine_2bit.download_genotypes_i8(), G)
+
+
+def test_2bit_stats_and_block_parity(gpca, oracle, engine_2bit):
+    M, N = 1500, 777
+    rng = np.random.default_rng(9)
+    G = _inject(oracle.synth_genotypes(M, N, 3, gpca.synth_thresholds(M, 3, seed=3, fst=0.1)), rng, 0.02)
+    G[0] = 0; G[1] = 2; G[2] = -127; G[3, : N // 2] = -127; G[4] = np.where(np.arange(N) % 2 == 0, 0, 2)
+    engine_2bit.upload_genotypes_i8(G)
+    for qc in [gpca.QcConfig.none(), gpca.QcConfig(), gpca.QcConfig(0.9, 0.05, 1e-3)]:
+        st = engine_2bit.snp_stats(qc)
+        counts, reason = engine_2bit.snp_qc_detail()
+        ref = oracle.snp_stats(G, N, qc.min_snp_call_rate, qc.min_snp_maf, qc.max_snp_hwe_p_value)
+        assert np.array_equal(counts, ref["counts"]) and np.array_equal(st["keep"], ref["keep"]) and np.array_equal(reason, ref["reason"])
+        assert np.array_equal(st["mu"], ref["mu"]) and np.all(np.abs(st["sigma"] - ref["sigma"]) <= np.spacing(ref["sigma"]))
+    st = engine_2bit.snp_stats(gpca.QcConfig(1.0, 0.05, 1.0))          # only fully called SNPs
+    rows = engine_2bit.pca_snp_rows()
+    sid = rng.permutation(len(rows))[:50]; cid = rng.permutation(N)[:123]
+    out = engine_2bit.standardize_block(sid, cid)
+    ref, err = oracle.standardize_block(G, st["mu"], st["sigma"], rows[sid], cid)
+    assert err is None and np.array_equal(out, ref)
+    engine_2bit.snp_stats(gpca.QcConfig(0.9, 0.05, 1.0))               # now SNPs with missing genotypes are kept
+    with pytest.raises(gpca.GpcaError) as e:
+        engine_2bit.standardize_block(np.arange(engine_2bit.num_pca_snps()), np.arange(N))
+    assert e.value.status == -5
+    with pytest.raises(gpca.GpcaError) as e:
+        engine_2bit.rsvd(2, 2, 1, 1)
+    assert e.value.status == -5
+
+
+def test_2bit_bed_upload_stays_packed(gpca, oracle, engine_2bit):
+    z = np.load(os.path.join(GOLD, "chr22_subset50_slice.npz"))
+    engine_2bit.upload_bed2bit(z["bed_rows"], int(z["n_samples"]))
+    assert np.array_equal(engine_2bit.download_genotypes_i8(), z["dosage_count_a1"])
+    rng = np.random.default_rng(3)
+    for n2 in (1, 5, 63, 130, 1030):
+        b = rng.integers(0, 256, size=(37, (n2 + 3) // 4), dtype=np.uint8)
+        lut = np.array([2, -127, 1, 0], np.int8)
+        exp = np.empty((37, b.shape[1] * 4), np.int8)
+        for s in range(4):
+            exp[:, s::4] = lut[(b >> (2 * s)) & 3]
+        engine_2bit.upload_bed2bit(b, n2)
+        assert np.array_equal(engine_2bit.download_genotypes_i8(), exp[:, :n2])
+        st = engine_2bit.snp_stats(gpca.QcConfig.none())
+        o = oracle.snp_stats(exp[:, :n2], n2, 0.0, 0.0, 1.0)
+        assert np.array_equal(engine_2bit.snp_qc_detail()[0], o["counts"]) and np.array_equal(st["keep"], o["keep"])
+
+
+def test_2bit_invalid_values_flagged(gpca, engine_2bit):
+    G = np.random.default_rng(5).integers(0, 3, size=(40, 300), dtype=np.int8)
+    G[3, 17] = 3
+    engine_2bit.upload_genotypes_i8(G)
+    engine_2bit.snp_stats(gpca.QcConfig.none())
+    with pytest.raises(gpca.GpcaError) as e:
+        engine_2bit.rsvd(2, 2, 1, 1)
+    assert e.value.status in (-5, -9)
+
+
+@pytest.mark.parametrize("M,N,P,k", [(4096, 512, 12, 8), (20000, 1000, 16, 10), (3000, 1500, 10, 6), (999, 257, 8, 4), (130, 70, 4, 3)])
+def test_rsvd_parity_2bit(gpca, oracle, engine_2bit, M, N, P, k):
+    G, r, b, R = _rsvd_case(gpca, oracle, engine_2bit, M, N, P, k, seed=1, fst=0.2)
+    e = engine_2bit
+    assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+    assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
+    assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]) < TOL_PC
+    tr = e.transform()
+    A = oracle.standardized_dense(G, N, r, b)
+    ref = A.T @ e.loadings().astype(np.float64)
+    assert np.max(np.abs(tr - ref)) < 1e-4 * np.max(np.abs(ref))
+
+
+def test_2bit_equals_int8_residency(gpca, oracle, engine_i8, engine_2bit):
+    """Same exact-integer arithmetic on the same codes: the packed path reproduces the int8-resident path."""
+    M, N = 6000, 900
+    G = oracle.synth_genotypes(M, N, 5, gpca.synth_thresholds(M, 8, seed=5, fst=0.3))
+    res = []
+    for e in (engine_i8, engine_2bit):
+        e.upload_genotypes_i8(G); e.snp_stats(); e.rsvd(6, 10, 2, seed=3)
+        res.append((e.eigenvalues(), e.scores(f64=True)))
+    assert np.max(np.abs(res[0][0] - res[1][0]) / res[0][0]) < 1e-8
+    assert oracle.max_abs_dpc(res[0][1], res[1][1]) < 1e-8
+
+
+def test_2bit_requires_exact_integer_path(gpca):
+    from genomic_pca_amd import _lib
+    with pytest.raises(gpca.GpcaError):
+        gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA, storage=_lib.STORE_2BIT)
