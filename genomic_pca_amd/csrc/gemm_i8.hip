@@ -36,6 +36,16 @@ __device__ __forceinline__ double combine_digits(const i32x16 (&a)[kDigits], int
     return (double)a[0][e] + 128.0 * (double)a[1][e] + 16384.0 * (double)a[2][e] + 2097152.0 * (double)a[3][e];
 }
 
+// ask the scheduler for N x { 1 MFMA, V VALU } so that the next step's decode issues in the shadow of the MFMAs
+template <int N, int V>
+__device__ __forceinline__ void interleave_mfma_valu() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);   // VALU
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------
@@ -346,22 +356,39 @@ __device__ __forceinline__ void gq2_load_g(Gq2G<R>& b, __amdgpu_buffer_rsrc_t rg
         for (int j = 0; j < 4; ++j) b.g[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], s0 + 32u * j, 0);
 }
 
+// decode the R operands of MFMA step S of one 128-sample block (one dword per tile)
 template <int R, int S>
-__device__ __forceinline__ void gq2_compute(const i32x4 (&g)[R], const Gq8Q& q, i32x16 (&acc)[R][kDigits]) {
-    i32x4 op[R];
+__device__ __forceinline__ void gq2_decode(const i32x4 (&g)[R], i32x4 (&op)[R]) {
 #pragma unroll
     for (int t = 0; t < R; ++t) op[t] = spread16((unsigned)g[t][S]);
+}
+__device__ __forceinline__ int spread4(unsigned w, int q) {   // byte q of w (4 samples) -> 4 int8 bytes
+    unsigned t = (w >> (8 * q)) & 0xffu;
+    t = (t | (t << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    return (int)t;
+}
+// The R x 4 int8 MFMAs of the current step, each followed by one micro-step (5 VALU ops = one output dword) of the
+// NEXT step's decode; sched_barrier(0) pins the order so the VALU work issues in the shadow of the matrix pipe.
+template <int R, int SN>
+__device__ __forceinline__ void gq2_mfma_decode(const i32x4 (&op)[R], const Gq8Q& q, i32x16 (&acc)[R][kDigits],
+                                                const i32x4 (&gn)[R], i32x4 (&opn)[R], const unsigned* lut) {
 #pragma unroll
     for (int d = 0; d < kDigits; ++d)
 #pragma unroll
-        for (int t = 0; t < R; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], q.q[d], acc[t][d], 0, 0, 0);
+        for (int t = 0; t < R; ++t) {
+            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], q.q[d], acc[t][d], 0, 0, 0);
+            const int m = d * R + t;          // 4R MFMAs <-> 4R output dwords (tile m / 4, dword m % 4)
+            opn[m >> 2][m & 3] = (int)lut[((unsigned)gn[m >> 2][SN] >> (8 * (m & 3))) & 0xffu];   // 2 VALU + 1 LDS read
+            __builtin_amdgcn_sched_barrier(0);
+        }
 }
 
 template <int R>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
-                                          float& csum, int64_t row0, int c, int h, int lane) {
+                                          float& csum, int64_t row0, int c, int h, int lane, const unsigned* lut) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
     uint32_t gvo[R];
 #pragma unroll
@@ -380,28 +407,35 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
 
     Gq2G<R> GA, GB;
     Gq8Q Q0, Q1, Q2, Q3;
+    i32x4 opA[R], opB[R];
     const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd);   // digit planes are < 2 GiB: one descriptor
     gq2_load_g<R>(GA, rg, gvo, 0u);
     gq8_load_q(Q0, rq, qvo, 0u); gq8_load_q(Q1, rq, qvo, QCH); gq8_load_q(Q2, rq, qvo, 2 * QCH);
-    // one phase = one MFMA step: prefetch the digit planes 3 steps ahead, decode R operands, R x 4 MFMAs
-#define GQ2_PHASE(GCUR, B, S, QCUR, QNEXT, STEP)                                            \
+    gq2_decode<R, 0>(GA.g[0], opA);
+    // One phase = one MFMA step: prefetch the digit planes 3 steps ahead; the R x 4 int8 MFMAs of this step (matrix
+    // pipe) and the bit-spreading of the NEXT step's operands (VALU, 5 ops per dword) sit in one scheduling region so
+    // that they interleave.  Operand sets alternate opA / opB.
+#define GQ2_PHASE(OPCUR, OPNXT, GNXT, BN, SN, QCUR, QNEXT, STEP)                            \
     { const uint32_t nst_ = (STEP) + 3u;                                                     \
       gq8_load_q(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }                       \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    gq2_compute<R, S>(GCUR.g[B], QCUR, acc);                                                 \
+    gq2_mfma_decode<R, SN>(OPCUR, QCUR, acc, GNXT.g[BN], OPNXT, lut);                        \
     __builtin_amdgcn_sched_barrier(0);
-#define GQ2_BLOCK(GCUR, B, STEP0)                      \
-    GQ2_PHASE(GCUR, B, 0, Q0, Q3, (STEP0) + 0u)         \
-    GQ2_PHASE(GCUR, B, 1, Q1, Q0, (STEP0) + 1u)         \
-    GQ2_PHASE(GCUR, B, 2, Q2, Q1, (STEP0) + 2u)         \
-    GQ2_PHASE(GCUR, B, 3, Q3, Q2, (STEP0) + 3u)
+    // block B of buffer GCUR: steps (B,0..3); the step after (B,3) is (BNX,0) of buffer GNX
+#define GQ2_BLOCK(GCUR, B, GNX, BNX, STEP0)                                   \
+    GQ2_PHASE(opA, opB, GCUR, B, 1, Q0, Q3, (STEP0) + 0u)                       \
+    GQ2_PHASE(opB, opA, GCUR, B, 2, Q1, Q0, (STEP0) + 1u)                       \
+    GQ2_PHASE(opA, opB, GCUR, B, 3, Q2, Q1, (STEP0) + 2u)                       \
+    GQ2_PHASE(opB, opA, GNX, BNX, 0, Q3, Q2, (STEP0) + 3u)
     for (int64_t sc = 0; sc < nsuper; sc += 2) {        // nsuper (512-sample super-chunks) is even
         const uint32_t st0 = (uint32_t)(sc * 16);
         const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;
         gq2_load_g<R>(GB, rg, gvo, (uint32_t)((sc + 1) * 128));
-        GQ2_BLOCK(GA, 0, st0) GQ2_BLOCK(GA, 1, st0 + 4u) GQ2_BLOCK(GA, 2, st0 + 8u) GQ2_BLOCK(GA, 3, st0 + 12u)
-        gq2_load_g<R>(GA, rg, gvo, (uint32_t)((sc + 2 * more) * 128));
-        GQ2_BLOCK(GB, 0, st0 + 16u) GQ2_BLOCK(GB, 1, st0 + 20u) GQ2_BLOCK(GB, 2, st0 + 24u) GQ2_BLOCK(GB, 3, st0 + 28u)
+        GQ2_BLOCK(GA, 0, GA, 1, st0) GQ2_BLOCK(GA, 1, GA, 2, st0 + 4u) GQ2_BLOCK(GA, 2, GA, 3, st0 + 8u)
+        GQ2_BLOCK(GA, 3, GB, 0, st0 + 12u)
+        gq2_load_g<R>(GA, rg, gvo, (uint32_t)((sc + 2 * more) * 128));   // last trip: re-loads its own first chunk (unused)
+        GQ2_BLOCK(GB, 0, GB, 1, st0 + 16u) GQ2_BLOCK(GB, 1, GB, 2, st0 + 20u) GQ2_BLOCK(GB, 2, GB, 3, st0 + 24u)
+        GQ2_BLOCK(GB, 3, GA, 0, st0 + 28u)
     }
 #undef GQ2_BLOCK
 #undef GQ2_PHASE
@@ -434,9 +468,13 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
     float csum = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
-    for (; u + 4 <= u_end; u += 4) gq2_group<4>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane);
-    if (u + 2 <= u_end) { gq2_group<2>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 2; }
-    if (u + 1 <= u_end) { gq2_group<1>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 1; }
+    // byte (4 two-bit codes) -> 4 int8 bytes: 256-entry table in LDS; the spread then costs 2 VALU + 1 ds_read per dword
+    __shared__ unsigned lut[256];
+    lut[threadIdx.x] = (unsigned)spread4(threadIdx.x, 0);
+    __syncthreads();
+    for (; u + 4 <= u_end; u += 4) gq2_group<4>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane, lut);
+    if (u + 2 <= u_end) { gq2_group<2>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane, lut); u += 2; }
+    if (u + 1 <= u_end) { gq2_group<1>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane, lut); u += 1; }
     const float o = csum + __shfl_xor(csum, 32);
     if (h == 0) cpart[wave * 32 + c] = o;
 }
@@ -453,27 +491,47 @@ void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan
 // cover 128 adjacent bytes of every row.  Four rows are OR-ed into a dword, and operand t is (x >> 2t) & 0x03030303.
 struct Gtt2Buf { unsigned g[16]; i32x4 t[kDigits]; };
 
+// (one-byte loads made the address unit the bottleneck -- 16 buffer_load_ubyte per 32-row block cost ~2700 cycles;
+//  lanes 4j..4j+3 now load the same dword and each extracts its byte)
 __device__ __forceinline__ void gtt2_load(Gtt2Buf& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off, uint32_t ld2,
                                           __amdgpu_buffer_rsrc_t rt, uint32_t tvo, uint32_t toff) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rg, gvo, row_off + (uint32_t)i * ld2, 0);
+    for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ld2, 0);
 #pragma unroll
     for (int d = 0; d < kDigits; ++d) b.t[d] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, toff + d * 1024, 0);
 }
-__device__ __forceinline__ void gtt2_compute(const Gtt2Buf& b, i32x16 (&acc)[4][kDigits]) {
+struct Gtt2Ops { i32x4 bt[4]; };
+__device__ __forceinline__ unsigned gtt2_quad(const Gtt2Buf& b, int w, unsigned bsh) {
+    // this lane's byte (bit offset bsh = 8 * (c & 3)) of rows 4w..4w+3 -> one dword
+    return ((b.g[4 * w] >> bsh) & 0xffu) | (((b.g[4 * w + 1] >> bsh) & 0xffu) << 8) |
+           (((b.g[4 * w + 2] >> bsh) & 0xffu) << 16) | ((b.g[4 * w + 3] >> bsh) << 24);
+}
+__device__ __forceinline__ void gtt2_decode(const Gtt2Buf& b, Gtt2Ops& o, unsigned bsh) {
     unsigned x[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-        x[w] = (b.g[4 * w] & 0xffu) | ((b.g[4 * w + 1] & 0xffu) << 8) | ((b.g[4 * w + 2] & 0xffu) << 16) | (b.g[4 * w + 3] << 24);
-    i32x4 bt[4];
+    for (int w = 0; w < 4; ++w) x[w] = gtt2_quad(b, w, bsh);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) bt[t][w] = (int)((x[w] >> (2 * t)) & 0x03030303u);
+        for (int w = 0; w < 4; ++w) o.bt[t][w] = (int)((x[w] >> (2 * t)) & 0x03030303u);
+}
+// 16 int8 MFMAs of block k, each followed by one of 16 micro-steps of block k+1's decode (per row quad w: combine 4 byte
+// loads into a dword, then the four shift/mask operands); sched_barrier(0) pins the interleave.
+__device__ __forceinline__ void gtt2_mfma_decode(const Gtt2Buf& b, const Gtt2Ops& o, i32x16 (&acc)[4][kDigits],
+                                                 const Gtt2Buf& bn, Gtt2Ops& on, unsigned bsh) {
+    unsigned x[4];
 #pragma unroll
     for (int d = 0; d < kDigits; ++d)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.t[d], bt[t], acc[t][d], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.t[d], o.bt[t], acc[t][d], 0, 0, 0);
+            const int m = d * 4 + t, w = m >> 2, ph = m & 3;
+            if (ph == 0) x[w] = gtt2_quad(bn, w, bsh);
+            if (ph == 1) { on.bt[0][w] = (int)(x[w] & 0x03030303u); on.bt[1][w] = (int)((x[w] >> 2) & 0x03030303u); }
+            if (ph == 2) on.bt[2][w] = (int)((x[w] >> 4) & 0x03030303u);
+            if (ph == 3) on.bt[3][w] = (int)((x[w] >> 6) & 0x03030303u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 }
 
 __global__ __launch_bounds__(256, 1) void k_gtt_2bit(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Mpad, int64_t Npad,
@@ -499,18 +557,23 @@ __global__ __launch_bounds__(256, 1) void k_gtt_2bit(const uint8_t* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
 
-    const uint32_t gvo = (uint32_t)(16 * h * ld2 + c);
+    const uint32_t gvo = (uint32_t)(16 * h * ld2 + (c & ~3));   // the dword holding this lane's byte
+    const unsigned bsh = 8u * (unsigned)(c & 3);
     const uint32_t tvo = (uint32_t)(lane * 16);
     constexpr uint32_t TKB = kDigits * 1024;
     const uint8_t* gp = G2 + m_begin * ld2 + (n0 >> 2);
     const int8_t* tp = Td + (m_begin >> 5) * TKB;
     Gtt2Buf B0, B1, B2, B3;
+    Gtt2Ops OA, OB;
     {
         const __amdgpu_buffer_rsrc_t rg0 = make_rsrc8(gp), rt0 = make_rsrc8(tp);
         gtt2_load(B0, rg0, gvo, 0u, (uint32_t)ld2, rt0, tvo, 0u);
         gtt2_load(B1, rg0, gvo, 32u * (uint32_t)ld2, (uint32_t)ld2, rt0, tvo, TKB);
         gtt2_load(B2, rg0, gvo, 64u * (uint32_t)ld2, (uint32_t)ld2, rt0, tvo, 2 * TKB);
     }
+    gtt2_decode(B0, OA, bsh);
+    // phase k: load block k+3; the 16 int8 MFMAs of block k and the decode (OR + shift/mask, VALU) of block k+1 share one
+    // scheduling region so that they interleave; operand sets alternate OA / OB
     for (int64_t kb = 0; kb < kblocks; kb += 4) {
         const __amdgpu_buffer_rsrc_t rg = make_rsrc8(gp + kb * 32 * ld2);
         const __amdgpu_buffer_rsrc_t rt = make_rsrc8(tp + kb * TKB);
@@ -518,19 +581,19 @@ __global__ __launch_bounds__(256, 1) void k_gtt_2bit(const uint8_t* __restrict__
         const uint32_t L32 = 32u * (uint32_t)ld2;
         gtt2_load(B3, rg, gvo, 3u * L32, (uint32_t)ld2, rt, tvo, 3 * TKB);
         __builtin_amdgcn_sched_barrier(0);
-        gtt2_compute(B0, acc);
+        gtt2_mfma_decode(B0, OA, acc, B1, OB, bsh);
         __builtin_amdgcn_sched_barrier(0);
         gtt2_load(B0, rg, gvo, 4u * L32 * more, (uint32_t)ld2, rt, tvo, 4 * TKB * more);
         __builtin_amdgcn_sched_barrier(0);
-        gtt2_compute(B1, acc);
+        gtt2_mfma_decode(B1, OB, acc, B2, OA, bsh);
         __builtin_amdgcn_sched_barrier(0);
         gtt2_load(B1, rg, gvo, (4u * more + 1u) * L32, (uint32_t)ld2, rt, tvo, (4 * more + 1) * TKB);
         __builtin_amdgcn_sched_barrier(0);
-        gtt2_compute(B2, acc);
+        gtt2_mfma_decode(B2, OA, acc, B3, OB, bsh);
         __builtin_amdgcn_sched_barrier(0);
         gtt2_load(B2, rg, gvo, (4u * more + 2u) * L32, (uint32_t)ld2, rt, tvo, (4 * more + 2) * TKB);
         __builtin_amdgcn_sched_barrier(0);
-        gtt2_compute(B3, acc);
+        gtt2_mfma_decode(B3, OB, acc, B0, OA, bsh);
         __builtin_amdgcn_sched_barrier(0);
     }
     double* yp = Ypart + (wchunk * Npad) * 32;
