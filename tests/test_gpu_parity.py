@@ -584,3 +584,25 @@ def test_2bit_requires_exact_integer_path(gpca):
     from genomic_pca_amd import _lib
     with pytest.raises(gpca.GpcaError):
         gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA, storage=_lib.STORE_2BIT)
+
+
+# ------------------------------------------------------------------------------------------------
+# wide sample axis (N ~ 5e4, BASELINE configs[3] shape class): all three GEMM paths against the oracle
+# ------------------------------------------------------------------------------------------------
+def test_wide_sample_axis_all_paths(gpca, oracle):
+    from genomic_pca_amd import _lib
+    M, N, P, k = 6000, 50_000, 12, 8
+    th = gpca.synth_thresholds(M, P, seed=19, fst=0.2)
+    G = oracle.synth_genotypes(M, N, 19, th)
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=4)
+    for prec, store in ((_lib.PREC_F32_MFMA, _lib.STORE_INT8), (_lib.PREC_I8_EXACT, _lib.STORE_INT8), (_lib.PREC_I8_EXACT, _lib.STORE_2BIT)):
+        with gpca.GpcaEngine(precision=prec, storage=store) as e:
+            e.upload_genotypes_i8(G)
+            s2 = e.snp_stats(gpca.QcConfig.none())
+            assert np.array_equal(s2["mu"], st["mu"]) and np.array_equal(s2["keep"], st["keep"])
+            e.rsvd(k, 10, 2, seed=4)
+            assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+            assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
+            assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]) < TOL_PC
