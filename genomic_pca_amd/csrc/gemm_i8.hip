@@ -617,6 +617,179 @@ void launch_gtt_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpa
                        plan.rows_per_wave);
 }
 
+// ================================================================================================
+// K2 with the digit planes of T' shared through LDS (int8-resident and packed genotypes).
+// The four waves of a workgroup own four adjacent 128-sample blocks and the SAME row range, so they consume the
+// same planes.  Wave w fetches plane d = w (1 KiB per 32-row block) into registers and writes it to a double-buffered
+// LDS stage of 4 blocks (16 KiB); everyone reads its operands back with conflict-free ds_read_b128.  L2 -> CU traffic
+// for the planes drops 4x (it equalled the int8 genotype traffic and was 4x the packed one).  One barrier per stage.
+// ================================================================================================
+template <bool PACKED>
+struct GttXG { unsigned g[16]; };
+
+template <bool PACKED>
+__device__ __forceinline__ void gttx_load_g(GttXG<PACKED>& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off, uint32_t ldr) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ldr, 0);
+}
+// decode micro-step m (0..15) of the next block's operands
+template <bool PACKED>
+__device__ __forceinline__ void gttx_decode_step(const GttXG<PACKED>& bn, Gtt2Ops& on, unsigned (&x)[4], unsigned (&y)[4], int m, unsigned bsh) {
+    const int w = m >> 2, ph = m & 3;
+    if (PACKED) {
+        if (ph == 0) x[w] = ((bn.g[4 * w] >> bsh) & 0xffu) | (((bn.g[4 * w + 1] >> bsh) & 0xffu) << 8) |
+                            (((bn.g[4 * w + 2] >> bsh) & 0xffu) << 16) | ((bn.g[4 * w + 3] >> bsh) << 24);
+        if (ph == 1) { on.bt[0][w] = (int)(x[w] & 0x03030303u); on.bt[1][w] = (int)((x[w] >> 2) & 0x03030303u); }
+        if (ph == 2) on.bt[2][w] = (int)((x[w] >> 4) & 0x03030303u);
+        if (ph == 3) on.bt[3][w] = (int)((x[w] >> 6) & 0x03030303u);
+    } else {   // 4x4 byte transpose of rows 4w..4w+3 (two v_perm stages)
+        const int r0 = (int)bn.g[4 * w], r1 = (int)bn.g[4 * w + 1], r2 = (int)bn.g[4 * w + 2], r3 = (int)bn.g[4 * w + 3];
+        if (ph == 0) { x[w] = (unsigned)permb(r1, r0, 0x05010400u); y[w] = (unsigned)permb(r1, r0, 0x07030602u); }
+        if (ph == 1) { x[w] = x[w]; }
+        if (ph == 2) {
+            const int y0 = permb(r3, r2, 0x05010400u);
+            on.bt[0][w] = permb(y0, (int)x[w], 0x05040100u); on.bt[1][w] = permb(y0, (int)x[w], 0x07060302u);
+        }
+        if (ph == 3) {
+            const int y1 = permb(r3, r2, 0x07030602u);
+            on.bt[2][w] = permb(y1, (int)y[w], 0x05040100u); on.bt[3][w] = permb(y1, (int)y[w], 0x07060302u);
+        }
+    }
+}
+template <bool PACKED>
+__device__ __forceinline__ void gttx_decode(const GttXG<PACKED>& b, Gtt2Ops& o, unsigned bsh) {
+    unsigned x[4], y[4];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) gttx_decode_step<PACKED>(b, o, x, y, m, bsh);
+}
+struct GttXT { i32x4 t[kDigits]; };
+// the 16 MFMAs of the current block; after each one a micro-step of the next block's decode, and (first four slots) the
+// LDS reads of the next block's digit operands
+template <bool PACKED>
+__device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i32x16 (&acc)[4][kDigits],
+                                           const GttXG<PACKED>& gn, Gtt2Ops& on, GttXT& tn, const i32x4* lds_next, unsigned bsh) {
+    unsigned x[4], y[4];
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tc.t[d], oc.bt[t], acc[t][d], 0, 0, 0);
+            const int m = d * 4 + t;
+            if (m < kDigits) tn.t[m] = lds_next[m * 64];
+            gttx_decode_step<PACKED>(gn, on, x, y, m, bsh);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 1) void k_gtt_x(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Mpad, int64_t Npad,
+                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
+                                                   int64_t ngroups, int64_t rows_per_wave) {
+    __shared__ i32x4 tds[2][4][kDigits][64];   // [slot][block in stage][plane][lane]: 2 x 16 KiB
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ngroup = blockIdx.x % ngroups;
+    const int64_t wchunk = blockIdx.x / ngroups;
+    const int64_t nblock = ngroup * 4 + wv;
+    int64_t n0 = nblock * 128;
+    const bool live = n0 < Npad;          // a dead wave (ragged last group) still loads planes and joins the barriers
+    if (!live) n0 = 0;
+    const int64_t m_begin = wchunk * rows_per_wave;
+    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
+    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
+    const int64_t nstage = kblocks >> 2;
+
+    i32x16 acc[4][kDigits];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    const uint32_t gvo = PACKED ? (uint32_t)(16 * h * ldr + (c & ~3)) : (uint32_t)(16 * h * ldr + 4 * c);
+    const unsigned bsh = 8u * (unsigned)(c & 3);
+    const uint8_t* gp = Gb + m_begin * ldr + (PACKED ? (n0 >> 2) : n0);
+    constexpr uint32_t TKB = kDigits * 1024;
+    const int8_t* tp = Td + (m_begin >> 5) * TKB + wv * 1024;    // this wave's plane
+    const uint32_t tvo = (uint32_t)(lane * 16);
+    const uint32_t L32 = 32u * (uint32_t)ldr;
+
+    GttXG<PACKED> B0, B1, B2, B3;
+    Gtt2Ops OA, OB;
+    GttXT TA, TB;
+    i32x4 PL0[4], PL1[4];     // plane w of stages s+1 / s+2 on their way to LDS
+    {
+        const __amdgpu_buffer_rsrc_t rg0 = make_rsrc8(gp), rt0 = make_rsrc8(tp);
+        gttx_load_g<PACKED>(B0, rg0, gvo, 0u, (uint32_t)ldr);
+        gttx_load_g<PACKED>(B1, rg0, gvo, L32, (uint32_t)ldr);
+        gttx_load_g<PACKED>(B2, rg0, gvo, 2u * L32, (uint32_t)ldr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PL0[j] = __builtin_amdgcn_raw_buffer_load_b128(rt0, tvo, j * TKB, 0);             // stage 0
+        const uint32_t s1 = nstage > 1 ? 4u : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rt0, tvo, (s1 + j) * TKB, 0);      // stage 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tds[0][j][wv][lane] = PL0[j];
+    }
+    __syncthreads();
+    gttx_decode<PACKED>(B0, OA, bsh);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) TA.t[d] = tds[0][0][d][lane];
+
+    for (int64_t st = 0; st < nstage; ++st) {
+        const int slot = (int)(st & 1);
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc8(gp + st * 128 * ldr);
+        const __amdgpu_buffer_rsrc_t rt = make_rsrc8(tp + st * 4 * TKB);
+        const uint32_t more = (st + 1 < nstage) ? 1u : 0u;
+        // planes: stage st+1 (in PL1) -> LDS slot^1 ; fetch stage st+2 into PL0 (then swap roles by copy)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tds[slot ^ 1][j][wv][lane] = PL1[j];
+        const uint32_t s2 = (st + 2 < nstage) ? 8u : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, (s2 + j) * TKB, 0);
+        const i32x4* cur = &tds[slot][0][0][lane];
+        const i32x4* nxt = &tds[slot ^ 1][0][0][lane];
+        // block 0 of the stage (operands TA/OA ready); next = block 1
+        gttx_load_g<PACKED>(B3, rg, gvo, 3u * L32, (uint32_t)ldr);
+        __builtin_amdgcn_sched_barrier(0);
+        gttx_phase<PACKED>(TA, OA, acc, B1, OB, TB, cur + 1 * kDigits * 64, bsh);
+        gttx_load_g<PACKED>(B0, rg, gvo, 4u * L32 * more, (uint32_t)ldr);
+        __builtin_amdgcn_sched_barrier(0);
+        gttx_phase<PACKED>(TB, OB, acc, B2, OA, TA, cur + 2 * kDigits * 64, bsh);
+        gttx_load_g<PACKED>(B1, rg, gvo, (4u * more + 1u) * L32, (uint32_t)ldr);
+        __builtin_amdgcn_sched_barrier(0);
+        gttx_phase<PACKED>(TA, OA, acc, B3, OB, TB, cur + 3 * kDigits * 64, bsh);
+        gttx_load_g<PACKED>(B2, rg, gvo, (4u * more + 2u) * L32, (uint32_t)ldr);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();     // stage st+1 is in LDS slot^1 for everyone; slot may be overwritten next trip after its last reads below
+        gttx_phase<PACKED>(TB, OB, acc, B0, OA, TA, nxt, bsh);   // block 3; prefetches block 0 of the next stage from slot^1
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!live) return;
+    double* yp = Ypart + (wchunk * Npad) * 32;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t n = n0 + 4 * c + t;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
+            double2 o;
+            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
+            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
+        }
+    }
+}
+
+void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const int8_t* Td,
+                  double* Ypart, const Gtt8Plan& plan) {
+    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    const dim3 grid((unsigned)plan.grid), blk(256);
+    if (packed) hipLaunchKernelGGL((k_gtt_x<true>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+    else hipLaunchKernelGGL((k_gtt_x<false>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Quantisation of the skinny operand: column abs-max -> scale; X[rows][32] -> digit planes
 // blocked [block = row/32][d][lane = 32*((row%32)/16) + col][j = row%16] (16 B per lane per plane).

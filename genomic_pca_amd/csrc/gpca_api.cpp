@@ -92,6 +92,7 @@ struct gpca_handle {
     int8_t *dQd = nullptr, *dTd = nullptr;
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
+    int lds_planes = 1;   // share the digit planes of the exact GEMMs through LDS (GPCA_LDS_PLANES=0 disables)
     int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
 
     // comm
@@ -193,6 +194,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     // tuning knobs (resident-wave targets of the two GEMM grids); defaults are the tuned values
     if (const char* e = getenv("GPCA_GQ_WAVES")) h->gq_waves_target = std::max(4, atoi(e));
     if (const char* e = getenv("GPCA_GTT_WAVES")) h->gtt_waves_target = std::max(4, atoi(e));
+    if (const char* e = getenv("GPCA_LDS_PLANES")) h->lds_planes = atoi(e);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
         delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
     }
@@ -669,7 +671,9 @@ static int stage_AtT(gpca_handle* h) {
         HIPCHK(hipGetLastError());
         {
             ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT) launch_gtt_2bit(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+            if (h->lds_planes) launch_gtt_x(h->st, h->storage == GPCA_STORE_2BIT ? (const void*)h->dG2 : (const void*)h->dG, h->storage == GPCA_STORE_2BIT,
+                                            h->storage == GPCA_STORE_2BIT ? h->ld2 : h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+            else if (h->storage == GPCA_STORE_2BIT) launch_gtt_2bit(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
             else launch_gtt_i8(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
         }
         HIPCHK(hipGetLastError());
