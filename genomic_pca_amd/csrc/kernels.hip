@@ -396,47 +396,77 @@ void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int6
     launch_sum_partials_t<double>(st, part, P, E, out, scratch);
 }
 
-// Gram: part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c]  (f64 accumulate)
-constexpr int kGramRowsPerBlock = 512;
-int64_t gram_num_parts(int64_t rows) { return (rows + kGramRowsPerBlock - 1) / kGramRowsPerBlock; }
+// Gram: part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c]  (f64 accumulate).
+// 256 threads = 4 row-groups x 64 threads; a thread owns a 4x4 (L=32) or 8x8 (L=64) patch of the L x L output and walks
+// every 4th row of the tile (8 LDS reads per 16 FMAs); the four row-groups are combined through LDS at the end.
+// Rows per block adapt to the problem so that ~1024 blocks are in flight (N = 10^4 used to get 20 blocks).
+static int64_t gram_rows_per_block(int64_t rows) {
+    int64_t r = (rows + 1023) / 1024;
+    r = (r + 31) / 32 * 32;
+    return r < 32 ? 32 : (r > 2048 ? 2048 : r);
+}
+int64_t gram_num_parts(int64_t rows) { const int64_t rpb = gram_rows_per_block(rows); return (rows + rpb - 1) / rpb; }
 
 template <typename T, int L>
-__global__ __launch_bounds__(256) void k_gram(const T* __restrict__ X, int64_t rows, double* __restrict__ part) {
-    constexpr int TPR = 256 / L;   // threads per output row a
-    constexpr int CPT = L / TPR;   // output columns per thread
+__global__ __launch_bounds__(256) void k_gram(const T* __restrict__ X, int64_t rows, int64_t rpb, double* __restrict__ part) {
+    constexpr int P = L / 8;                 // patch edge: 4 (L=32) or 8 (L=64); 8 x 8 patches cover L x L with 64 threads
     __shared__ double tile[32][L + 1];
-    const int a = threadIdx.x / TPR, c0 = (threadIdx.x % TPR) * CPT;
-    double acc[CPT];
+    __shared__ double red[3][64][P * P];
+    const int tg = threadIdx.x & 63, rgp = threadIdx.x >> 6;
+    const int a0 = (tg >> 3) * P, c0 = (tg & 7) * P;
+    double acc[P][P];
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) acc[k] = 0.0;
-    const int64_t r0 = (int64_t)blockIdx.x * kGramRowsPerBlock;
-    const int64_t r1 = (r0 + kGramRowsPerBlock < rows) ? r0 + kGramRowsPerBlock : rows;
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < P; ++j) acc[i][j] = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
     for (int64_t rb = r0; rb < r1; rb += 32) {
         for (int e = threadIdx.x; e < 32 * L; e += 256) {
             const int rr = e / L, cc = e % L;
             tile[rr][cc] = (rb + rr < r1) ? (double)X[(rb + rr) * L + cc] : 0.0;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int rr = 0; rr < 32; ++rr) {
-            const double xa = tile[rr][a];
+#pragma unroll 2
+        for (int rr = rgp; rr < 32; rr += 4) {
+            double xa[P], xc[P];
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) acc[k] += xa * tile[rr][c0 + k];
+            for (int i = 0; i < P; ++i) { xa[i] = tile[rr][a0 + i]; xc[i] = tile[rr][c0 + i]; }
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int j = 0; j < P; ++j) acc[i][j] += xa[i] * xc[j];
         }
         __syncthreads();
     }
+    if (rgp > 0) {
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) part[(int64_t)blockIdx.x * L * L + a * L + c0 + k] = acc[k];
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j) red[rgp - 1][tg][i * P + j] = acc[i][j];
+    }
+    __syncthreads();
+    if (rgp == 0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const double v = ((acc[i][j] + red[0][tg][i * P + j]) + red[1][tg][i * P + j]) + red[2][tg][i * P + j];
+                part[(int64_t)blockIdx.x * L * L + (a0 + i) * L + c0 + j] = v;
+            }
+    }
 }
 void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part) {
+    const int64_t rpb = gram_rows_per_block(rows);
     const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
-    if (L == 32) hipLaunchKernelGGL((k_gram<double, 32>), grid, blk, 0, st, X, rows, part);
-    else hipLaunchKernelGGL((k_gram<double, 64>), grid, blk, 0, st, X, rows, part);
+    if (L == 32) hipLaunchKernelGGL((k_gram<double, 32>), grid, blk, 0, st, X, rows, rpb, part);
+    else hipLaunchKernelGGL((k_gram<double, 64>), grid, blk, 0, st, X, rows, rpb, part);
 }
 void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part) {
+    const int64_t rpb = gram_rows_per_block(rows);
     const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
-    if (L == 32) hipLaunchKernelGGL((k_gram<float, 32>), grid, blk, 0, st, X, rows, part);
-    else hipLaunchKernelGGL((k_gram<float, 64>), grid, blk, 0, st, X, rows, part);
+    if (L == 32) hipLaunchKernelGGL((k_gram<float, 32>), grid, blk, 0, st, X, rows, rpb, part);
+    else hipLaunchKernelGGL((k_gram<float, 64>), grid, blk, 0, st, X, rows, rpb, part);
 }
 
 // X[n][:] <- X[n][:] Z, in place through an LDS row tile; optional f32 copy into Qout (pad rows zeroed)
@@ -464,36 +494,39 @@ void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, 
     else hipLaunchKernelGGL((k_apply_right<64>), dim3((unsigned)((span + 3) / 4)), dim3(256), 0, st, X, rows, Z, Qout, rows_pad);
 }
 
-// out[n][kc] = sum_j X[row(n)][j] Z[j][kc];  one thread per output element
+// out[n][kc] = sum_j X[row(n)][j] Z[j][kc].  A quarter-wave (16 lanes) owns one row: lane q loads elements q, q+16, ...
+// (coalesced 64-byte pieces), the row is exchanged through LDS, and each lane produces outputs kc = q, q+16, ...
 template <typename TX>
 __global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, const int64_t* __restrict__ row_ids,
                                                   int64_t nrows, int L, const double* __restrict__ Z, int K,
                                                   double* __restrict__ out64, float* __restrict__ out32) {
-    extern __shared__ double zsm[];
+    extern __shared__ double zsm[];          // Z [L][K], then 16 rows x L doubles
+    double* xrow = zsm + L * K;
     for (int e = threadIdx.x; e < L * K; e += 256) zsm[e] = Z[e];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int64_t n = (int64_t)blockIdx.x * 16 + rl;
+    if (n < nrows) {
+        const int64_t src = row_ids ? row_ids[n] : n;
+        for (int j = q; j < L; j += 16) xrow[rl * L + j] = (double)X[src * L + j];
+    }
     __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= nrows * K) return;
-    const int64_t n = t / K;
-    const int kc = (int)(t - n * K);
-    const int64_t src = row_ids ? row_ids[n] : n;
-    const TX* x = X + src * L;
-    double a = 0.0;
-    for (int j = 0; j < L; ++j) a += (double)x[j] * zsm[j * K + kc];
-    if (out64) out64[t] = a;
-    if (out32) out32[t] = (float)a;
+    if (n >= nrows) return;
+    for (int kc = q; kc < K; kc += 16) {
+        double a = 0.0;
+        for (int j = 0; j < L; ++j) a += xrow[rl * L + j] * zsm[j * K + kc];
+        if (out64) out64[n * K + kc] = a;
+        if (out32) out32[n * K + kc] = (float)a;
+    }
 }
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
                          float* out32) {
-    const int64_t total = rows * K;
-    hipLaunchKernelGGL((k_rightmul<double>), dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X,
+    hipLaunchKernelGGL((k_rightmul<double>), dim3((unsigned)((rows + 15) / 16)), dim3(256), sizeof(double) * (L * K + 16 * L), st, X,
                        (const int64_t*)nullptr, rows, L, Z, K, out64, out32);
 }
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
                                 const double* Z, int K, float* out32) {
-    const int64_t total = nrows * K;
-    if (total == 0) return;
-    hipLaunchKernelGGL((k_rightmul<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * L * K, st, X, row_ids,
+    if (nrows == 0) return;
+    hipLaunchKernelGGL((k_rightmul<float>), dim3((unsigned)((nrows + 15) / 16)), dim3(256), sizeof(double) * (L * K + 16 * L), st, X, row_ids,
                        nrows, L, Z, K, (double*)nullptr, out32);
 }
 
