@@ -618,6 +618,152 @@ void launch_gtt_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpa
 }
 
 // ================================================================================================
+// K1 with the digit planes of Q shared through LDS (int8-resident genotypes).
+// A workgroup owns a contiguous range of 32-row units and walks it in rounds of 4 waves x R tiles; inside a round all
+// four waves sweep the sample axis together, so one fetch of the planes serves the workgroup: wave w brings plane
+// d = w of each 128-sample stage (4 MFMA steps, 16 KiB) into a double-buffered LDS slot, everyone reads its operands
+// back with ds_read_b128.  Tiles past the end of the range recompute a valid tile and skip the store.
+// ================================================================================================
+template <int R>
+__device__ __forceinline__ void gqx_phase(const i32x4 (&g)[R], const Gq8Q& qc, i32x16 (&acc)[R][kDigits], Gq8Q& qn,
+                                          const i32x4* lds_next) {
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) {
+        qn.q[d] = lds_next[d * 64];
+#pragma unroll
+        for (int t = 0; t < R; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(g[t], qc.q[d], acc[t][d], 0, 0, 0);
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
+                                          const int8_t* __restrict__ Qd, i32x4 (*tds)[4][kDigits][64], int wv, int lane, int c,
+                                          int h, int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          float& csum) {
+    const int64_t row0 = unit0 * 32;
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
+    uint32_t gvo[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)(((t < nvalid ? 32 * t : 0) + c) * ldg + 16 * h);
+    constexpr uint32_t QCH = kDigits * 1024;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd + wv * 1024);    // this wave's plane
+    const uint32_t qvo = (uint32_t)(lane * 16);
+
+    i32x16 acc[R][kDigits];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    Gq8G<R> GA, GB;
+    Gq8Q QA, QB;
+    i32x4 PL0[4], PL1[4];
+    gq8_load_g<R, 0>(GA, rg, gvo, 0u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) PL0[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, j * QCH, 0);
+    {
+        const uint32_t s1 = nstage > 1 ? 4u : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (s1 + j) * QCH, 0);
+    }
+    __syncthreads();                       // the previous round's last LDS reads are done
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tds[0][j][wv][lane] = PL0[j];
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) QA.q[d] = tds[0][0][d][lane];
+
+#define GQX_STAGE(GCUR, GNXT, ST, SLOT)                                                                  \
+    {                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) tds[(SLOT) ^ 1][j][wv][lane] = PL1[j];             \
+        const uint32_t s2_ = ((ST) + 2 < nstage) ? (uint32_t)((ST) + 2) : 0u;                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+            PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (s2_ * 4u + j) * QCH, 0);            \
+        const uint32_t g1_ = ((ST) + 1 < nstage) ? (uint32_t)((ST) + 1) : 0u;                            \
+        gq8_load_g<R, 0>(GNXT, rg, gvo, g1_ * 128u);                                                     \
+        const i32x4* cur_ = &tds[(SLOT)][0][0][lane];                                                    \
+        const i32x4* nxt_ = &tds[(SLOT) ^ 1][0][0][lane];                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gqx_phase<R>(GCUR.g[0], QA, acc, QB, cur_ + 1 * kDigits * 64);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gqx_phase<R>(GCUR.g[1], QB, acc, QA, cur_ + 2 * kDigits * 64);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gqx_phase<R>(GCUR.g[2], QA, acc, QB, cur_ + 3 * kDigits * 64);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        __syncthreads();                                                                                 \
+        gqx_phase<R>(GCUR.g[3], QB, acc, QA, nxt_);                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    }
+    for (int64_t st = 0; st < nstage; st += 2) {     // nstage (128-sample stages) is even
+        GQX_STAGE(GA, GB, st, 0)
+        GQX_STAGE(GB, GA, st + 1, 1)
+    }
+#undef GQX_STAGE
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        if (t < nvalid) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float ri = rv[row], bi = bv[row];
+                const float gq = (float)(combine_digits(acc[t], e) * qs);
+                const float tv = ri * gq + bi * sj;
+                csum += bi * tv;
+                Tout[row * 32 + c] = scale_out ? ri * tv : tv;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nstage,
+                                                  const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
+                                                  const float* __restrict__ rv, const float* __restrict__ bv,
+                                                  const float* __restrict__ sv, float* __restrict__ Tout,
+                                                  float* __restrict__ cpart, int scale_out) {
+    __shared__ i32x4 tds[2][4][kDigits][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
+    const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
+    float csum = 0.f;
+    const float sj = sv[c];
+    const double qs = qscale[c];
+    int64_t u = u0;
+    while (u < u1) {
+        const int64_t rem = u1 - u;
+        if (rem > 8) {           // 4 tiles per wave
+            const int64_t mine = u + 4 * wv;
+            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
+            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum);
+            u += 16;
+        } else if (rem > 4) {    // 2 tiles per wave
+            const int64_t mine = u + 2 * wv;
+            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
+            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum);
+            u += 8;
+        } else {                 // 1 tile per wave
+            const int64_t mine = u + wv;
+            const int nv = mine < u1 ? 1 : 0;
+            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum);
+            u += 4;
+        }
+    }
+    const float o = csum + __shfl_xor(csum, 32);
+    if (h == 0) cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o;
+}
+
+void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, int scale_out) {
+    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
+    const int64_t nstage = Npad / 128;    // Npad is a multiple of 256 -> even
+    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, scale_out);
+}
+
+// ================================================================================================
 // K2 with the digit planes of T' shared through LDS (int8-resident and packed genotypes).
 // The four waves of a workgroup own four adjacent 128-sample blocks and the SAME row range, so they consume the
 // same planes.  Wave w fetches plane d = w (1 KiB per 32-row block) into registers and writes it to a double-buffered

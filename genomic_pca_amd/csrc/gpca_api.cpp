@@ -698,6 +698,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
         {
             ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
             if (h->storage == GPCA_STORE_2BIT) launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+            else if (h->lds_planes) launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
             else launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
         }
         HIPCHK(hipGetLastError());
