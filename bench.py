@@ -163,7 +163,7 @@ def main():
         sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run (also with one rank: same code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -196,7 +196,7 @@ def main():
         eng.snp_stats(g.QcConfig.none(), fetch=False)
         if t_stats is None:
             t_stats = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
             eng.comm_init(world, rank, uid, snp_offset)
         dt, timings = timed_run(eng, a, k, barrier, dist, torch)
