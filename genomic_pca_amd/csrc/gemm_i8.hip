@@ -388,7 +388,7 @@ template <int R>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
-                                          float& csum, int64_t row0, int c, int h, int lane, const unsigned* lut) {
+                                          float& csum, float& amax, int64_t row0, int c, int h, int lane, const unsigned* lut) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
     uint32_t gvo[R];
 #pragma unroll
@@ -448,7 +448,9 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
             const float gq = (float)(combine_digits(acc[t], e) * qs);
             const float tv = ri * gq + bi * sj;
             csum += bi * tv;
-            Tout[row * 32 + c] = scale_out ? ri * tv : tv;
+            const float ov = scale_out ? ri * tv : tv;
+            amax = fmaxf(amax, fabsf(ov));
+            Tout[row * 32 + c] = ov;
         }
     }
 }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
                                                      const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                      const float* __restrict__ rv, const float* __restrict__ bv,
                                                      const float* __restrict__ sv, float* __restrict__ Tout,
-                                                     float* __restrict__ cpart, int scale_out) {
+                                                     float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -465,26 +467,27 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
     const int64_t waves = (int64_t)gridDim.x * 4;
     int64_t u = (units * wave) / waves;
     const int64_t u_end = (units * (wave + 1)) / waves;
-    float csum = 0.f;
+    float csum = 0.f, amax = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
     // byte (4 two-bit codes) -> 4 int8 bytes: 256-entry table in LDS; the spread then costs 2 VALU + 1 ds_read per dword
     __shared__ unsigned lut[256];
     lut[threadIdx.x] = (unsigned)spread4(threadIdx.x, 0);
     __syncthreads();
-    for (; u + 4 <= u_end; u += 4) gq2_group<4>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane, lut);
-    if (u + 2 <= u_end) { gq2_group<2>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane, lut); u += 2; }
-    if (u + 1 <= u_end) { gq2_group<1>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane, lut); u += 1; }
+    for (; u + 4 <= u_end; u += 4) gq2_group<4>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut);
+    if (u + 2 <= u_end) { gq2_group<2>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 2; }
+    if (u + 1 <= u_end) { gq2_group<1>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 1; }
     const float o = csum + __shfl_xor(csum, 32);
-    if (h == 0) cpart[wave * 32 + c] = o;
+    const float am = fmaxf(amax, __shfl_xor(amax, 32));
+    if (h == 0) { cpart[wave * 32 + c] = o; apart[wave * 32 + c] = (double)am; }
 }
 
 void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                     const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                    int scale_out) {
+                    double* apart, int scale_out) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nsuper = Npad / 512;   // Npad is a multiple of 1024 in 2-bit mode -> even
-    hipLaunchKernelGGL(k_gq_2bit, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out);
+    hipLaunchKernelGGL(k_gq_2bit, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
 }
 
 // ---- K2, packed.  Lane (c, h) loads ONE byte (4 samples) from each of its 16 SNP rows; the four waves of a workgroup
@@ -640,7 +643,7 @@ __device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t 
                                           const int8_t* __restrict__ Qd, i32x4 (*tds)[4][kDigits][64], int wv, int lane, int c,
                                           int h, int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
-                                          float& csum) {
+                                          float& csum, float& amax) {
     const int64_t row0 = unit0 * 32;
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
     uint32_t gvo[R];
@@ -712,7 +715,9 @@ __device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t 
                 const float gq = (float)(combine_digits(acc[t], e) * qs);
                 const float tv = ri * gq + bi * sj;
                 csum += bi * tv;
-                Tout[row * 32 + c] = scale_out ? ri * tv : tv;
+                const float ov = scale_out ? ri * tv : tv;
+                amax = fmaxf(amax, fabsf(ov));
+                Tout[row * 32 + c] = ov;
             }
         }
     }
@@ -722,14 +727,14 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
-                                                  float* __restrict__ cpart, int scale_out) {
+                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
     __shared__ i32x4 tds[2][4][kDigits][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
     const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
-    float csum = 0.f;
+    float csum = 0.f, amax = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
     int64_t u = u0;
@@ -738,29 +743,31 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
         if (rem > 8) {           // 4 tiles per wave
             const int64_t mine = u + 4 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum);
+            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
             u += 16;
         } else if (rem > 4) {    // 2 tiles per wave
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum);
+            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
             u += 8;
         } else {                 // 1 tile per wave
             const int64_t mine = u + wv;
             const int nv = mine < u1 ? 1 : 0;
-            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum);
+            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
             u += 4;
         }
     }
     const float o = csum + __shfl_xor(csum, 32);
-    if (h == 0) cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o;
+    const float am = fmaxf(amax, __shfl_xor(amax, 32));   // column abs-max of this wave's output rows (for the digit scale)
+    if (h == 0) { cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o; apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am; }
 }
 
 void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
-                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, int scale_out) {
+                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
+                 int scale_out) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;    // Npad is a multiple of 256 -> even
-    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, scale_out);
+    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
 }
 
 // ================================================================================================
@@ -1014,6 +1021,13 @@ static void quantize_t(hipStream_t st, const T* X, int64_t rows, int64_t rows_pa
     hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv);
     const int64_t blocks = rows_pad / 32;
     hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout);
+}
+// abs-max partials already produced by the kernel that wrote X (K1 epilogue): finish the scale and quantise
+void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
+                                double* scale, double* inv, int8_t* Xd, int layout) {
+    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, apart, P, scale, inv);
+    const int64_t blocks = rows_pad / 32;
+    hipLaunchKernelGGL((k_quantize<float>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout);
 }
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
                          double* inv, int8_t* Xd, int layout) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout); }

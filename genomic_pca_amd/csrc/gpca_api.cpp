@@ -90,6 +90,7 @@ struct gpca_handle {
     Gtt8Plan plan8{};
     // exact-integer path
     int8_t *dQd = nullptr, *dTd = nullptr;
+    double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false;   // column abs-max partials of T' from the K1 epilogue
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
     int lds_planes = 1;   // share the digit planes of the exact GEMMs through LDS (GPCA_LDS_PLANES=0 disables)
@@ -219,7 +220,7 @@ static void free_ws(gpca_handle* h) {
     dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
     dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
-    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
+    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
     h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
     h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
     h->have_rsvd = false;
@@ -667,7 +668,9 @@ static int stage_AtT(gpca_handle* h) {
     const double elems = (double)h->M * (double)h->N;
     if (h->precision == GPCA_PREC_I8_EXACT) {
         // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64
-        launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd);
+        if (h->apart_valid) launch_quantize_f32_premax(h->st, h->dT, h->Mpad, h->Mpad, h->d_apart, h->gqplan.waves, h->d_tscale, h->d_tinv, h->dTd, 0);
+        else launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd);
+        h->apart_valid = false;
         HIPCHK(hipGetLastError());
         {
             ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
@@ -697,8 +700,8 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     if (h->precision == GPCA_PREC_I8_EXACT) {
         {
             ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT) launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
-            else if (h->lds_planes) launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            else if (h->lds_planes) { launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
             else launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
         }
         HIPCHK(hipGetLastError());
@@ -778,6 +781,7 @@ static int ensure_workspace(gpca_handle* h) {
         CHK(ensure(h, h->dQd, h->cap_Qd, (size_t)Npad * 32 * kDigits));
         CHK(ensure(h, h->dTd, h->cap_Td, (size_t)h->Mpad * 32 * kDigits));
         CHK(ensure(h, h->dYpart64, h->cap_Ypart64, (size_t)h->plan8.W * (size_t)Npad * 32));
+        CHK(ensure(h, h->d_apart, h->cap_apart, (size_t)h->gqplan.waves * 32));
         if (!h->d_qscale) {
             HIPCHK(hipMalloc((void**)&h->d_qscale, 32 * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, 32 * 8));
             HIPCHK(hipMalloc((void**)&h->d_tscale, 32 * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, 32 * 8));

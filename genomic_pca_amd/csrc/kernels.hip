@@ -494,40 +494,41 @@ void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, 
     else hipLaunchKernelGGL((k_apply_right<64>), dim3((unsigned)((span + 3) / 4)), dim3(256), 0, st, X, rows, Z, Qout, rows_pad);
 }
 
-// out[n][kc] = sum_j X[row(n)][j] Z[j][kc].  A quarter-wave (16 lanes) owns one row: lane q loads elements q, q+16, ...
-// (coalesced 64-byte pieces), the row is exchanged through LDS, and each lane produces outputs kc = q, q+16, ...
-template <typename TX>
+// out[n][kc] = sum_j X[row(n)][j] Z[j][kc].  One thread per row: the row sits in registers (L/4 16-byte loads), Z is
+// broadcast from LDS, K outputs are written as one contiguous run.  (HBM-bound: rows in, K values out.)
+template <typename TX, int L>
 __global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, const int64_t* __restrict__ row_ids,
-                                                  int64_t nrows, int L, const double* __restrict__ Z, int K,
+                                                  int64_t nrows, const double* __restrict__ Z, int K,
                                                   double* __restrict__ out64, float* __restrict__ out32) {
-    extern __shared__ double zsm[];          // Z [L][K], then 16 rows x L doubles
-    double* xrow = zsm + L * K;
+    extern __shared__ double zsm[];          // Z [L][K]
     for (int e = threadIdx.x; e < L * K; e += 256) zsm[e] = Z[e];
-    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int64_t n = (int64_t)blockIdx.x * 16 + rl;
-    if (n < nrows) {
-        const int64_t src = row_ids ? row_ids[n] : n;
-        for (int j = q; j < L; j += 16) xrow[rl * L + j] = (double)X[src * L + j];
-    }
     __syncthreads();
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= nrows) return;
-    for (int kc = q; kc < K; kc += 16) {
+    const int64_t src = row_ids ? row_ids[n] : n;
+    double x[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) x[j] = (double)X[src * L + j];
+    for (int kc = 0; kc < K; ++kc) {
         double a = 0.0;
-        for (int j = 0; j < L; ++j) a += xrow[rl * L + j] * zsm[j * K + kc];
+#pragma unroll
+        for (int j = 0; j < L; ++j) a += x[j] * zsm[j * K + kc];
         if (out64) out64[n * K + kc] = a;
         if (out32) out32[n * K + kc] = (float)a;
     }
 }
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
                          float* out32) {
-    hipLaunchKernelGGL((k_rightmul<double>), dim3((unsigned)((rows + 15) / 16)), dim3(256), sizeof(double) * (L * K + 16 * L), st, X,
-                       (const int64_t*)nullptr, rows, L, Z, K, out64, out32);
+    const dim3 grid((unsigned)((rows + 255) / 256)), blk(256);
+    if (L == 32) hipLaunchKernelGGL((k_rightmul<double, 32>), grid, blk, sizeof(double) * L * K, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
+    else hipLaunchKernelGGL((k_rightmul<double, 64>), grid, blk, sizeof(double) * L * K, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
 }
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
                                 const double* Z, int K, float* out32) {
     if (nrows == 0) return;
-    hipLaunchKernelGGL((k_rightmul<float>), dim3((unsigned)((nrows + 15) / 16)), dim3(256), sizeof(double) * (L * K + 16 * L), st, X, row_ids,
-                       nrows, L, Z, K, (double*)nullptr, out32);
+    const dim3 grid((unsigned)((nrows + 255) / 256)), blk(256);
+    if (L == 32) hipLaunchKernelGGL((k_rightmul<float, 32>), grid, blk, sizeof(double) * L * K, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
+    else hipLaunchKernelGGL((k_rightmul<float, 64>), grid, blk, sizeof(double) * L * K, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
 }
 
 constexpr int kColsumRowsPerBlock = 256;
