@@ -329,6 +329,12 @@ void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad
 // 0.25 B per genotype; the kernels become matrix-core / VALU bound.
 // ================================================================================================
 
+#ifndef GPCA_ABLATE
+#define GPCA_ABLATE 0   // scripts/kbench/kbench_gq2.hip: bit0 no decode, bit1 no Q loads, bit2 no G loads, bit3 no MFMA,
+#endif                  // bit4 clock stamps (s_memtime / s_memrealtime per workgroup into g_kbench_stamp)
+#if GPCA_ABLATE & 16
+__device__ unsigned long long g_kbench_stamp[2 * 4096];
+#endif
 // 16 samples (one 32-bit word of 2-bit codes) -> 16 int8 bytes:  per output dword 5 VALU ops (bfe, 2 x (lshl_or, and))
 __device__ __forceinline__ i32x4 spread16(unsigned w) {
     i32x4 o;
@@ -377,9 +383,11 @@ __device__ __forceinline__ void gq2_mfma_decode(const i32x4 (&op)[R], const Gq8Q
     for (int d = 0; d < kDigits; ++d)
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], q.q[d], acc[t][d], 0, 0, 0);
+            if (GPCA_ABLATE & 8) acc[t][d][0] ^= op[t][d] ^ q.q[d][t & 3];
+            else acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], q.q[d], acc[t][d], 0, 0, 0);
             const int m = d * R + t;          // 4R MFMAs <-> 4R output dwords (tile m / 4, dword m % 4)
-            opn[m >> 2][m & 3] = (int)lut[((unsigned)gn[m >> 2][SN] >> (8 * (m & 3))) & 0xffu];   // 2 VALU + 1 LDS read
+            if (GPCA_ABLATE & 1) opn[m >> 2][m & 3] = gn[m >> 2][SN];
+            else opn[m >> 2][m & 3] = (int)lut[((unsigned)gn[m >> 2][SN] >> (8 * (m & 3))) & 0xffu];   // 2 VALU + 1 LDS read
             __builtin_amdgcn_sched_barrier(0);
         }
 }
@@ -411,13 +419,15 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd);   // digit planes are < 2 GiB: one descriptor
     gq2_load_g<R>(GA, rg, gvo, 0u);
     gq8_load_q(Q0, rq, qvo, 0u); gq8_load_q(Q1, rq, qvo, QCH); gq8_load_q(Q2, rq, qvo, 2 * QCH);
+    if (GPCA_ABLATE & 2) Q3 = Q0;
+    if (GPCA_ABLATE & 4) GB = GA;
     gq2_decode<R, 0>(GA.g[0], opA);
     // One phase = one MFMA step: prefetch the digit planes 3 steps ahead; the R x 4 int8 MFMAs of this step (matrix
     // pipe) and the bit-spreading of the NEXT step's operands (VALU, 5 ops per dword) sit in one scheduling region so
     // that they interleave.  Operand sets alternate opA / opB.
 #define GQ2_PHASE(OPCUR, OPNXT, GNXT, BN, SN, QCUR, QNEXT, STEP)                            \
     { const uint32_t nst_ = (STEP) + 3u;                                                     \
-      gq8_load_q(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }                       \
+      if (!(GPCA_ABLATE & 2)) gq8_load_q(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }  \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     gq2_mfma_decode<R, SN>(OPCUR, QCUR, acc, GNXT.g[BN], OPNXT, lut);                        \
     __builtin_amdgcn_sched_barrier(0);
@@ -430,10 +440,10 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     for (int64_t sc = 0; sc < nsuper; sc += 2) {        // nsuper (512-sample super-chunks) is even
         const uint32_t st0 = (uint32_t)(sc * 16);
         const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;
-        gq2_load_g<R>(GB, rg, gvo, (uint32_t)((sc + 1) * 128));
+        if (!(GPCA_ABLATE & 4)) gq2_load_g<R>(GB, rg, gvo, (uint32_t)((sc + 1) * 128));
         GQ2_BLOCK(GA, 0, GA, 1, st0) GQ2_BLOCK(GA, 1, GA, 2, st0 + 4u) GQ2_BLOCK(GA, 2, GA, 3, st0 + 8u)
         GQ2_BLOCK(GA, 3, GB, 0, st0 + 12u)
-        gq2_load_g<R>(GA, rg, gvo, (uint32_t)((sc + 2 * more) * 128));   // last trip: re-loads its own first chunk (unused)
+        if (!(GPCA_ABLATE & 4)) gq2_load_g<R>(GA, rg, gvo, (uint32_t)((sc + 2 * more) * 128));   // last trip: re-loads its own first chunk (unused)
         GQ2_BLOCK(GB, 0, GB, 1, st0 + 16u) GQ2_BLOCK(GB, 1, GB, 2, st0 + 20u) GQ2_BLOCK(GB, 2, GB, 3, st0 + 24u)
         GQ2_BLOCK(GB, 3, GA, 0, st0 + 28u)
     }
@@ -474,12 +484,21 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
     __shared__ unsigned lut[256];
     lut[threadIdx.x] = (unsigned)spread4(threadIdx.x, 0);
     __syncthreads();
+#if GPCA_ABLATE & 16
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (; u + 4 <= u_end; u += 4) gq2_group<4>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut);
     if (u + 2 <= u_end) { gq2_group<2>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 2; }
     if (u + 1 <= u_end) { gq2_group<1>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 1; }
     const float o = csum + __shfl_xor(csum, 32);
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
     if (h == 0) { cpart[wave * 32 + c] = o; apart[wave * 32 + c] = (double)am; }
+#if GPCA_ABLATE & 16
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_kbench_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+        g_kbench_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
 }
 
 void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
@@ -727,7 +746,8 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
-                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
+                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out,
+                                                  int rmax) {
     __shared__ i32x4 tds[2][4][kDigits][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -740,12 +760,12 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
     int64_t u = u0;
     while (u < u1) {
         const int64_t rem = u1 - u;
-        if (rem > 8) {           // 4 tiles per wave
+        if (rem > 8 && rmax >= 4) {           // 4 tiles per wave
             const int64_t mine = u + 4 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
             gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
             u += 16;
-        } else if (rem > 4) {    // 2 tiles per wave
+        } else if (rem > 4 && rmax >= 2) {    // 2 tiles per wave
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
             gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
@@ -767,7 +787,369 @@ void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& pla
                  int scale_out) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;    // Npad is a multiple of 256 -> even
-    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+    static const int rmax = getenv("GPCA_GQ_R") ? atoi(getenv("GPCA_GQ_R")) : 4;
+    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, rmax);
+}
+
+// ================================================================================================
+// K1 by LDS-DMA (int8-resident genotypes).  Operand-shaped loads (one wave instruction = 32 rows x 32 B) keep the
+// texture-address unit twice as busy as full-line requests and cap this kernel near 4.9 TB/s; here every genotype byte
+// arrives as 8-row x 128-byte pieces written straight into LDS by `buffer_load_dwordx4 ... lds` (1 KiB per wave
+// instruction, no VGPR destination) and is read back in operand shape with ds_read_b128.
+//   * unit = one 32-row tile x one 128-sample stage = 4 KiB = 4 pieces.  The LDS image of a piece is lane-linear
+//     (lane l -> base + 16 l); lane l fetches row 8 i + (l >> 3), 16-byte chunk (l & 7) ^ (l >> 3), so row r keeps chunk
+//     k at position k ^ (r & 7) and the operand read (row c, chunk 2 s + h) is bank-conflict free.
+//   * each wave owns a ring of 6 unit slots and walks its R = 4 tiles tile-outer inside a stage (the 16 digit-plane
+//     operands of the stage sit in registers), so units are consumed strictly in order; the unit just finished is
+//     re-filled with the unit 6 ahead.  The digit planes of stage s+1 are DMA-ed (wave w: plane w) at the start of
+//     stage s behind the workgroup barrier.
+//   * the DMAs are inline asm, invisible to the compiler's s_waitcnt bookkeeping: completion is counted by hand.
+//     Issue order per stage:  Q(s+1), G(4s+6), G(4s+7), G(4s+8), G(4s+9)   (4 instructions each).
+//     - stage start, vmcnt(16): Q(s) was issued one stage ago, 4 unit fills (16) are younger.
+//     - before the first read of unit m (at step 3 of unit m-1), G(m+1..m+4) are younger (16) plus one plane batch
+//       (4), two when m = 1 mod 4:  vmcnt(20) / vmcnt(24).
+//     The prologue issues G0 G1 Q0 G2 G3 G4 G5 so that the same counts hold from the first stage on.
+//   A wave reads only its own unit slots: its counted vmcnt orders those reads; the planes are shared, so their wait is
+//   followed by the workgroup barrier.
+// ================================================================================================
+constexpr int kGqdSlots = 6;
+struct GqdSmem {
+    i32x4 q[2][4][kDigits][64];          // digit planes: [slot][step][digit][lane]          32 KiB
+    i32x4 g[4][kGqdSlots][256];          // genotype units: [wave][slot][piece i][lane]      96 KiB
+};
+
+__device__ __forceinline__ void gqd_dma(uint32_t lds_addr, uint32_t voff, i32x4 rsrc, uint32_t soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int N> __device__ __forceinline__ void gqd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
+    const uint64_t a = (uint64_t)p;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));
+    r.z = 0x7fffffff;
+    r.w = GPCA_RSRC_FLAGS;
+    return r;
+}
+
+__device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
+                                          const int8_t* __restrict__ Qd, GqdSmem* sm, int wv, int lane, int c, int h,
+                                          int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          float& csum, float& amax) {
+    constexpr int R = 4;
+    const int64_t row0 = unit0 * 32;
+    const i32x4 rg = gqd_rsrc(G + row0 * ldg);
+    const i32x4 rq = gqd_rsrc(Qd + wv * 1024);
+    const uint32_t ld32 = (uint32_t)ldg;
+    const uint32_t gvo = (uint32_t)(lane >> 3) * ld32 + 16u * (uint32_t)((lane & 7) ^ (lane >> 3));
+    const uint32_t qvo = (uint32_t)(lane * 16);
+    uint32_t toff[R];                                   // wave-uniform byte offset of tile t (tiles past the range: tile 0)
+#pragma unroll
+    for (int t = 0; t < R; ++t) toff[t] = (uint32_t)(t < nvalid ? 32 * t : 0) * ld32;
+    constexpr uint32_t QCH = kDigits * 1024;
+    const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
+    const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (kGqdSlots * 4096u);
+    const char* gl = reinterpret_cast<const char*>(&sm->g[wv][0][0]);
+    uint32_t loff[4];                                   // operand read: row c, chunk (2 s + h) ^ (c & 7)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) loff[s4] = (uint32_t)(c * 128 + (((2 * s4 + h) ^ (c & 7)) * 16));
+
+    i32x16 acc[R][kDigits];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    // fill unit (stage st, tile t) into ring slot `slot`
+#define GQD_ISSUE_G(ST, T, SLOT)                                                                          \
+    {                                                                                                     \
+        const uint32_t so_ = toff[(T)] + (uint32_t)(ST) * 128u;                                           \
+        const uint32_t la_ = lds_g + (uint32_t)(SLOT) * 4096u;                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma(la_ + 1024u * i, gvo, rg, so_ + 8u * i * ld32); \
+    }
+#define GQD_ISSUE_Q(ST, QS)                                                                               \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+            gqd_dma(lds_q + (uint32_t)(((QS) * 4 + j) * kDigits) * 1024u, qvo, rq, ((uint32_t)(ST) * 4u + j) * QCH); \
+    }
+    const int64_t s1 = nstage > 1 ? 1 : 0;
+    GQD_ISSUE_G(0, 0, 0) GQD_ISSUE_G(0, 1, 1)
+    GQD_ISSUE_Q(0, 0)
+    GQD_ISSUE_G(0, 2, 2) GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5)
+    int64_t ist = s1;        // next unit to issue: (stage ist, tile it), always into the slot just consumed
+    int it = 2;
+    uint32_t rslot = 0;      // slot of the unit being consumed
+    i32x4 gcur, gnxt;
+
+    for (int64_t st = 0; st < nstage; ++st) {
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");      // Q(st) landed in every wave's plane
+        GQD_ISSUE_Q(st + 1 < nstage ? st + 1 : 0, (int)((st + 1) & 1))
+        i32x4 q[4][kDigits];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int d = 0; d < kDigits; ++d) q[s4][d] = sm->q[st & 1][s4][d][lane];
+        if (st == 0) gcur = *reinterpret_cast<const i32x4*>(gl + loff[0]);     // unit 0 (slot 0) landed with Q(0)
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const char* ub = gl + rslot * 4096u;
+            const uint32_t nslot = rslot == kGqdSlots - 1 ? 0u : rslot + 1u;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 < 3) {
+                    gnxt = *reinterpret_cast<const i32x4*>(ub + loff[s4 + 1]);
+                } else {
+                    if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>();           // the next unit has landed
+                    gnxt = *reinterpret_cast<const i32x4*>(gl + nslot * 4096u + loff[0]);
+                }
+#pragma unroll
+                for (int d = 0; d < kDigits; ++d)
+                    acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(gcur, q[s4][d], acc[t][d], 0, 0, 0);
+                if (s4 == 3) {
+                    // every read of this unit has returned (its last operand fed the MFMAs above): re-fill its slot
+                    asm volatile("" :: "v"(gcur));
+                    GQD_ISSUE_G(ist, it, rslot)
+                    if (++it == R) { it = 0; ist = ist + 1 < nstage ? ist + 1 : 0; }
+                }
+                gcur = gnxt;
+            }
+            rslot = nslot;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // ring and plane slots quiescent before the next round
+#undef GQD_ISSUE_G
+#undef GQD_ISSUE_Q
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        if (t < nvalid) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float ri = rv[row], bi = bv[row];
+                const float gq = (float)(combine_digits(acc[t], e) * qs);
+                const float tv = ri * gq + bi * sj;
+                csum += bi * tv;
+                const float ov = scale_out ? ri * tv : tv;
+                amax = fmaxf(amax, fabsf(ov));
+                Tout[row * 32 + c] = ov;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nstage,
+                                                  const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
+                                                  const float* __restrict__ rv, const float* __restrict__ bv,
+                                                  const float* __restrict__ sv, float* __restrict__ Tout,
+                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
+    extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
+    GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
+    i32x4 (*tds)[4][kDigits][64] = sm->q;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
+    const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
+    float csum = 0.f, amax = 0.f;
+    const float sj = sv[c];
+    const double qs = qscale[c];
+    int64_t u = u0;
+    while (u < u1) {
+        const int64_t rem = u1 - u;
+        if (rem > 8) {           // 4 tiles per wave, genotypes by LDS-DMA
+            const int64_t mine = u + 4 * wv;
+            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
+            gqd_round(G, ldg, nstage, Qd, sm, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            u += 16;
+        } else if (rem > 4) {    // tails: the register-staged rounds
+            const int64_t mine = u + 2 * wv;
+            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
+            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            u += 8;
+        } else {
+            const int64_t mine = u + wv;
+            const int nv = mine < u1 ? 1 : 0;
+            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            u += 4;
+        }
+    }
+    const float o = csum + __shfl_xor(csum, 32);
+    const float am = fmaxf(amax, __shfl_xor(amax, 32));
+    if (h == 0) { cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o; apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am; }
+}
+
+int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+                const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
+                int scale_out) {
+    static const int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)sizeof(GqdSmem));
+    if (attr != 0) return attr;
+    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
+    const int64_t nstage = Npad / 128;
+    hipLaunchKernelGGL(k_gq_d, grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+    return 0;
+}
+
+// ================================================================================================
+// K1, packed genotypes, digit planes of Q shared through LDS: k_gq_x's staging (wave w brings plane w of each 128-sample
+// stage) with k_gq_2bit's operand path (16-byte loads = 64 samples of a row half, four stages = one 128-byte line of the
+// row requested back to back; a 256-entry LDS table spreads a byte of codes into 4 int8 operands in the MFMA shadow).
+// ================================================================================================
+template <int R, int SN>
+__device__ __forceinline__ void gqx2_phase(const i32x4 (&op)[R], const Gq8Q& qc, i32x16 (&acc)[R][kDigits], Gq8Q& qn,
+                                           const i32x4* lds_next, const i32x4 (&gn)[R], i32x4 (&opn)[R], const unsigned* lut) {
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) {
+        qn.q[d] = lds_next[d * 64];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], qc.q[d], acc[t][d], 0, 0, 0);
+            const int m = d * R + t;
+            opn[m >> 2][m & 3] = (int)lut[((unsigned)gn[m >> 2][SN] >> (8 * (m & 3))) & 0xffu];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void gqx2_round(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
+                                           const int8_t* __restrict__ Qd, i32x4 (*tds)[4][kDigits][64], const unsigned* lut,
+                                           int wv, int lane, int c, int h, int64_t unit0, int nvalid, double qs,
+                                           const float* __restrict__ rv, const float* __restrict__ bv, float sj,
+                                           float* __restrict__ Tout, int scale_out, float& csum, float& amax) {
+    const int64_t row0 = unit0 * 32;
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
+    uint32_t gvo[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)(((t < nvalid ? 32 * t : 0) + c) * ld2 + 16 * h);
+    constexpr uint32_t QCH = kDigits * 1024;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd + wv * 1024);    // this wave's plane
+    const uint32_t qvo = (uint32_t)(lane * 16);
+    const int64_t nstage = nsuper * 4;
+
+    i32x16 acc[R][kDigits];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    Gq2G<R> GA, GB;
+    Gq8Q QA, QB;
+    i32x4 opA[R], opB[R];
+    i32x4 PL0[4], PL1[4];
+    gq2_load_g<R>(GA, rg, gvo, 0u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) PL0[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, j * QCH, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (4u + j) * QCH, 0);   // nstage >= 8
+    __syncthreads();                       // the previous round's last LDS reads are done
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tds[0][j][wv][lane] = PL0[j];
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) QA.q[d] = tds[0][0][d][lane];
+    gq2_decode<R, 0>(GA.g[0], opA);
+
+    // stage ST = block B of buffer GCUR; the stage after it is block BNX of buffer GNX
+#define GQX2_STAGE(GCUR, B, GNX, BNX, ST, SLOT)                                                           \
+    {                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) tds[(SLOT) ^ 1][j][wv][lane] = PL1[j];             \
+        const uint32_t s2_ = ((ST) + 2 < nstage) ? (uint32_t)((ST) + 2) : 0u;                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+            PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (s2_ * 4u + j) * QCH, 0);            \
+        const i32x4* cur_ = &tds[(SLOT)][0][0][lane];                                                    \
+        const i32x4* nxt_ = &tds[(SLOT) ^ 1][0][0][lane];                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gqx2_phase<R, 1>(opA, QA, acc, QB, cur_ + 1 * kDigits * 64, GCUR.g[B], opB, lut);                \
+        gqx2_phase<R, 2>(opB, QB, acc, QA, cur_ + 2 * kDigits * 64, GCUR.g[B], opA, lut);                \
+        gqx2_phase<R, 3>(opA, QA, acc, QB, cur_ + 3 * kDigits * 64, GCUR.g[B], opB, lut);                \
+        __syncthreads();                                                                                 \
+        gqx2_phase<R, 0>(opB, QB, acc, QA, nxt_, GNX.g[BNX], opA, lut);                                  \
+    }
+    for (int64_t sc = 0; sc < nsuper; sc += 2) {        // nsuper (512-sample super-chunks) is even
+        const int64_t st0 = sc * 4;
+        const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;
+        gq2_load_g<R>(GB, rg, gvo, (uint32_t)((sc + 1) * 128));
+        GQX2_STAGE(GA, 0, GA, 1, st0 + 0, 0) GQX2_STAGE(GA, 1, GA, 2, st0 + 1, 1)
+        GQX2_STAGE(GA, 2, GA, 3, st0 + 2, 0) GQX2_STAGE(GA, 3, GB, 0, st0 + 3, 1)
+        gq2_load_g<R>(GA, rg, gvo, (uint32_t)((sc + 2 * more) * 128));   // last trip: re-loads its own first chunk (unused)
+        GQX2_STAGE(GB, 0, GB, 1, st0 + 4, 0) GQX2_STAGE(GB, 1, GB, 2, st0 + 5, 1)
+        GQX2_STAGE(GB, 2, GB, 3, st0 + 6, 0) GQX2_STAGE(GB, 3, GA, 0, st0 + 7, 1)
+    }
+#undef GQX2_STAGE
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        if (t < nvalid) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float ri = rv[row], bi = bv[row];
+                const float gq = (float)(combine_digits(acc[t], e) * qs);
+                const float tv = ri * gq + bi * sj;
+                csum += bi * tv;
+                const float ov = scale_out ? ri * tv : tv;
+                amax = fmaxf(amax, fabsf(ov));
+                Tout[row * 32 + c] = ov;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_gq_x2(const uint8_t* __restrict__ G2, int64_t ld2, int64_t units, int64_t nsuper,
+                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
+                                                   const float* __restrict__ rv, const float* __restrict__ bv,
+                                                   const float* __restrict__ sv, float* __restrict__ Tout,
+                                                   float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
+    __shared__ i32x4 tds[2][4][kDigits][64];
+    __shared__ unsigned lut[256];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    lut[threadIdx.x] = (unsigned)spread4(threadIdx.x, 0);
+    const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
+    const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
+    float csum = 0.f, amax = 0.f;
+    const float sj = sv[c];
+    const double qs = qscale[c];
+    int64_t u = u0;
+    while (u < u1) {      // (the table is visible after the first __syncthreads of the first round)
+        const int64_t rem = u1 - u;
+        if (rem > 8) {
+            const int64_t mine = u + 4 * wv;
+            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
+            gqx2_round<4>(G2, ld2, nsuper, Qd, tds, lut, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            u += 16;
+        } else if (rem > 4) {
+            const int64_t mine = u + 2 * wv;
+            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
+            gqx2_round<2>(G2, ld2, nsuper, Qd, tds, lut, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            u += 8;
+        } else {
+            const int64_t mine = u + wv;
+            const int nv = mine < u1 ? 1 : 0;
+            gqx2_round<1>(G2, ld2, nsuper, Qd, tds, lut, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            u += 4;
+        }
+    }
+    const float o = csum + __shfl_xor(csum, 32);
+    const float am = fmaxf(amax, __shfl_xor(amax, 32));
+    if (h == 0) { cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o; apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am; }
+}
+
+void launch_gq_x2(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
+                  int scale_out) {
+    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
+    const int64_t nsuper = Npad / 512;   // Npad is a multiple of 1024 in 2-bit mode -> even, and >= 8 stages
+    hipLaunchKernelGGL(k_gq_x2, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
 }
 
 // ================================================================================================

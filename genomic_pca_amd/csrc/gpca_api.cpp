@@ -93,6 +93,7 @@ struct gpca_handle {
     double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false;   // column abs-max partials of T' from the K1 epilogue
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
+    int gq_dma = 1;       // K1 (int8-resident) genotype loads by LDS-DMA, full-line pieces (GPCA_GQ_DMA=0: register-staged k_gq_x)
     int lds_planes = 1;   // share the digit planes of the exact GEMMs through LDS (GPCA_LDS_PLANES=0 disables)
     int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
 
@@ -196,6 +197,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (const char* e = getenv("GPCA_GQ_WAVES")) h->gq_waves_target = std::max(4, atoi(e));
     if (const char* e = getenv("GPCA_GTT_WAVES")) h->gtt_waves_target = std::max(4, atoi(e));
     if (const char* e = getenv("GPCA_LDS_PLANES")) h->lds_planes = atoi(e);
+    if (const char* e = getenv("GPCA_GQ_DMA")) h->gq_dma = atoi(e);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
         delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
     }
@@ -700,7 +702,13 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     if (h->precision == GPCA_PREC_I8_EXACT) {
         {
             ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            if (h->storage == GPCA_STORE_2BIT && h->lds_planes) { launch_gq_x2(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            else if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            else if (h->lds_planes && h->gq_dma) {
+                const int e = launch_gq_d(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out);
+                if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
+                h->apart_valid = scale_out != 0;
+            }
             else if (h->lds_planes) { launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
             else launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
         }

@@ -130,6 +130,14 @@ void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan
 // quantise X whose column abs-max partials [P][32] were already produced by the kernel that wrote it (K1 epilogue)
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
                                 double* scale, double* inv, int8_t* Xd, int layout);
+// K1 with the genotypes brought in by LDS-DMA (full-line pieces); returns a hipError_t value (0 = ok)
+int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+                const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
+                int scale_out);
+// K1, packed genotypes, digit planes shared through LDS
+void launch_gq_x2(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
+                  int scale_out);
 // K1 with the digit planes of Q shared through LDS (int8-resident genotypes)
 void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,

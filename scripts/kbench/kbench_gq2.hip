@@ -1,0 +1,49 @@
+// Ablation harness for the packed K1 kernel (k_gq_2bit): the product source is compiled with GPCA_ABLATE = bitmask
+// (bit0 no decode, bit1 no Q loads, bit2 no G loads, bit3 no MFMA) and timed on a 1M x 10k problem.  Not product code.
+//   for a in 0 1 2 4 6 7 8; do hipcc --offload-arch=gfx950 -O3 -DGPCA_ABLATE=$a -o kb_$a kbench_gq2.hip; ./kb_$a; done
+#include "../../genomic_pca_amd/csrc/gemm_i8.hip"
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+__global__ void k_fill(uint32_t* p, int64_t n, uint32_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+        p[i] = x;
+    }
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main(int argc, char** argv) {
+    const int64_t M = 1000064, N = 10000, Npad = 10240, ld2 = Npad / 4;
+    const int waves = argc > 1 ? atoi(argv[1]) : 1024;
+    uint8_t* G2; int8_t* Qd; double* qs; float *r, *b, *s, *T, *cp; double* ap;
+    CK(hipMalloc(&G2, M * ld2)); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G2, M * ld2 / 4, 1u);
+    CK(hipMalloc(&Qd, Npad * 32 * 4)); hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, (uint32_t*)Qd, Npad * 32, 2u);
+    CK(hipMalloc(&qs, 32 * 8)); CK(hipMemset(qs, 0, 32 * 8));
+    CK(hipMalloc(&r, M * 4)); CK(hipMalloc(&b, M * 4)); CK(hipMalloc(&s, 32 * 4)); CK(hipMalloc(&T, M * 32 * 4));
+    CK(hipMemset(r, 0, M * 4)); CK(hipMemset(b, 0, M * 4)); CK(hipMemset(s, 0, 32 * 4));
+    CK(hipMalloc(&cp, waves * 32 * 4)); CK(hipMalloc(&ap, waves * 32 * 8));
+    gpca::GqPlan plan{M / 32, waves};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 2; ++it) gpca::launch_gq_2bit(0, G2, ld2, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1);
+    CK(hipDeviceSynchronize());
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) gpca::launch_gq_2bit(0, G2, ld2, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1);
+    hipEventRecord(e1); CK(hipEventSynchronize(e1));
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double mf = (double)M * Npad * 32 * 4 / 32768.0;   // MFMAs
+    printf("ablate %d waves %d: %.3f ms  (%.1f %% of the i8 MFMA floor %.3f ms)\n", GPCA_ABLATE, waves, ms,
+           100.0 * (mf * 32 / (1024 * 2.39e9) * 1e3) / ms, mf * 32 / (1024 * 2.39e9) * 1e3);
+#if GPCA_ABLATE & 16
+    {   // steady state: 300 more launches, then read the stamps of the last one
+        for (int it = 0; it < 300; ++it) gpca::launch_gq_2bit(0, G2, ld2, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st(2 * 4096);
+        CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(gpca::g_kbench_stamp), st.size() * 8));
+        std::vector<double> ghz;
+        for (int b2 = 0; b2 < waves / 4; ++b2) ghz.push_back((double)st[2 * b2] / (double)st[2 * b2 + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        printf("  in-kernel clock: median %.3f GHz (min %.3f max %.3f), median wave cycles %.0f\n", ghz[ghz.size() / 2], ghz.front(), ghz.back(), (double)st[0]);
+    }
+#endif
+    return 0;
+}

@@ -1,0 +1,140 @@
+// HBM read-bandwidth ceiling probe for gfx950: streaming-read kernels over a 10 GiB buffer with varying loads in flight,
+// grid sizes and cache policies.  Calibrates what "speed of light" means for the HBM-bound genotype passes (K1/K2).
+//   hipcc --offload-arch=gfx950 -O3 -o kbench_stream kbench_stream.hip && ./kbench_stream
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <int U, int NT>
+__global__ __launch_bounds__(256) void k_read(const i32x4* __restrict__ p, int64_t n16, int* __restrict__ out) {
+    // grid-stride over 16-byte elements; U independent loads in flight per lane
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    i32x4 acc = {0, 0, 0, 0};
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        i32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+// contiguous-per-block variant: each block owns one contiguous slab (like a wave owning SNP rows)
+template <int U>
+__global__ __launch_bounds__(256) void k_read_slab(const i32x4* __restrict__ p, int64_t n16, int* __restrict__ out) {
+    const int64_t per = n16 / gridDim.x;
+    const i32x4* q = p + per * blockIdx.x;
+    i32x4 acc = {0, 0, 0, 0};
+    for (int64_t i = threadIdx.x; i + (U - 1) * 256 < per; i += U * 256) {
+        i32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = q[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+// K1's access pattern: a wave owns 32*R rows of a row-major [M][ld] byte matrix and sweeps the columns 128 B at a time.
+// PAT 0: lane (c = lane & 31, h = lane >> 5) loads 16 B at row c, byte 32 j + 16 h  (the MFMA A-operand mapping; one wave
+//        instruction touches 32 rows x 32 B), four j back to back = one 128-B line per row.
+// PAT 1: line-coalesced: lane l loads 16 B at row (l >> 3) + 8 j, byte 16 (l & 7)  (one instruction = 8 full lines).
+template <int R, int PAT>
+__global__ __launch_bounds__(256, 1) void k_read_rows(const char* __restrict__ p, int64_t M, int64_t ld, int* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t units = M / (32 * R);
+    i32x4 acc = {0, 0, 0, 0};
+    for (int64_t u = (units * wave) / waves; u < (units * (wave + 1)) / waves; ++u) {
+        const char* base = p + u * 32 * R * ld;
+        for (int64_t col = 0; col < ld; col += 128) {
+            i32x4 v[R][4];
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t row = PAT == 0 ? 32 * t + (lane & 31) : 32 * t + 8 * j + (lane >> 3);
+                    const int64_t off = PAT == 0 ? 32 * j + 16 * (lane >> 5) : 16 * (lane & 7);
+                    v[t][j] = *reinterpret_cast<const i32x4*>(base + row * ld + col + off);
+                }
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc ^= v[t][j];
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+// operand-map pattern with J back-to-back 32-byte pieces per row per sweep step (J = 4: one 128-B line, 8: two, 16: four)
+template <int R, int J>
+__global__ __launch_bounds__(256, 1) void k_read_rows_j(const char* __restrict__ p, int64_t M, int64_t ld, int* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t units = M / (32 * R);
+    i32x4 acc = {0, 0, 0, 0};
+    for (int64_t u = (units * wave) / waves; u < (units * (wave + 1)) / waves; ++u) {
+        const char* base = p + u * 32 * R * ld;
+        for (int64_t col = 0; col < ld; col += 32 * J) {
+            i32x4 v[R][J];
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    v[t][j] = *reinterpret_cast<const i32x4*>(base + (32 * t + (lane & 31)) * ld + col + 32 * j + 16 * (lane >> 5));
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc ^= v[t][j];
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+template <typename F> static float time_ms(F f, int reps) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a); for (int r = 0; r < reps; ++r) f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+int main() {
+    const int64_t bytes = 11LL << 30; const int64_t n16 = bytes / 16;
+    i32x4* p; int* out; CK(hipMalloc(&p, bytes)); CK(hipMalloc(&out, 4)); CK(hipMemset(p, 1, bytes)); CK(hipMemset(out, 0, 4));
+    const int grids[] = {1024, 16384};
+    for (int g : grids) {
+        float t1 = time_ms([&] { hipLaunchKernelGGL((k_read<1, 0>), dim3(g), dim3(256), 0, 0, p, n16, out); }, 5);
+        float t4 = time_ms([&] { hipLaunchKernelGGL((k_read<4, 0>), dim3(g), dim3(256), 0, 0, p, n16, out); }, 5);
+        float t8 = time_ms([&] { hipLaunchKernelGGL((k_read<8, 0>), dim3(g), dim3(256), 0, 0, p, n16, out); }, 5);
+        float n4 = time_ms([&] { hipLaunchKernelGGL((k_read<4, 1>), dim3(g), dim3(256), 0, 0, p, n16, out); }, 5);
+        float s4 = time_ms([&] { hipLaunchKernelGGL((k_read_slab<4>), dim3(g), dim3(256), 0, 0, p, n16, out); }, 5);
+        float s8 = time_ms([&] { hipLaunchKernelGGL((k_read_slab<8>), dim3(g), dim3(256), 0, 0, p, n16, out); }, 5);
+        printf("grid %6d  stride U1 %.2f  U4 %.2f  U8 %.2f  U4nt %.2f | slab U4 %.2f  U8 %.2f  TB/s\n", g, bytes / t1 * 1e-9,
+               bytes / t4 * 1e-9, bytes / t8 * 1e-9, bytes / n4 * 1e-9, bytes / s4 * 1e-9, bytes / s8 * 1e-9);
+        fflush(stdout);
+    }
+    {
+        const int64_t M = 1000064, ld = 10240;   // 10.24 GB, the C2 genotype matrix
+        const int wgs[] = {256, 512, 1024};
+        for (int g : wgs) {
+            float a4 = time_ms([&] { hipLaunchKernelGGL((k_read_rows<4, 0>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float a2 = time_ms([&] { hipLaunchKernelGGL((k_read_rows<2, 0>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float b4 = time_ms([&] { hipLaunchKernelGGL((k_read_rows<4, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float b2 = time_ms([&] { hipLaunchKernelGGL((k_read_rows<2, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            const double gb = (double)M * ld;
+            printf("rows grid %5d  operand-map R4 %.2f R2 %.2f | line-coalesced R4 %.2f R2 %.2f  TB/s\n", g, gb / a4 * 1e-9, gb / a2 * 1e-9,
+                   gb / b4 * 1e-9, gb / b2 * 1e-9);
+            fflush(stdout);
+            float c1 = time_ms([&] { hipLaunchKernelGGL((k_read_rows_j<4, 8>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float c2 = time_ms([&] { hipLaunchKernelGGL((k_read_rows_j<2, 8>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float c3 = time_ms([&] { hipLaunchKernelGGL((k_read_rows_j<2, 16>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float c4 = time_ms([&] { hipLaunchKernelGGL((k_read_rows_j<1, 16>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float c5 = time_ms([&] { hipLaunchKernelGGL((k_read_rows_j<1, 8>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            float c6 = time_ms([&] { hipLaunchKernelGGL((k_read_rows_j<1, 4>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            printf("           operand-map  R4x256B %.2f  R2x256B %.2f  R2x512B %.2f  R1x512B %.2f  R1x256B %.2f  R1x128B %.2f TB/s\n",
+                   gb / c1 * 1e-9, gb / c2 * 1e-9, gb / c3 * 1e-9, gb / c4 * 1e-9, gb / c5 * 1e-9, gb / c6 * 1e-9);
+            fflush(stdout);
+        }
+    }
+    return 0;
+}
