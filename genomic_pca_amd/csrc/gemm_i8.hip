@@ -22,6 +22,9 @@ namespace gpca {
 
 // cache policy of the once-read genotype stream: 0 = default, 2 = non-temporal (GPCA_STREAM_NT=1)
 static const bool g_stream_nt = [] { const char* e = getenv("GPCA_STREAM_NT"); return e && atoi(e) != 0; }();
+// the LDS-DMA genotype stream of k_gq_d: full-line pieces read once per pass -> non-temporal by default (measured
+// 1.82 -> 1.71 ms per pass; GPCA_GQ_DMA_NT=0 restores the default cache policy)
+static const bool g_dma_nt = [] { const char* e = getenv("GPCA_GQ_DMA_NT"); return !e || atoi(e) != 0; }();
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -818,11 +821,17 @@ struct GqdSmem {
     i32x4 g[4][kGqdSlots][256];          // genotype units: [wave][slot][piece i][lane]      96 KiB
 };
 
+template <int NT = 0>
 __device__ __forceinline__ void gqd_dma(uint32_t lds_addr, uint32_t voff, i32x4 rsrc, uint32_t soff) {
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    if (NT)      // streamed once per pass: non-temporal
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    else
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 template <int N> __device__ __forceinline__ void gqd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
@@ -835,6 +844,7 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
     return r;
 }
 
+template <int NT>
 __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
                                           const int8_t* __restrict__ Qd, GqdSmem* sm, int wv, int lane, int c, int h,
                                           int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
@@ -871,7 +881,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     {                                                                                                     \
         const uint32_t so_ = toff[(T)] + (uint32_t)(ST) * 128u;                                           \
         const uint32_t la_ = lds_g + (uint32_t)(SLOT) * 4096u;                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma(la_ + 1024u * i, gvo, rg, so_ + 8u * i * ld32); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma<NT>(la_ + 1024u * i, gvo, rg, so_ + 8u * i * ld32); \
     }
 #define GQD_ISSUE_Q(ST, QS)                                                                               \
     {                                                                                                     \
@@ -943,6 +953,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     }
 }
 
+template <int NT>
 __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nstage,
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
@@ -965,7 +976,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
         if (rem > 8) {           // 4 tiles per wave, genotypes by LDS-DMA
             const int64_t mine = u + 4 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqd_round(G, ldg, nstage, Qd, sm, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqd_round<NT>(G, ldg, nstage, Qd, sm, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
             u += 16;
         } else if (rem > 4) {    // tails: the register-staged rounds
             const int64_t mine = u + 2 * wv;
@@ -987,12 +998,15 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                 int scale_out) {
-    static const int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)sizeof(GqdSmem));
-    if (attr != 0) return attr;
+    static const int attr0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)sizeof(GqdSmem));
+    static const int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)sizeof(GqdSmem));
+    if (attr0 != 0 || attr1 != 0) return attr0 ? attr0 : attr1;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;
-    hipLaunchKernelGGL(k_gq_d, grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+    if (g_dma_nt) hipLaunchKernelGGL(k_gq_d<1>, grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+    else hipLaunchKernelGGL(k_gq_d<0>, grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
     return 0;
 }
 
@@ -1162,10 +1176,16 @@ void launch_gq_x2(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& 
 template <bool PACKED>
 struct GttXG { unsigned g[16]; };
 
+// int8 rows: every 128-byte line is consumed whole by one instruction of one wave and never again in the pass -> nt
+// (measured 1.90 -> 1.80 ms per pass).  Packed rows: the four waves of a workgroup share lines -> default policy
+// (nt there measured 3.91 -> 4.22 ms per step).
+#ifndef GPCA_GTTX_AUX
+#define GPCA_GTTX_AUX 2
+#endif
 template <bool PACKED>
 __device__ __forceinline__ void gttx_load_g(GttXG<PACKED>& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off, uint32_t ldr) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ldr, 0);
+    for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ldr, PACKED ? 0 : GPCA_GTTX_AUX);
 }
 // decode micro-step m (0..15) of the next block's operands
 template <bool PACKED>
@@ -1219,13 +1239,21 @@ __device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i
 template <bool PACKED>
 __global__ __launch_bounds__(256, 1) void k_gtt_x(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Mpad, int64_t Npad,
                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t ngroups, int64_t rows_per_wave) {
+                                                   int64_t ngroups, int64_t rows_per_wave, int xcd_remap) {
     __shared__ i32x4 tds[2][4][kDigits][64];   // [slot][block in stage][plane][lane]: 2 x 16 KiB
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int64_t ngroup = blockIdx.x % ngroups;
-    const int64_t wchunk = blockIdx.x / ngroups;
+    // workgroup b runs on XCD b % 8 (round-robin dispatch).  With the remap the workgroups of one XCD take CONSECUTIVE
+    // virtual ids, so the n-groups that share a row chunk -- and therefore the same digit planes of T' -- sit behind one
+    // L2 and fetch those planes from HBM once instead of once per XCD.
+    int64_t vb = blockIdx.x;
+    if (xcd_remap) {
+        const int64_t q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
+        vb = x * q + (x < r ? x : r) + blockIdx.x / 8;
+    }
+    const int64_t ngroup = vb % ngroups;
+    const int64_t wchunk = vb / ngroups;
     const int64_t nblock = ngroup * 4 + wv;
     int64_t n0 = nblock * 128;
     const bool live = n0 < Npad;          // a dead wave (ragged last group) still loads planes and joins the barriers
@@ -1321,8 +1349,9 @@ void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64
                   double* Ypart, const Gtt8Plan& plan) {
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     const dim3 grid((unsigned)plan.grid), blk(256);
-    if (packed) hipLaunchKernelGGL((k_gtt_x<true>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
-    else hipLaunchKernelGGL((k_gtt_x<false>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+    static const int remap = getenv("GPCA_GTT_XCD") ? atoi(getenv("GPCA_GTT_XCD")) : 0;
+    if (packed) hipLaunchKernelGGL((k_gtt_x<true>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
+    else hipLaunchKernelGGL((k_gtt_x<false>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
 }
 
 // ------------------------------------------------------------------------------------------------

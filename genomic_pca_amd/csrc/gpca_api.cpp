@@ -81,6 +81,7 @@ struct gpca_handle {
     int k = 0, l = 0, L = 0;
     bool have_rsvd = false;
     float *dQ = nullptr, *dT = nullptr, *dTb = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
+    int* d_cholflag = nullptr;   // first failed CholeskyQR pivot + 1 (0 = ok), written by k_chol_inv
     double *d_scratch64 = nullptr, *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
     double* d_scores64 = nullptr; float* d_scores32 = nullptr; float* d_load32 = nullptr; int* d_sign = nullptr;
     size_t cap_Q = 0, cap_T = 0, cap_Tb = 0, cap_Ypart = 0, cap_cpart = 0, cap_Y = 0, cap_part64 = 0, cap_scores = 0, cap_load = 0;
@@ -222,7 +223,7 @@ static void free_ws(gpca_handle* h) {
     dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
     dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
-    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
+    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_cholflag); dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
     h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
     h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
     h->have_rsvd = false;
@@ -607,32 +608,6 @@ static int allreduce_f64(gpca_handle* h, double* dbuf, int64_t count) {
 }
 
 // ---- small dense (host, f64) ----------------------------------------------------------------------------------
-static int chol_upper(std::vector<double>& W, int n, int ld) {  // W = R^T R in place (upper), 0 ok / j+1 on failure
-    for (int j = 0; j < n; ++j) {
-        double d = W[j * ld + j];
-        for (int k = 0; k < j; ++k) d -= W[k * ld + j] * W[k * ld + j];
-        if (!(d > 0.0) || !std::isfinite(d)) return j + 1;
-        d = std::sqrt(d);
-        W[j * ld + j] = d;
-        for (int c = j + 1; c < n; ++c) {
-            double s = W[j * ld + c];
-            for (int k = 0; k < j; ++k) s -= W[k * ld + j] * W[k * ld + c];
-            W[j * ld + c] = s / d;
-        }
-    }
-    return 0;
-}
-static void upper_inverse(const std::vector<double>& R, std::vector<double>& X, int n, int ld) {
-    std::fill(X.begin(), X.end(), 0.0);
-    for (int j = 0; j < n; ++j) {
-        X[j * ld + j] = 1.0 / R[j * ld + j];
-        for (int i = j - 1; i >= 0; --i) {
-            double s = 0.0;
-            for (int k = i + 1; k <= j; ++k) s += R[i * ld + k] * X[k * ld + j];
-            X[i * ld + j] = -s / R[i * ld + i];
-        }
-    }
-}
 static void jacobi_eigh(std::vector<double>& A, std::vector<double>& V, std::vector<double>& w, int n) {
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -702,7 +677,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     if (h->precision == GPCA_PREC_I8_EXACT) {
         {
             ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT && h->lds_planes) { launch_gq_x2(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            if (h->storage == GPCA_STORE_2BIT && h->lds_planes >= 2) { launch_gq_x2(   /* measured slower than k_gq_2bit (3.8 vs 3.5 ms): opt-in only */h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
             else if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
             else if (h->lds_planes && h->gq_dma) {
                 const int e = launch_gq_d(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out);
@@ -728,26 +703,16 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
 // CholeskyQR2 of dY -> dQ (f32, padded), s = 1^T Q
 static int stage_orth(gpca_handle* h) {
     const int L = h->L, l = h->l;
-    std::vector<double> W((size_t)L * L), X((size_t)L * L);
-    for (int round = 0; round < 2; ++round) {
+    for (int round = 0; round < 2; ++round) {      // CholeskyQR2, entirely on the stream (no host round trip)
         const int64_t parts = gram_num_parts(h->N);
         launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
         HIPCHK(hipGetLastError());
         launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(W.data(), h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
-        HIPCHK(hipStreamSynchronize(h->st));
-        const int rc = chol_upper(W, l, L);
-        if (rc) {
-            char buf[160];
-            snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not positive (rank-deficient sketch)", rc - 1, l);
-            return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
-        }
-        upper_inverse(W, X, l, L);
-        HIPCHK(hipMemcpyAsync(h->dZ, X.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, h->st));
+        launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
+        HIPCHK(hipGetLastError());
         launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, round == 1 ? h->dQ : nullptr, h->ldg);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(h->st));  // X (host) is reused next round
     }
     const int64_t parts = colsum_num_parts(h->N);
     launch_colsum_f64(h->st, h->dY, h->N, L, h->d_part64);   // dY now holds the orthonormal basis in f64
@@ -783,6 +748,7 @@ static int ensure_workspace(gpca_handle* h) {
         HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, 64 * 64 * 8));
         HIPCHK(hipMalloc((void**)&h->dZ, 64 * 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
         HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
+        HIPCHK(hipMalloc((void**)&h->d_cholflag, 4));
     }
     if (h->precision == GPCA_PREC_I8_EXACT) {
         h->plan8 = gtt8_plan(h->Mpad, Npad, h->gtt_waves_target);
@@ -823,6 +789,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     h->have_rsvd = false;
     CHK(ensure_workspace(h));
     const int L = h->L;
+    HIPCHK(hipMemsetAsync(h->d_cholflag, 0, 4, h->st));
 
     // 1. sketch: T' = r o Omega, c = b^T Omega;  Y = A^T Omega;  Q = orth(Y)
     {
@@ -851,8 +818,15 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         CHK(allreduce_f64(h, h->dW, (int64_t)L * L));
     }
     std::vector<double> Wfull((size_t)L * L), C((size_t)l * l), V((size_t)l * l), w((size_t)l);
+    int cholflag = 0;
     HIPCHK(hipMemcpyAsync(Wfull.data(), h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipMemcpyAsync(&cholflag, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
+    if (cholflag) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not positive (rank-deficient sketch)", cholflag - 1, l);
+        return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
+    }
     for (int a = 0; a < l; ++a) for (int c = 0; c < l; ++c) C[(size_t)a * l + c] = 0.5 * (Wfull[(size_t)a * L + c] + Wfull[(size_t)c * L + a]);
     jacobi_eigh(C, V, w, l);
     h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);

@@ -72,6 +72,8 @@ int64_t gram_num_parts(int64_t rows);
 void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part);
 void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part);
 // X[n][:] <- X[n][:] * Z  (Z: [L][L] f64, in place); optionally also the blocked f32 basis Qb (rows_pad rows, pad rows zeroed)
+// W = R^T R (n x n, pitch ld <= 64), Z = R^-1; *flag = j + 1 on a non-positive pivot (first failure wins)
+void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag);
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qb,
                                 int64_t rows_pad);
 // out[n][kc] = sum_j X[n][j] Z[j][kc]   (Z: [L][K] f64)

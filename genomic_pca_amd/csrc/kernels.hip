@@ -487,6 +487,54 @@ __global__ __launch_bounds__(256) void k_apply_right(double* __restrict__ X, int
     if (n < rows) X[n * L + cc] = a;
     if (Qout && n < rows_pad) Qout[blocked_q_index(n, cc, L >> 5)] = (n < rows) ? (float)a : 0.f;
 }
+// CholeskyQR's small factorisation on the device: W (n x n, pitch ld, upper triangle used) = R^T R, Z = R^-1 (upper,
+// zero elsewhere, the whole ld x ld block written).  One workgroup, thread c owns column c; same operation order as a
+// row-by-row Cholesky-Crout on the host, so no host round trip (and no stream sync) sits between the Gram matrix and the
+// right-multiplication.  A non-positive pivot records (j + 1) in *flag (first failure wins) and the factorisation
+// carries on with pivot 1 so that nothing downstream spins or faults; the caller checks the flag once, at the end.
+__global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, int n, int ld, double* __restrict__ Zg,
+                                                 int* __restrict__ flag) {
+    __shared__ double R[64 * 64];
+    __shared__ double X[64 * 64];
+    const int c = threadIdx.x;
+    for (int r = 0; r < ld; ++r) {
+        if (c < ld) { R[r * ld + c] = Wg[r * ld + c]; X[r * ld + c] = 0.0; }
+    }
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        double d = R[j * ld + j];
+        for (int k = 0; k < j; ++k) d -= R[k * ld + j] * R[k * ld + j];
+        if (!(d > 0.0) || !isfinite(d)) {
+            if (c == 0) atomicCAS(flag, 0, j + 1);
+            d = 1.0;
+        }
+        d = sqrt(d);
+        double s = 0.0;
+        if (c > j && c < n) {
+            s = R[j * ld + c];
+            for (int k = 0; k < j; ++k) s -= R[k * ld + j] * R[k * ld + c];
+        }
+        __syncthreads();
+        if (c == j) R[j * ld + j] = d;
+        else if (c > j && c < n) R[j * ld + c] = s / d;
+    }
+    __syncthreads();
+    if (c < n) {                      // column c of R^-1 by back substitution
+        X[c * ld + c] = 1.0 / R[c * ld + c];
+        for (int i = c - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int k = i + 1; k <= c; ++k) s += R[i * ld + k] * X[k * ld + c];
+            X[i * ld + c] = -s / R[i * ld + i];
+        }
+    }
+    __syncthreads();
+    for (int r = 0; r < ld; ++r)
+        if (c < ld) Zg[r * ld + c] = X[r * ld + c];
+}
+void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(64), 0, st, W, n, ld, Z, flag);
+}
+
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,
                                 int64_t rows_pad) {
     const int64_t span = Qout ? rows_pad : rows;
