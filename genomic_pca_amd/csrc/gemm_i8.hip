@@ -1011,162 +1011,6 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
 }
 
 // ================================================================================================
-// K1, packed genotypes, digit planes of Q shared through LDS: k_gq_x's staging (wave w brings plane w of each 128-sample
-// stage) with k_gq_2bit's operand path (16-byte loads = 64 samples of a row half, four stages = one 128-byte line of the
-// row requested back to back; a 256-entry LDS table spreads a byte of codes into 4 int8 operands in the MFMA shadow).
-// ================================================================================================
-template <int R, int SN>
-__device__ __forceinline__ void gqx2_phase(const i32x4 (&op)[R], const Gq8Q& qc, i32x16 (&acc)[R][kDigits], Gq8Q& qn,
-                                           const i32x4* lds_next, const i32x4 (&gn)[R], i32x4 (&opn)[R], const unsigned* lut) {
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) {
-        qn.q[d] = lds_next[d * 64];
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], qc.q[d], acc[t][d], 0, 0, 0);
-            const int m = d * R + t;
-            opn[m >> 2][m & 3] = (int)lut[((unsigned)gn[m >> 2][SN] >> (8 * (m & 3))) & 0xffu];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-template <int R>
-__device__ __forceinline__ void gqx2_round(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
-                                           const int8_t* __restrict__ Qd, i32x4 (*tds)[4][kDigits][64], const unsigned* lut,
-                                           int wv, int lane, int c, int h, int64_t unit0, int nvalid, double qs,
-                                           const float* __restrict__ rv, const float* __restrict__ bv, float sj,
-                                           float* __restrict__ Tout, int scale_out, float& csum, float& amax) {
-    const int64_t row0 = unit0 * 32;
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
-    uint32_t gvo[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)(((t < nvalid ? 32 * t : 0) + c) * ld2 + 16 * h);
-    constexpr uint32_t QCH = kDigits * 1024;
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd + wv * 1024);    // this wave's plane
-    const uint32_t qvo = (uint32_t)(lane * 16);
-    const int64_t nstage = nsuper * 4;
-
-    i32x16 acc[R][kDigits];
-#pragma unroll
-    for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
-
-    Gq2G<R> GA, GB;
-    Gq8Q QA, QB;
-    i32x4 opA[R], opB[R];
-    i32x4 PL0[4], PL1[4];
-    gq2_load_g<R>(GA, rg, gvo, 0u);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) PL0[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, j * QCH, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (4u + j) * QCH, 0);   // nstage >= 8
-    __syncthreads();                       // the previous round's last LDS reads are done
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tds[0][j][wv][lane] = PL0[j];
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) QA.q[d] = tds[0][0][d][lane];
-    gq2_decode<R, 0>(GA.g[0], opA);
-
-    // stage ST = block B of buffer GCUR; the stage after it is block BNX of buffer GNX
-#define GQX2_STAGE(GCUR, B, GNX, BNX, ST, SLOT)                                                           \
-    {                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) tds[(SLOT) ^ 1][j][wv][lane] = PL1[j];             \
-        const uint32_t s2_ = ((ST) + 2 < nstage) ? (uint32_t)((ST) + 2) : 0u;                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
-            PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (s2_ * 4u + j) * QCH, 0);            \
-        const i32x4* cur_ = &tds[(SLOT)][0][0][lane];                                                    \
-        const i32x4* nxt_ = &tds[(SLOT) ^ 1][0][0][lane];                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        gqx2_phase<R, 1>(opA, QA, acc, QB, cur_ + 1 * kDigits * 64, GCUR.g[B], opB, lut);                \
-        gqx2_phase<R, 2>(opB, QB, acc, QA, cur_ + 2 * kDigits * 64, GCUR.g[B], opA, lut);                \
-        gqx2_phase<R, 3>(opA, QA, acc, QB, cur_ + 3 * kDigits * 64, GCUR.g[B], opB, lut);                \
-        __syncthreads();                                                                                 \
-        gqx2_phase<R, 0>(opB, QB, acc, QA, nxt_, GNX.g[BNX], opA, lut);                                  \
-    }
-    for (int64_t sc = 0; sc < nsuper; sc += 2) {        // nsuper (512-sample super-chunks) is even
-        const int64_t st0 = sc * 4;
-        const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;
-        gq2_load_g<R>(GB, rg, gvo, (uint32_t)((sc + 1) * 128));
-        GQX2_STAGE(GA, 0, GA, 1, st0 + 0, 0) GQX2_STAGE(GA, 1, GA, 2, st0 + 1, 1)
-        GQX2_STAGE(GA, 2, GA, 3, st0 + 2, 0) GQX2_STAGE(GA, 3, GB, 0, st0 + 3, 1)
-        gq2_load_g<R>(GA, rg, gvo, (uint32_t)((sc + 2 * more) * 128));   // last trip: re-loads its own first chunk (unused)
-        GQX2_STAGE(GB, 0, GB, 1, st0 + 4, 0) GQX2_STAGE(GB, 1, GB, 2, st0 + 5, 1)
-        GQX2_STAGE(GB, 2, GB, 3, st0 + 6, 0) GQX2_STAGE(GB, 3, GA, 0, st0 + 7, 1)
-    }
-#undef GQX2_STAGE
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-        if (t < nvalid) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float ri = rv[row], bi = bv[row];
-                const float gq = (float)(combine_digits(acc[t], e) * qs);
-                const float tv = ri * gq + bi * sj;
-                csum += bi * tv;
-                const float ov = scale_out ? ri * tv : tv;
-                amax = fmaxf(amax, fabsf(ov));
-                Tout[row * 32 + c] = ov;
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void k_gq_x2(const uint8_t* __restrict__ G2, int64_t ld2, int64_t units, int64_t nsuper,
-                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
-                                                   const float* __restrict__ rv, const float* __restrict__ bv,
-                                                   const float* __restrict__ sv, float* __restrict__ Tout,
-                                                   float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
-    __shared__ i32x4 tds[2][4][kDigits][64];
-    __shared__ unsigned lut[256];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    lut[threadIdx.x] = (unsigned)spread4(threadIdx.x, 0);
-    const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
-    const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
-    float csum = 0.f, amax = 0.f;
-    const float sj = sv[c];
-    const double qs = qscale[c];
-    int64_t u = u0;
-    while (u < u1) {      // (the table is visible after the first __syncthreads of the first round)
-        const int64_t rem = u1 - u;
-        if (rem > 8) {
-            const int64_t mine = u + 4 * wv;
-            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqx2_round<4>(G2, ld2, nsuper, Qd, tds, lut, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
-            u += 16;
-        } else if (rem > 4) {
-            const int64_t mine = u + 2 * wv;
-            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx2_round<2>(G2, ld2, nsuper, Qd, tds, lut, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
-            u += 8;
-        } else {
-            const int64_t mine = u + wv;
-            const int nv = mine < u1 ? 1 : 0;
-            gqx2_round<1>(G2, ld2, nsuper, Qd, tds, lut, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
-            u += 4;
-        }
-    }
-    const float o = csum + __shfl_xor(csum, 32);
-    const float am = fmaxf(amax, __shfl_xor(amax, 32));
-    if (h == 0) { cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o; apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am; }
-}
-
-void launch_gq_x2(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
-                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                  int scale_out) {
-    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
-    const int64_t nsuper = Npad / 512;   // Npad is a multiple of 1024 in 2-bit mode -> even, and >= 8 stages
-    hipLaunchKernelGGL(k_gq_x2, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
-}
-
-// ================================================================================================
 // K2 with the digit planes of T' shared through LDS (int8-resident and packed genotypes).
 // The four waves of a workgroup own four adjacent 128-sample blocks and the SAME row range, so they consume the
 // same planes.  Wave w fetches plane d = w (1 KiB per 32-row block) into registers and writes it to a double-buffered

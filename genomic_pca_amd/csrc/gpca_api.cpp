@@ -677,8 +677,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     if (h->precision == GPCA_PREC_I8_EXACT) {
         {
             ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT && h->lds_planes >= 2) { launch_gq_x2(   /* measured slower than k_gq_2bit (3.8 vs 3.5 ms): opt-in only */h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
-            else if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
             else if (h->lds_planes && h->gq_dma) {
                 const int e = launch_gq_d(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out);
                 if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");

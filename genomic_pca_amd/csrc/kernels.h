@@ -136,10 +136,6 @@ void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, in
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                 int scale_out);
-// K1, packed genotypes, digit planes shared through LDS
-void launch_gq_x2(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
-                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                  int scale_out);
 // K1 with the digit planes of Q shared through LDS (int8-resident genotypes)
 void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
