@@ -462,11 +462,69 @@ void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, doubl
     if (L == 32) hipLaunchKernelGGL((k_gram<double, 32>), grid, blk, 0, st, X, rows, rpb, part);
     else hipLaunchKernelGGL((k_gram<double, 64>), grid, blk, 0, st, X, rows, rpb, part);
 }
+// Gram of the tall f32 factor (B = A Q, M rows) on the f64 matrix cores: W = X^T X as 16x16x4 MFMAs.  Lane (i = lane & 15,
+// k = lane >> 4) converts X[n + k][16 g + i] once and uses it both as the A element (X^T tile g) and as the B element
+// (X tile g); only the upper-triangular tiles are computed, the lower ones are mirrored on store.  Four waves take
+// interleaved 4-row groups and are combined through LDS in a fixed order.  (The VALU version spent 132 us on the
+// 128 MB factor -- LDS-read bound; this one is HBM-bound.)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <int L>
+__global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, int64_t rows, int64_t rpb,
+                                                   double* __restrict__ part) {
+    constexpr int G = L / 16, NT = G * (G + 1) / 2;
+    __shared__ double red[3][NT][64][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 15, k = lane >> 4;
+    f64x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
+    for (int64_t n = r0 + 16 * wv; n < r1; n += 64) {       // 16 rows per wave and trip: 4 MFMA k-steps
+        double x[4][G];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = n + 4 * u + k;
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[u][g] = row < r1 ? (double)X[row * L + 16 * g + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int t = 0;
+#pragma unroll
+            for (int ga = 0; ga < G; ++ga)
+#pragma unroll
+                for (int gc = ga; gc < G; ++gc, ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][ga], x[u][gc], acc[t], 0, 0, 0);
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wv - 1][t][lane][r] = acc[t][r];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    double* out = part + (int64_t)blockIdx.x * L * L;
+    int t = 0;
+#pragma unroll
+    for (int ga = 0; ga < G; ++ga)
+#pragma unroll
+        for (int gc = ga; gc < G; ++gc, ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = ((acc[t][r] + red[0][t][lane][r]) + red[1][t][lane][r]) + red[2][t][lane][r];
+                const int a = 16 * ga + 4 * r + k, c = 16 * gc + i;     // f64 16x16x4: D[4 r + lane / 16][lane % 16] (probe_mfma_f64.hip)
+                out[a * L + c] = v;
+                if (ga != gc) out[c * L + a] = v;
+            }
+}
 void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part) {
     const int64_t rpb = gram_rows_per_block(rows);
     const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
-    if (L == 32) hipLaunchKernelGGL((k_gram<float, 32>), grid, blk, 0, st, X, rows, rpb, part);
-    else hipLaunchKernelGGL((k_gram<float, 64>), grid, blk, 0, st, X, rows, rpb, part);
+    if (L == 32) hipLaunchKernelGGL((k_gram_mfma<32>), grid, blk, 0, st, X, rows, rpb, part);
+    else hipLaunchKernelGGL((k_gram_mfma<64>), grid, blk, 0, st, X, rows, rpb, part);
 }
 
 // X[n][:] <- X[n][:] Z, in place through an LDS row tile; optional f32 copy into Qout (pad rows zeroed)
@@ -487,52 +545,94 @@ __global__ __launch_bounds__(256) void k_apply_right(double* __restrict__ X, int
     if (n < rows) X[n * L + cc] = a;
     if (Qout && n < rows_pad) Qout[blocked_q_index(n, cc, L >> 5)] = (n < rows) ? (float)a : 0.f;
 }
-// CholeskyQR's small factorisation on the device: W (n x n, pitch ld, upper triangle used) = R^T R, Z = R^-1 (upper,
-// zero elsewhere, the whole ld x ld block written).  One workgroup, thread c owns column c; same operation order as a
-// row-by-row Cholesky-Crout on the host, so no host round trip (and no stream sync) sits between the Gram matrix and the
-// right-multiplication.  A non-positive pivot records (j + 1) in *flag (first failure wins) and the factorisation
-// carries on with pivot 1 so that nothing downstream spins or faults; the caller checks the flag once, at the end.
-__global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, int n, int ld, double* __restrict__ Zg,
+// CholeskyQR's small factorisation on the device: W (n x n, pitch NN, upper triangle used) = R^T R, Z = R^-1 (upper,
+// zero elsewhere, the whole NN x NN block written), so that no host round trip (and no stream sync) sits between the
+// Gram matrix and the right-multiplication.  ONE WAVE, everything in registers: lane c owns column c of R and of R^-1;
+// an element of another column is fetched with v_readlane (compile-time lane after full unrolling), so there is no
+// LDS traffic and no barrier -- a 1024-thread LDS version spent 50 us on its ~180 barriers and dependent LDS reads.
+//   * Cholesky, right-looking: step j scales row j by 1/sqrt(pivot) and subtracts its outer product from the trailing
+//     rows (each element sees the same subtractions, in the same order, as a row-by-row Cholesky-Crout).
+//   * R^-1: lane c back-substitutes R x = e_c from the bottom row up; x[k] = 0 for k > c falls out by itself.
+// Rows / columns n..NN-1 are treated as identity.  A non-positive pivot records (j + 1) in *flag (first failure wins)
+// and the factorisation carries on with pivot 1, so nothing downstream spins or faults; the caller checks the flag
+// once, at the end of the rSVD.
+// (volatile asm tied to the accumulator it feeds: left to itself the scheduler hoists all ~1000 broadcasts ahead of
+//  the FMAs that consume them and then spills ~1400 SGPRs through v_writelane)
+template <int LANE>
+__device__ __forceinline__ double lane_bcast(double v, double& dep) {
+    int lo, hi;
+    // the compiler's hazard recogniser does not look inside the string: the wait states a VALU-written VGPR needs before
+    // v_readlane reads it, and a VALU-written SGPR needs before a VALU reads it as an operand, are supplied here
+    asm volatile("s_nop 1\n\tv_readlane_b32 %0, %3, %5\n\tv_readlane_b32 %1, %4, %5\n\ts_nop 1"
+                 : "=s"(lo), "=s"(hi), "+v"(dep) : "v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(LANE));
+    return __hiloint2double(hi, lo);
+}
+// 1 / sqrt(x) in f64 from the hardware estimate and two Newton steps (the correctly rounded sqrt + divide pair costs
+// ~500 dependent cycles per pivot; this chain ~100)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+template <int NN, int J, int R>
+struct CholRow {   // col[r] -= R[j][r] * R[j][c] for r = R .. NN-1 (compile-time lanes)
+    static __device__ __forceinline__ void run(double (&col)[NN]) {
+        if constexpr (R < NN) { const double a = lane_bcast<R>(col[J], col[R]); col[R] -= a * col[J]; CholRow<NN, J, R + 1>::run(col); }
+    }
+};
+template <int NN, int J>
+struct CholStep {
+    static __device__ __forceinline__ void run(double (&col)[NN], double (&dinv)[NN], int c, int* flag) {
+        if constexpr (J < NN) {
+            double piv = lane_bcast<J>(col[J], col[J]);
+            if (!(piv > 0.0) || !isfinite(piv)) {
+                if (c == 0) atomicCAS(flag, 0, J + 1);
+                piv = 1.0;
+            }
+            dinv[J] = rsqrt_nr(piv);
+            col[J] = (c == J) ? piv * dinv[J] : col[J] * dinv[J];
+            CholRow<NN, J, J + 1>::run(col);
+            CholStep<NN, J + 1>::run(col, dinv, c, flag);
+        }
+    }
+};
+template <int NN, int I, int K>
+struct InvRow {
+    static __device__ __forceinline__ void run(const double (&col)[NN], const double (&x)[NN], double& acc) {
+        if constexpr (K < NN) { const double a = lane_bcast<K>(col[I], acc); acc -= a * x[K]; InvRow<NN, I, K + 1>::run(col, x, acc); }
+    }
+};
+template <int NN, int I>
+struct InvStep {
+    static __device__ __forceinline__ void run(const double (&col)[NN], double (&x)[NN], const double (&dinv)[NN], int c) {
+        if constexpr (I >= 0) {
+            double acc = (c == I) ? 1.0 : 0.0;
+            InvRow<NN, I, I + 1>::run(col, x, acc);
+            x[I] = acc * dinv[I];
+            InvStep<NN, I - 1>::run(col, x, dinv, c);
+        }
+    }
+};
+template <int NN>
+__global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, int n, double* __restrict__ Zg,
                                                  int* __restrict__ flag) {
-    __shared__ double R[64 * 64];
-    __shared__ double X[64 * 64];
     const int c = threadIdx.x;
-    for (int r = 0; r < ld; ++r) {
-        if (c < ld) { R[r * ld + c] = Wg[r * ld + c]; X[r * ld + c] = 0.0; }
+    double col[NN], x[NN], dinv[NN];
+#pragma unroll
+    for (int r = 0; r < NN; ++r) col[r] = Wg[r * NN + (c & (NN - 1))];      // (unconditional: the loads stay in flight together)
+#pragma unroll
+    for (int r = 0; r < NN; ++r) col[r] = (r < n && c < n) ? col[r] : ((r == c) ? 1.0 : 0.0);
+    CholStep<NN, 0>::run(col, dinv, c, flag);
+    InvStep<NN, NN - 1>::run(col, x, dinv, c);
+    if (c < NN) {
+#pragma unroll
+        for (int i = 0; i < NN; ++i) Zg[i * NN + c] = (i < n && c < n) ? x[i] : 0.0;
     }
-    for (int j = 0; j < n; ++j) {
-        __syncthreads();
-        double d = R[j * ld + j];
-        for (int k = 0; k < j; ++k) d -= R[k * ld + j] * R[k * ld + j];
-        if (!(d > 0.0) || !isfinite(d)) {
-            if (c == 0) atomicCAS(flag, 0, j + 1);
-            d = 1.0;
-        }
-        d = sqrt(d);
-        double s = 0.0;
-        if (c > j && c < n) {
-            s = R[j * ld + c];
-            for (int k = 0; k < j; ++k) s -= R[k * ld + j] * R[k * ld + c];
-        }
-        __syncthreads();
-        if (c == j) R[j * ld + j] = d;
-        else if (c > j && c < n) R[j * ld + c] = s / d;
-    }
-    __syncthreads();
-    if (c < n) {                      // column c of R^-1 by back substitution
-        X[c * ld + c] = 1.0 / R[c * ld + c];
-        for (int i = c - 1; i >= 0; --i) {
-            double s = 0.0;
-            for (int k = i + 1; k <= c; ++k) s += R[i * ld + k] * X[k * ld + c];
-            X[i * ld + c] = -s / R[i * ld + i];
-        }
-    }
-    __syncthreads();
-    for (int r = 0; r < ld; ++r)
-        if (c < ld) Zg[r * ld + c] = X[r * ld + c];
 }
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
-    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(64), 0, st, W, n, ld, Z, flag);
+    if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
+    else hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
 }
 
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,
@@ -543,40 +643,63 @@ void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, 
 }
 
 // out[n][kc] = sum_j X[row(n)][j] Z[j][kc].  One thread per row: the row sits in registers (L/4 16-byte loads), Z is
-// broadcast from LDS, K outputs are written as one contiguous run.  (HBM-bound: rows in, K values out.)
+// broadcast from LDS.  The f32 outputs of a block (256 rows x K, one contiguous run of the output) are staged in LDS and
+// written back coalesced -- per-thread runs of K floats at a K-float stride cost 6.7x write amplification (WRITE_SIZE
+// 538 MB for an 80 MB result).  The f64 output (scores: N rows only) is written directly.
 template <typename TX, int L>
 __global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, const int64_t* __restrict__ row_ids,
                                                   int64_t nrows, const double* __restrict__ Z, int K,
                                                   double* __restrict__ out64, float* __restrict__ out32) {
-    extern __shared__ double zsm[];          // Z [L][K]
+    extern __shared__ double zsm[];          // Z [L][K], then (f32 output only) the staging tile [256][K | 1]
+    float* osm = reinterpret_cast<float*>(zsm + L * K);
+    const int KP = K | 1;                    // odd pitch: conflict-free column writes
     for (int e = threadIdx.x; e < L * K; e += 256) zsm[e] = Z[e];
     __syncthreads();
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= nrows) return;
-    const int64_t src = row_ids ? row_ids[n] : n;
-    double x[L];
+    const int64_t n0 = (int64_t)blockIdx.x * 256;
+    const int64_t n = n0 + threadIdx.x;
+    if (n < nrows) {
+        const int64_t src = row_ids ? row_ids[n] : n;
+        double x[L];
 #pragma unroll
-    for (int j = 0; j < L; ++j) x[j] = (double)X[src * L + j];
-    for (int kc = 0; kc < K; ++kc) {
-        double a = 0.0;
+        for (int j = 0; j < L; ++j) x[j] = (double)X[src * L + j];
+        for (int kc = 0; kc < K; ++kc) {
+            double a = 0.0;
 #pragma unroll
-        for (int j = 0; j < L; ++j) a += x[j] * zsm[j * K + kc];
-        if (out64) out64[n * K + kc] = a;
-        if (out32) out32[n * K + kc] = (float)a;
+            for (int j = 0; j < L; ++j) a += x[j] * zsm[j * K + kc];
+            if (out64) out64[n * K + kc] = a;
+            if (out32) osm[threadIdx.x * KP + kc] = (float)a;
+        }
     }
+    if (!out32) return;
+    __syncthreads();
+    const int64_t rows_here = (nrows - n0 < 256) ? nrows - n0 : 256;
+    const int total = (int)rows_here * K;
+    float* dst = out32 + n0 * K;
+    for (int e = threadIdx.x; e < total; e += 256) dst[e] = osm[(e / K) * KP + (e % K)];
 }
+static size_t rightmul_lds(int L, int K, bool f32out) { return sizeof(double) * L * K + (f32out ? sizeof(float) * 256 * (size_t)(K | 1) : 0); }
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
                          float* out32) {
     const dim3 grid((unsigned)((rows + 255) / 256)), blk(256);
-    if (L == 32) hipLaunchKernelGGL((k_rightmul<double, 32>), grid, blk, sizeof(double) * L * K, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
-    else hipLaunchKernelGGL((k_rightmul<double, 64>), grid, blk, sizeof(double) * L * K, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
+    const size_t lds = rightmul_lds(L, K, out32 != nullptr);
+    if (L == 32) hipLaunchKernelGGL((k_rightmul<double, 32>), grid, blk, lds, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
+    else {
+        static const int a = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)a;
+        hipLaunchKernelGGL((k_rightmul<double, 64>), grid, blk, lds, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
+    }
 }
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
                                 const double* Z, int K, float* out32) {
     if (nrows == 0) return;
     const dim3 grid((unsigned)((nrows + 255) / 256)), blk(256);
-    if (L == 32) hipLaunchKernelGGL((k_rightmul<float, 32>), grid, blk, sizeof(double) * L * K, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
-    else hipLaunchKernelGGL((k_rightmul<float, 64>), grid, blk, sizeof(double) * L * K, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
+    const size_t lds = rightmul_lds(L, K, true);
+    if (L == 32) hipLaunchKernelGGL((k_rightmul<float, 32>), grid, blk, lds, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
+    else {
+        static const int a = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)a;
+        hipLaunchKernelGGL((k_rightmul<float, 64>), grid, blk, lds, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
+    }
 }
 
 constexpr int kColsumRowsPerBlock = 256;

@@ -606,3 +606,29 @@ def test_wide_sample_axis_all_paths(gpca, oracle):
             assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
             assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
             assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]) < TOL_PC
+
+
+# ------------------------------------------------------------------------------------------------
+# bitwise repeatability: hand-counted waits (LDS-DMA K1) and inline-asm wait states show up as runs that differ
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec,store,M,N,k", [("i8", "int8", 300_000, 2048, 20), ("i8", "int8", 40_000, 10_000, 10),
+                                               ("i8", "2bit", 300_000, 2048, 20), ("f32", "int8", 300_000, 2048, 20),
+                                               ("f32", "int8", 100_000, 1024, 40)])
+def test_rsvd_bitwise_repeatable(gpca, prec, store, M, N, k):
+    """Every kernel has a fixed reduction tree and no float atomics, so the same call must return the same bits.  Sizes
+    are chosen so that each K1 workgroup runs full LDS-DMA rounds (> 8 row units per workgroup)."""
+    from genomic_pca_amd import _lib
+    p = _lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA
+    s = _lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8
+    th = gpca.synth_thresholds(M, 3, seed=7)
+    with gpca.GpcaEngine(precision=p, storage=s) as e:
+        e.synth_genotypes(M, N, 7, th)
+        e.snp_stats(gpca.QcConfig.none())
+        ref = None
+        for _ in range(6):
+            e.rsvd(k, 10, 2, seed=3)
+            cur = (e.eigenvalues(), e.scores(f64=True), e.loadings())
+            if ref is None:
+                ref = cur
+            else:
+                assert all(np.array_equal(a, b) for a, b in zip(ref, cur))
