@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict_
     __syncthreads();
     if (pg != 0) return;
     for (int g = 1; g < 32; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
-    const double S = 0.49 * 268435456.0;   // 0.49 * 128^4
+    const double S = kDigitScale;
     scale[cc] = a > 0.0 ? a / S : 0.0;
     inv[cc] = a > 0.0 ? S / a : 0.0;
 }
@@ -1283,6 +1283,11 @@ void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, in
     hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, apart, P, scale, inv);
     const int64_t blocks = rows_pad / 32;
     hipLaunchKernelGGL((k_quantize<float>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout);
+}
+// quantise X (f64) with a column scale that is already on the device (k_finish_q)
+void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout) {
+    const int64_t blocks = rows_pad / 32;
+    hipLaunchKernelGGL((k_quantize<double>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, inv, Xd, layout);
 }
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
                          double* inv, int8_t* Xd, int layout) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout); }

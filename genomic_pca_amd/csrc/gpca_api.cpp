@@ -710,18 +710,17 @@ static int stage_orth(gpca_handle* h) {
         HIPCHK(hipGetLastError());
         launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
         HIPCHK(hipGetLastError());
-        launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, round == 1 ? h->dQ : nullptr, h->ldg);
+        if (round == 0) launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, nullptr, h->ldg);
+        else launch_apply_right_tail(h->st, h->dY, h->N, L, h->dZ, h->dQ, h->ldg, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L);
         HIPCHK(hipGetLastError());
     }
-    const int64_t parts = colsum_num_parts(h->N);
-    launch_colsum_f64(h->st, h->dY, h->N, L, h->d_part64);   // dY now holds the orthonormal basis in f64
+    // dY now holds the orthonormal basis in f64: s = Q^T 1 and (exact-integer path) the digit scale of Q, then its planes
+    const bool i8 = h->precision == GPCA_PREC_I8_EXACT;
+    launch_finish_q(h->st, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L, tail_num_parts(h->ldg), L, h->d_s64, h->d_s32,
+                    i8 ? h->d_qscale : nullptr, i8 ? h->d_qinv : nullptr);
     HIPCHK(hipGetLastError());
-    launch_sum_partials_f64(h->st, h->d_part64, parts, L, h->d_s64, h->d_scratch64);
-    HIPCHK(hipGetLastError());
-    launch_f64_to_f32(h->st, h->d_s64, h->d_s32, L);
-    HIPCHK(hipGetLastError());
-    if (h->precision == GPCA_PREC_I8_EXACT) {   // digit planes of the basis for the int8 G Q product
-        launch_quantize_f64(h->st, h->dY, h->N, h->ldg, h->d_part64, h->d_qscale, h->d_qinv, h->dQd, h->storage == GPCA_STORE_2BIT ? 1 : 0);
+    if (i8) {
+        launch_quantize_f64_prescaled(h->st, h->dY, h->N, h->ldg, h->d_qinv, h->dQd, h->storage == GPCA_STORE_2BIT ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     return GPCA_OK;
@@ -740,7 +739,7 @@ static int ensure_workspace(gpca_handle* h) {
     const int64_t cparts = std::max(h->gqplan.waves, omega_num_parts(h->Mpad));
     CHK(ensure(h, h->d_cpart, h->cap_cpart, (size_t)cparts * L));
     CHK(ensure(h, h->dY, h->cap_Y, (size_t)N * L));
-    const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L, absmax_num_parts(h->Mpad) * (int64_t)32});
+    const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L, absmax_num_parts(h->Mpad) * (int64_t)32, 2 * tail_num_parts(Npad) * (int64_t)L});
     CHK(ensure(h, h->d_part64, h->cap_part64, (size_t)p64));
     if (!h->d_c) {
         HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));

@@ -72,6 +72,14 @@ int64_t gram_num_parts(int64_t rows);
 void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part);
 void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part);
 // X[n][:] <- X[n][:] * Z  (Z: [L][L] f64, in place); optionally also the blocked f32 basis Qb (rows_pad rows, pad rows zeroed)
+// the digit planes hold round(x * S / colmax): S = 0.49 * 128^4 keeps every digit of the signed base-128 expansion in int8
+constexpr double kDigitScale = 0.49 * 268435456.0;
+// last right-multiplication of CholeskyQR2 + partials of Q^T 1 and of the column abs-max; k_finish_q reduces them
+int64_t tail_num_parts(int64_t rows_pad);
+void launch_apply_right_tail(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout, int64_t rows_pad,
+                             double* csum_part, double* amax_part);
+void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax_part, int64_t P, int L, double* s64, float* s32,
+                     double* scale, double* inv);
 // W = R^T R (n x n, pitch ld <= 64), Z = R^-1; *flag = j + 1 on a non-positive pivot (first failure wins)
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag);
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qb,
@@ -129,6 +137,7 @@ void launch_standardize_block_2bit(hipStream_t st, const uint8_t* G2, int64_t ld
 void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                     const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
                     double* apart, int scale_out);
+void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout);
 // quantise X whose column abs-max partials [P][32] were already produced by the kernel that wrote it (K1 epilogue)
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
                                 double* scale, double* inv, int8_t* Xd, int layout);

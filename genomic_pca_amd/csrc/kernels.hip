@@ -545,6 +545,71 @@ __global__ __launch_bounds__(256) void k_apply_right(double* __restrict__ X, int
     if (n < rows) X[n * L + cc] = a;
     if (Qout && n < rows_pad) Qout[blocked_q_index(n, cc, L >> 5)] = (n < rows) ? (float)a : 0.f;
 }
+// Last right-multiplication of CholeskyQR2, fused with everything the next stage needs from the orthonormal basis:
+// X <- X Z in place (f64), the f32 blocked copy Qb (pad rows zeroed), and per-workgroup partials of the column sums
+// (s = Q^T 1, the centring term of A Q) and of the column abs-max (digit scale of the exact-integer path).  A workgroup
+// walks kTailRows rows so that Z is staged once per 64 rows and the partial arrays stay small; k_finish_q reduces them
+// in a fixed order.  Replaces k_colsum + 2 x k_sum_partials + k_f64_to_f32 + k_col_absmax + k_finish_scale.
+constexpr int kTailRows = 64;
+int64_t tail_num_parts(int64_t rows_pad) { return (rows_pad + kTailRows - 1) / kTailRows; }
+template <int L>
+__global__ __launch_bounds__(256) void k_apply_right_tail(double* __restrict__ X, int64_t rows, const double* __restrict__ Z,
+                                                          float* __restrict__ Qout, int64_t rows_pad,
+                                                          double* __restrict__ csum_part, double* __restrict__ amax_part) {
+    constexpr int RPB = 256 / L;
+    __shared__ double zs[L][L + 1];
+    __shared__ double xs[RPB][L];
+    __shared__ double red[2][RPB][L];
+    for (int e = threadIdx.x; e < L * L; e += 256) zs[e / L][e % L] = Z[e];
+    const int rr = threadIdx.x / L, cc = threadIdx.x % L;
+    double cs = 0.0, am = 0.0;
+    const int64_t n0 = (int64_t)blockIdx.x * kTailRows;
+    for (int sub = 0; sub < kTailRows; sub += RPB) {
+        const int64_t n = n0 + sub + rr;
+        __syncthreads();                                   // zs ready (first trip) / xs free (later trips)
+        xs[rr][cc] = (n < rows) ? X[n * L + cc] : 0.0;
+        __syncthreads();
+        double a = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < L; ++j) a += xs[rr][j] * zs[j][cc];
+        if (n < rows) { X[n * L + cc] = a; cs += a; am = fmax(am, fabs(a)); }
+        if (Qout && n < rows_pad) Qout[blocked_q_index(n, cc, L >> 5)] = (n < rows) ? (float)a : 0.f;
+    }
+    red[0][rr][cc] = cs; red[1][rr][cc] = am;
+    __syncthreads();
+    if (rr == 0) {
+        for (int g = 1; g < RPB; ++g) { cs += red[0][g][cc]; am = fmax(am, red[1][g][cc]); }
+        csum_part[(int64_t)blockIdx.x * L + cc] = cs;
+        amax_part[(int64_t)blockIdx.x * L + cc] = am;
+    }
+}
+void launch_apply_right_tail(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout, int64_t rows_pad,
+                             double* csum_part, double* amax_part) {
+    const dim3 grid((unsigned)tail_num_parts(rows_pad)), blk(256);
+    if (L == 32) hipLaunchKernelGGL((k_apply_right_tail<32>), grid, blk, 0, st, X, rows, Z, Qout, rows_pad, csum_part, amax_part);
+    else hipLaunchKernelGGL((k_apply_right_tail<64>), grid, blk, 0, st, X, rows, Z, Qout, rows_pad, csum_part, amax_part);
+}
+// s64/s32[c] = sum_p csum_part[p][c] (fixed order);  digit scale of column c from max_p amax_part[p][c]:
+// scale = max / S, inv = S / max (0 for an all-zero column), S = kDigitScale.  One workgroup.
+__global__ __launch_bounds__(1024) void k_finish_q(const double* __restrict__ csum_part, const double* __restrict__ amax_part,
+                                                   int64_t P, int L, double* __restrict__ s64, float* __restrict__ s32,
+                                                   double* __restrict__ scale, double* __restrict__ inv) {
+    __shared__ double rs[1024], rm[1024];
+    const int cc = threadIdx.x % L, pg = threadIdx.x / L, G = 1024 / L;
+    double a = 0.0, m = 0.0;
+    for (int64_t p = pg; p < P; p += G) { a += csum_part[p * L + cc]; m = fmax(m, amax_part[p * L + cc]); }
+    rs[threadIdx.x] = a; rm[threadIdx.x] = m;
+    __syncthreads();
+    if (pg != 0) return;
+    for (int g = 1; g < G; ++g) { a += rs[g * L + cc]; m = fmax(m, rm[g * L + cc]); }
+    s64[cc] = a; s32[cc] = (float)a;
+    if (scale) { scale[cc] = m > 0.0 ? m / kDigitScale : 0.0; inv[cc] = m > 0.0 ? kDigitScale / m : 0.0; }
+}
+void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax_part, int64_t P, int L, double* s64, float* s32,
+                     double* scale, double* inv) {
+    hipLaunchKernelGGL(k_finish_q, dim3(1), dim3(1024), 0, st, csum_part, amax_part, P, L, s64, s32, scale, inv);
+}
+
 // CholeskyQR's small factorisation on the device: W (n x n, pitch NN, upper triangle used) = R^T R, Z = R^-1 (upper,
 // zero elsewhere, the whole NN x NN block written), so that no host round trip (and no stream sync) sits between the
 // Gram matrix and the right-multiplication.  ONE WAVE, everything in registers: lane c owns column c of R and of R^-1;

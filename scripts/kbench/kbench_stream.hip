@@ -92,6 +92,58 @@ __global__ __launch_bounds__(256, 1) void k_read_rows_j(const char* __restrict__
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
 }
+// K2's access pattern: a wave owns a 128-byte column slab of a row range; lane (c = lane & 31, h = lane >> 5) loads the
+// dword of row 16 h + i, bytes 4 c .. 4 c + 3 (one wave instruction = 2 rows x 128 B), 16 i per 32-row block, NB blocks in
+// flight.  Four waves of a workgroup take adjacent slabs.  NT: non-temporal.
+template <int NB, int NT>
+__global__ __launch_bounds__(256, 1) void k_read_cols(const char* __restrict__ p, int64_t M, int64_t ld, int64_t rows_per_wg, int* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ngroups = ld / 512;
+    const int64_t ngroup = blockIdx.x % ngroups, wchunk = blockIdx.x / ngroups;
+    const int64_t m0 = wchunk * rows_per_wg, m1 = (m0 + rows_per_wg < M) ? m0 + rows_per_wg : M;
+    const char* base = p + (ngroup * 4 + wv) * 128 + 4 * (lane & 31) + (int64_t)(16 * (lane >> 5)) * ld;
+    unsigned acc = 0;
+    for (int64_t m = m0; m + 32 * NB <= m1; m += 32 * NB) {
+        unsigned v[NB][16];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned* q = reinterpret_cast<const unsigned*>(base + (m + 32 * b + i) * ld);
+                v[b][i] = NT ? __builtin_nontemporal_load(q) : *q;
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc ^= v[b][i];
+    }
+    if (acc == 0x12345678u) out[0] = 1;
+}
+// same slab ownership, but the bytes arrive as 8-row x 128-byte b128 pieces (what an LDS-DMA version would request)
+template <int NB, int NT>
+__global__ __launch_bounds__(256, 1) void k_read_cols_wide(const char* __restrict__ p, int64_t M, int64_t ld, int64_t rows_per_wg, int* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ngroups = ld / 512;
+    const int64_t ngroup = blockIdx.x % ngroups, wchunk = blockIdx.x / ngroups;
+    const int64_t m0 = wchunk * rows_per_wg, m1 = (m0 + rows_per_wg < M) ? m0 + rows_per_wg : M;
+    const char* base = p + (ngroup * 4 + wv) * 128 + 16 * (lane & 7) + (int64_t)(lane >> 3) * ld;
+    i32x4 acc = {0, 0, 0, 0};
+    for (int64_t m = m0; m + 32 * NB <= m1; m += 32 * NB) {
+        i32x4 v[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i32x4* q = reinterpret_cast<const i32x4*>(base + (m + 32 * b + 8 * i) * ld);
+                v[b][i] = NT ? __builtin_nontemporal_load(q) : *q;
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc ^= v[b][i];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
 template <typename F> static float time_ms(F f, int reps) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -115,7 +167,7 @@ int main() {
     }
     {
         const int64_t M = 1000064, ld = 10240;   // 10.24 GB, the C2 genotype matrix
-        const int wgs[] = {256, 512, 1024};
+        const int wgs[] = {256};
         for (int g : wgs) {
             float a4 = time_ms([&] { hipLaunchKernelGGL((k_read_rows<4, 0>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
             float a2 = time_ms([&] { hipLaunchKernelGGL((k_read_rows<2, 0>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
@@ -135,6 +187,19 @@ int main() {
                    gb / c1 * 1e-9, gb / c2 * 1e-9, gb / c3 * 1e-9, gb / c4 * 1e-9, gb / c5 * 1e-9, gb / c6 * 1e-9);
             fflush(stdout);
         }
+    }
+    {
+        const int64_t M = 1000064, ld = 10240, rpw = 40064;   // K2's plan at C2: 20 n-groups x 25 row chunks = 500 workgroups
+        const int g = 500;
+        const double gb = (double)M * ld;
+        float a0 = time_ms([&] { hipLaunchKernelGGL((k_read_cols<4, 0>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
+        float a1 = time_ms([&] { hipLaunchKernelGGL((k_read_cols<4, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
+        float a2 = time_ms([&] { hipLaunchKernelGGL((k_read_cols<2, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
+        float b0 = time_ms([&] { hipLaunchKernelGGL((k_read_cols_wide<4, 0>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
+        float b1 = time_ms([&] { hipLaunchKernelGGL((k_read_cols_wide<4, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
+        float b2 = time_ms([&] { hipLaunchKernelGGL((k_read_cols_wide<8, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
+        printf("column slabs (K2 plan): dword loads NB4 %.2f  NB4 nt %.2f  NB2 nt %.2f | b128 pieces NB4 %.2f  NB4 nt %.2f  NB8 nt %.2f TB/s\n",
+               gb / a0 * 1e-9, gb / a1 * 1e-9, gb / a2 * 1e-9, gb / b0 * 1e-9, gb / b1 * 1e-9, gb / b2 * 1e-9);
     }
     return 0;
 }
