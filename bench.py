@@ -96,7 +96,7 @@ def pmc_traffic(kernel):
     scripts/gpu_profile.sh: separate rocprofv3 --pmc runs).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950 wide coalesced reads (calibrated on k_snp_stats: 2 x 5120.1 MB = the 10 240 MB it streams)."""
     import glob
-    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit", "gemm_GtT_2bit": "gpca::k_gtt_x<true>", "gemm_GQ_i8": "gpca::k_gq_d", "gemm_GtT_i8": "gpca::k_gtt_x<false>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
+    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit", "gemm_GtT_2bit": "gpca::k_gtt_x<true>", "gemm_GQ_i8": "gpca::k_gq_d<1>", "gemm_GtT_i8": "gpca::k_gtt_d<1>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
            "gemm_GtT_f32": "gpca::k_gtt_f32<1>"}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not key or not files:

@@ -1189,6 +1189,157 @@ __global__ __launch_bounds__(256, 1) void k_gtt_x(const uint8_t* __restrict__ Gb
     }
 }
 
+// ================================================================================================
+// K2 by LDS-DMA (int8-resident genotypes).  k_gtt_x keeps four 32-row blocks of dwords per wave in registers (64 VGPRs)
+// plus 32 VGPRs of digit planes on their way to LDS, fills the 256-VGPR budget and so has ~12 KiB per wave in flight:
+// latency-bound at ~5.5 TB/s while the same request pattern alone streams at 6.9.  Here both streams arrive by
+// `buffer_load_dwordx4 ... lds` (no VGPR destination): a ring of 6 row-major [32 rows][128 B] units per wave (20 KiB in
+// flight) and wave w's plane of T' for the next stage; the dwords of a block are read back from LDS two phases before
+// they are multiplied (16 ds_read_b32, rows contiguous across lanes: conflict-free) and transposed by the same v_perm
+// micro-steps in the shadow of the MFMAs.
+//   phase b:  [vmcnt] read block b+2 from LDS | 16 MFMAs of block b || T' planes + decode of block b+1 | re-fill the slot
+//             of block b+1 (all of its reads have been consumed) with block b+7.
+//   before the last phase of stage s (4 phases): vmcnt + workgroup barrier -> T'(s+1) visible, slot of T'(s) free:
+//             issue T'(s+2).
+// Hand-counted completion (the DMAs are invisible to the compiler).  Issue order in steady state:
+//   ... T'(s+2), G(4s+10), G(4s+11), G(4s+12), G(4s+13), T'(s+3), ...      (4 instructions each)
+//   - barrier of stage s: T'(s+1) was issued one stage earlier, 4 unit fills are younger           -> vmcnt(16)
+//   - start of phase b: G(b+2) must have landed; younger: G(b+3..b+6) and one plane batch, two when b = 3 mod 4
+//                                                                                                 -> vmcnt(20) / (24)
+// The prologue issues G0 G1 T'0 G2 G3 G4 G5 T'1, loads blocks 0 and 1 into registers, then G6: the same counts hold.
+// ================================================================================================
+template <int NT>
+__device__ __forceinline__ void gtd_issue_g(const uint8_t* gp, int64_t ldr, int64_t blk, int64_t kblocks, uint32_t lds_slot, uint32_t gvo) {
+    const int64_t ub = blk < kblocks ? blk : 0;
+    const i32x4 rg = gqd_rsrc(gp + ub * 32 * ldr);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot's last LDS reads have returned
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gqd_dma<NT>(lds_slot + 1024u * i, gvo, rg, 8u * i * (uint32_t)ldr);
+}
+__device__ __forceinline__ void gtd_issue_t(const int8_t* tp, int64_t st, int64_t nstage, uint32_t lds_t_slot, uint32_t tvo) {
+    constexpr uint32_t TKB = kDigits * 1024;
+    const int64_t us = st < nstage ? st : 0;
+    const i32x4 rt = gqd_rsrc(tp + us * 4 * TKB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gqd_dma<0>(lds_t_slot + (uint32_t)(j * kDigits) * 1024u, tvo, rt, j * TKB);
+}
+__device__ __forceinline__ void gtd_read_g(GttXG<false>& b, const char* unit) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b.g[i] = *reinterpret_cast<const unsigned*>(unit + i * 128);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Mpad, int64_t Npad,
+                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
+                                                   int64_t ngroups, int64_t rows_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
+    GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t ngroup = blockIdx.x % ngroups;
+    const int64_t wchunk = blockIdx.x / ngroups;
+    const int64_t nblock = ngroup * 4 + wv;
+    int64_t n0 = nblock * 128;
+    const bool live = n0 < Npad;          // a dead wave (ragged last group) still moves planes and joins the barriers
+    if (!live) n0 = 0;
+    const int64_t m_begin = wchunk * rows_per_wave;
+    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
+    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
+    const int64_t nstage = kblocks >> 2;
+
+    i32x16 acc[4][kDigits];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    constexpr uint32_t TKB = kDigits * 1024;
+    const uint8_t* gp = Gb + m_begin * ldr + n0;
+    const int8_t* tp = Td + (m_begin >> 5) * TKB + wv * 1024;    // this wave's plane
+    const uint32_t gvo = (uint32_t)(lane >> 3) * (uint32_t)ldr + 16u * (uint32_t)(lane & 7);
+    const uint32_t tvo = (uint32_t)(lane * 16);
+    const uint32_t lds_t = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
+    const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (kGqdSlots * 4096u);
+    const char* gl = reinterpret_cast<const char*>(&sm->g[wv][0][0]) + (16 * h) * 128 + 4 * c;   // this lane's dword column
+    i32x4 (*tds)[4][kDigits][64] = sm->q;
+
+    GttXG<false> GA, GB;
+    Gtt2Ops OA, OB;
+    GttXT TA, TB;
+    gtd_issue_g<NT>(gp, ldr, 0, kblocks, lds_g + 0u * 4096u, gvo);
+    gtd_issue_g<NT>(gp, ldr, 1, kblocks, lds_g + 1u * 4096u, gvo);
+    gtd_issue_t(tp, 0, nstage, lds_t, tvo);
+    gtd_issue_g<NT>(gp, ldr, 2, kblocks, lds_g + 2u * 4096u, gvo);
+    gtd_issue_g<NT>(gp, ldr, 3, kblocks, lds_g + 3u * 4096u, gvo);
+    gtd_issue_g<NT>(gp, ldr, 4, kblocks, lds_g + 4u * 4096u, gvo);
+    gtd_issue_g<NT>(gp, ldr, 5, kblocks, lds_g + 5u * 4096u, gvo);
+    gtd_issue_t(tp, 1, nstage, lds_t + 4u * TKB, tvo);
+    asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");      // G0, G1 and every wave's plane of T'(0) landed
+    gtd_read_g(GA, gl);
+    gtd_read_g(GB, gl + 4096);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) TA.t[d] = tds[0][0][d][lane];
+    gttx_decode<false>(GA, OA, 0u);
+    asm volatile("" :: "v"(GB.g[15]));
+    gtd_issue_g<NT>(gp, ldr, 6, kblocks, lds_g + 0u * 4096u, gvo);
+    uint32_t s1 = 1;            // ring slot of block b + 1 (re-filled at the end of phase b)
+    int64_t ib = 7;             // block that goes into it
+
+    // one phase: TC/OC = operands of block b; GN (registers of block b+1) -> ON, TN; GR receives block b+2
+#define GTD_PHASE(TC, OC, GN, ON, TN, GR, W, TSLOT, TBLK)                                                  \
+    {                                                                                                    \
+        const uint32_t s2_ = s1 == kGqdSlots - 1 ? 0u : s1 + 1u;                                         \
+        gqd_wait_vm<W>();                                                                                \
+        gtd_read_g(GR, gl + s2_ * 4096u);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gttx_phase<false>(TC, OC, acc, GN, ON, TN, &tds[(TSLOT)][(TBLK)][0][lane], 0u);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gtd_issue_g<NT>(gp, ldr, ib, kblocks, lds_g + s1 * 4096u, gvo);                                  \
+        ++ib; s1 = s2_;                                                                                  \
+    }
+    for (int64_t st = 0; st < nstage; ++st) {
+        const int slot = (int)(st & 1);
+        GTD_PHASE(TA, OA, GB, OB, TB, GA, 20, slot, 1)
+        GTD_PHASE(TB, OB, GA, OA, TA, GB, 20, slot, 2)
+        GTD_PHASE(TA, OA, GB, OB, TB, GA, 20, slot, 3)
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");   // T'(st+1) visible; everyone is done with T'(st)
+        gtd_issue_t(tp, st + 2, nstage, lds_t + (uint32_t)slot * 4u * TKB, tvo);
+        GTD_PHASE(TB, OB, GA, OA, TA, GB, 24, slot ^ 1, 0)
+    }
+#undef GTD_PHASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after this workgroup's LDS is released
+    if (!live) return;
+    double* yp = Ypart + (wchunk * Npad) * 32;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t n = n0 + 4 * c + t;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
+            double2 o;
+            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
+            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
+        }
+    }
+}
+
+int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
+                 const Gtt8Plan& plan) {
+    static const int attr0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_d<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)sizeof(GqdSmem));
+    static const int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_d<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)sizeof(GqdSmem));
+    if (attr0 != 0 || attr1 != 0) return attr0 ? attr0 : attr1;
+    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    const dim3 grid((unsigned)plan.grid), blk(256);
+    if (g_dma_nt) hipLaunchKernelGGL(k_gtt_d<1>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+    else hipLaunchKernelGGL(k_gtt_d<0>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+    return 0;
+}
+
 void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const int8_t* Td,
                   double* Ypart, const Gtt8Plan& plan) {
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;

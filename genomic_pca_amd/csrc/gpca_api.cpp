@@ -91,9 +91,10 @@ struct gpca_handle {
     Gtt8Plan plan8{};
     // exact-integer path
     int8_t *dQd = nullptr, *dTd = nullptr;
-    double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false;   // column abs-max partials of T' from the K1 epilogue
+    double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false; int64_t apart_parts = 0;   // column abs-max partials of T' from the K1 epilogue
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
+    int gtt_dma = 1;      // K2 (int8-resident) by LDS-DMA (GPCA_GTT_DMA=0: register-staged k_gtt_x)
     int gq_dma = 1;       // K1 (int8-resident) genotype loads by LDS-DMA, full-line pieces (GPCA_GQ_DMA=0: register-staged k_gq_x)
     int lds_planes = 1;   // share the digit planes of the exact GEMMs through LDS (GPCA_LDS_PLANES=0 disables)
     int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
@@ -199,6 +200,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (const char* e = getenv("GPCA_GTT_WAVES")) h->gtt_waves_target = std::max(4, atoi(e));
     if (const char* e = getenv("GPCA_LDS_PLANES")) h->lds_planes = atoi(e);
     if (const char* e = getenv("GPCA_GQ_DMA")) h->gq_dma = atoi(e);
+    if (const char* e = getenv("GPCA_GTT_DMA")) h->gtt_dma = atoi(e);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
         delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
     }
@@ -645,13 +647,17 @@ static int stage_AtT(gpca_handle* h) {
     const double elems = (double)h->M * (double)h->N;
     if (h->precision == GPCA_PREC_I8_EXACT) {
         // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64
-        if (h->apart_valid) launch_quantize_f32_premax(h->st, h->dT, h->Mpad, h->Mpad, h->d_apart, h->gqplan.waves, h->d_tscale, h->d_tinv, h->dTd, 0);
+        if (h->apart_valid) launch_quantize_f32_premax(h->st, h->dT, h->Mpad, h->Mpad, h->d_apart, h->apart_parts, h->d_tscale, h->d_tinv, h->dTd, 0);
         else launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd);
         h->apart_valid = false;
         HIPCHK(hipGetLastError());
         {
             ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->lds_planes) launch_gtt_x(h->st, h->storage == GPCA_STORE_2BIT ? (const void*)h->dG2 : (const void*)h->dG, h->storage == GPCA_STORE_2BIT,
+            if (h->lds_planes && h->gtt_dma && h->storage != GPCA_STORE_2BIT) {
+                const int e = launch_gtt_d(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+                if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
+            }
+            else if (h->lds_planes) launch_gtt_x(h->st, h->storage == GPCA_STORE_2BIT ? (const void*)h->dG2 : (const void*)h->dG, h->storage == GPCA_STORE_2BIT,
                                             h->storage == GPCA_STORE_2BIT ? h->ld2 : h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
             else if (h->storage == GPCA_STORE_2BIT) launch_gtt_2bit(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
             else launch_gtt_i8(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
@@ -677,13 +683,13 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     if (h->precision == GPCA_PREC_I8_EXACT) {
         {
             ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves; }
             else if (h->lds_planes && h->gq_dma) {
                 const int e = launch_gq_d(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out);
                 if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
-                h->apart_valid = scale_out != 0;
+                h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves;
             }
-            else if (h->lds_planes) { launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; }
+            else if (h->lds_planes) { launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves; }
             else launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
         }
         HIPCHK(hipGetLastError());
@@ -792,8 +798,9 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     // 1. sketch: T' = r o Omega, c = b^T Omega;  Y = A^T Omega;  Q = orth(Y)
     {
         ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
-        if (h->precision == GPCA_PREC_I8_EXACT) launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart, 0);
-        else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart);
+        if (h->precision == GPCA_PREC_I8_EXACT) HIPCHK(hipMemsetAsync(h->d_apart, 0, 32 * 8, h->st));
+        if (h->precision == GPCA_PREC_I8_EXACT) { launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart, h->d_apart, 0); h->apart_valid = true; h->apart_parts = 1; }
+        else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart, nullptr, 1);
     }
     HIPCHK(hipGetLastError());
     CHK(stage_sum_c(h, omega_num_parts(h->Mpad)));

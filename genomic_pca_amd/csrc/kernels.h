@@ -46,7 +46,7 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
 // sketch operand: Tb (blocked, all Mpad rows) = r_i * Omega[i][j] (j < l, else 0); cpart[wave][j] = sum_i b_i Omega[i][j]
 int64_t omega_num_parts(int64_t Mpad);
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
-                  const float* r, const float* b, float* Tb, float* cpart, int blocked = 1);
+                  const float* r, const float* b, float* Tb, float* cpart, double* apart, int blocked = 1);
 
 // K1: T = r o (G Q) + b s^T.  Tb != NULL: write r o T blocked into Tb and cpart[wave][j] = sum_i b_i T_ij
 // (power iteration); Tb == NULL: write T row-major into Tout (projection B = A Q).  Qb is the blocked basis.
@@ -141,6 +141,9 @@ void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows
 // quantise X whose column abs-max partials [P][32] were already produced by the kernel that wrote it (K1 epilogue)
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
                                 double* scale, double* inv, int8_t* Xd, int layout);
+// K2 with genotypes and digit planes brought in by LDS-DMA (int8-resident); returns a hipError_t value (0 = ok)
+int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
+                 const Gtt8Plan& plan);
 // K1 with the genotypes brought in by LDS-DMA (full-line pieces); returns a hipError_t value (0 = ok)
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,

@@ -289,15 +289,22 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
 // ------------------------------------------------------------------------------------------------
 int64_t omega_num_parts(int64_t Mpad) { return (Mpad + 63) / 64; }
 
-__global__ __launch_bounds__(256) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
+__global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
                                                const float* __restrict__ r, const float* __restrict__ b,
-                                               float* __restrict__ Tb, float* __restrict__ cpart, int blocked) {
-    __shared__ float red[4][64];
+                                               float* __restrict__ Tb, float* __restrict__ cpart, double* __restrict__ apart,
+                                               int blocked) {
+    // Each lane draws the L normals of its own SNP row; the wave's 64 x L tile is staged in LDS (pitch L + 1) so that
+    //   * T' = r o Omega leaves as full rows, lane-contiguous (a lane writing its row 4 bytes at a time at a 128-byte
+    //     stride cost 4.3x write amplification), and
+    //   * the wave's partial of c = b^T Omega is a conflict-free column walk instead of 6 cross-lane steps per column.
+    __shared__ float zt[2][64][65];
+    __shared__ float rs[2][64], bs[2][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t i = wave * 64 + lane;
+    const int64_t wave = (int64_t)blockIdx.x * 2 + wv;
+    const int64_t i0 = wave * 64, i = i0 + lane;
     const bool live = i < M;
-    const float ri = live ? r[i] : 0.f, bi = live ? b[i] : 0.f;
+    rs[wv][lane] = live ? r[i] : 0.f;
+    bs[wv][lane] = live ? b[i] : 0.f;
     const uint64_t gi = (uint64_t)(i + snp_offset);
     const int LT = L >> 5;
     for (int jq = 0; jq < L / 4; ++jq) {
@@ -315,22 +322,54 @@ __global__ __launch_bounds__(256) void k_omega(int64_t M, int64_t Mpad, int l, i
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float zf = (4 * jq + t < l) ? (float)z[t] : 0.f;
-            if (i < Mpad) Tb[blocked ? blocked_t_index(i, 4 * jq + t, LT) : i * L + 4 * jq + t] = ri * zf;
-            float cv = bi * zf;
-#pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) cv += __shfl_xor(cv, o2);
-            if (lane == 0) red[wv][4 * jq + t] = cv;
+            zt[wv][lane][4 * jq + t] = zf;
+            // the blocked operand layout of the f32 path interleaves rows: its lane-per-row stores are already contiguous
+            if (blocked && i < Mpad) Tb[blocked_t_index(i, 4 * jq + t, LT)] = rs[wv][lane] * zf;
         }
     }
     __syncthreads();
-    if (lane < L && wave < (Mpad + 63) / 64) cpart[wave * L + lane] = red[wv][lane];
+    // T' rows: element e = row * L + col of the tile, lanes take consecutive elements
+    if (!blocked)
+        for (int e = lane; e < 64 * L; e += 64) {
+            const int row = e / L, col = e % L;
+            const int64_t gr = i0 + row;
+            if (gr < Mpad) Tb[gr * L + col] = rs[wv][row] * zt[wv][row][col];
+        }
+    // c partial: lane = column (two half-waves split the rows for L = 32), rows in a fixed order
+    if (wave < (Mpad + 63) / 64) {
+        if (L == 32) {
+            const int col = lane & 31, hh = lane >> 5;
+            float cv = 0.f, am = 0.f;
+            for (int row = 32 * hh; row < 32 * hh + 32; ++row) {
+                const float zv = zt[wv][row][col];
+                cv += bs[wv][row] * zv;
+                am = fmaxf(am, fabsf(rs[wv][row] * zv));
+            }
+            cv += __shfl_xor(cv, 32);
+            am = fmaxf(am, __shfl_xor(am, 32));
+            if (hh == 0) {
+                cpart[wave * L + col] = cv;
+                // |T'| column max (digit scale of the first exact product): one 32-entry array for the whole grid.  max is
+                // order-independent, so the atomic keeps the result deterministic; non-negative doubles order like their
+                // bit patterns; the plain pre-read skips the atomic once the running max has settled (it only grows).
+                if (apart) {
+                    const double amd = (double)am;
+                    if (amd > apart[col]) atomicMax(reinterpret_cast<unsigned long long*>(apart) + col, (unsigned long long)__double_as_longlong(amd));
+                }
+            }
+        } else {
+            float cv = 0.f;
+            for (int row = 0; row < 64; ++row) cv += bs[wv][row] * zt[wv][row][lane];
+            cpart[wave * L + lane] = cv;
+        }
+    }
 }
 
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
-                  const float* b, float* Tb, float* cpart, int blocked) {
+                  const float* b, float* Tb, float* cpart, double* apart, int blocked) {
     const int64_t waves = omega_num_parts(Mpad);
-    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
-                       cpart, blocked);
+    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
+                       cpart, apart, blocked);
 }
 
 __global__ __launch_bounds__(256) void k_reduce_y(const float* __restrict__ Ypart, int W, int64_t Npad, int64_t N, int L,
