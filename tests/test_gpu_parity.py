@@ -632,3 +632,33 @@ def test_rsvd_bitwise_repeatable(gpca, prec, store, M, N, k):
                 ref = cur
             else:
                 assert all(np.array_equal(a, b) for a, b in zip(ref, cur))
+
+
+# ------------------------------------------------------------------------------------------------
+# the alternative kernels behind the diagnostic switches stay correct ("Diagnostic switches")
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env", [{"GPCA_GQ_DMA": "0"}, {"GPCA_GTT_DMA": "0"}, {"GPCA_GQ_DMA": "0", "GPCA_GTT_DMA": "0"},
+                                 {"GPCA_LDS_PLANES": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GTT_WAVES": "64"}])
+def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
+    """Register-staged (k_gq_x / k_gtt_x) and per-wave-plane (k_gq_i8 / k_gtt_i8) kernels, and a tiny grid that forces
+    full LDS-DMA rounds on a small matrix, against the default configuration: the integer products are exact, so only
+    the f32 partials of the centring term may move (<= 1e-8), and the oracle parity bar holds."""
+    from genomic_pca_amd import _lib
+    M, N, k = 20000, 1000, 10
+    th = gpca.synth_thresholds(M, 16, seed=1, fst=0.2)
+    G = oracle.synth_genotypes(M, N, 1, th)
+    res = {}
+    for name, e_env in (("default", {}), ("alt", env)):
+        with monkeypatch.context() as mp:
+            for key, val in e_env.items():
+                mp.setenv(key, val)
+            with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
+                e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 10, 2, seed=1)
+                res[name] = (e.eigenvalues(), e.scores(f64=True), e.loadings().astype(np.float64))
+    assert np.max(np.abs(res["alt"][0] - res["default"][0]) / res["default"][0]) < 1e-8
+    assert oracle.max_abs_dpc(res["alt"][1], res["default"][1]) < 1e-8
+    assert oracle.max_abs_dpc(res["alt"][2], res["default"][2]) < 1e-6
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=1)
+    assert oracle.max_abs_dpc(res["alt"][1], R["scores"]) < TOL_PC
