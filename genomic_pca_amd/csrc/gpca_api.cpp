@@ -81,6 +81,8 @@ struct gpca_handle {
     int k = 0, l = 0, L = 0;
     bool have_rsvd = false;
     float *dQ = nullptr, *dT = nullptr, *dTb = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
+    double* h_pin = nullptr;     // pinned host staging for the l x l blocks of the final eigenproblem (W | Z | flag)
+    int spin_sync = 1;           // busy-poll the stream at the two syncs of gpca_rsvd (GPCA_SPIN_SYNC=0: hipStreamSynchronize)
     int* d_cholflag = nullptr;   // first failed CholeskyQR pivot + 1 (0 = ok), written by k_chol_inv
     double *d_scratch64 = nullptr, *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
     double* d_scores64 = nullptr; float* d_scores32 = nullptr; float* d_load32 = nullptr; int* d_sign = nullptr;
@@ -200,6 +202,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (const char* e = getenv("GPCA_GTT_WAVES")) h->gtt_waves_target = std::max(4, atoi(e));
     if (const char* e = getenv("GPCA_LDS_PLANES")) h->lds_planes = atoi(e);
     if (const char* e = getenv("GPCA_GQ_DMA")) h->gq_dma = atoi(e);
+    if (const char* e = getenv("GPCA_SPIN_SYNC")) h->spin_sync = atoi(e);
     if (const char* e = getenv("GPCA_GTT_DMA")) h->gtt_dma = atoi(e);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
         delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
@@ -225,7 +228,7 @@ static void free_ws(gpca_handle* h) {
     dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
     dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
-    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_cholflag); dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
+    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_cholflag); if (h->h_pin) { (void)hipHostFree(h->h_pin); h->h_pin = nullptr; } dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
     h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
     h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
     h->have_rsvd = false;
@@ -636,6 +639,14 @@ static void jacobi_eigh(std::vector<double>& A, std::vector<double>& V, std::vec
 }
 
 // ---- rsvd stages -----------------------------------------------------------------------------------------------
+// wait for the engine's stream: busy-poll (lowest wake-up latency, one host core spins) or hipStreamSynchronize
+static hipError_t stream_wait(gpca_handle* h) {
+    if (!h->spin_sync) return hipStreamSynchronize(h->st);
+    hipError_t e;
+    while ((e = hipStreamQuery(h->st)) == hipErrorNotReady) {}
+    return e;
+}
+
 static int stage_sum_c(gpca_handle* h, int64_t parts) {
     launch_sum_partials_f32(h->st, h->d_cpart, parts, h->L, h->d_c, h->d_scratch64);
     HIPCHK(hipGetLastError());
@@ -750,7 +761,8 @@ static int ensure_workspace(gpca_handle* h) {
     if (!h->d_c) {
         HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));
         HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, 64 * 64 * 8));
-        HIPCHK(hipMalloc((void**)&h->dZ, 64 * 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
+        HIPCHK(hipMalloc((void**)&h->dZ, 2 * 64 * 64 * 8));
+        HIPCHK(hipHostMalloc((void**)&h->h_pin, (3 * 64 * 64 + 16) * 8, hipHostMallocDefault)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
         HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
         HIPCHK(hipMalloc((void**)&h->d_cholflag, 4));
     }
@@ -822,40 +834,44 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         HIPCHK(hipGetLastError());
         CHK(allreduce_f64(h, h->dW, (int64_t)L * L));
     }
-    std::vector<double> Wfull((size_t)L * L), C((size_t)l * l), V((size_t)l * l), w((size_t)l);
-    int cholflag = 0;
-    HIPCHK(hipMemcpyAsync(Wfull.data(), h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(hipMemcpyAsync(&cholflag, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(hipStreamSynchronize(h->st));
-    if (cholflag) {
+    // The only host step: the l x l eigenproblem.  Pinned staging + a busy-polled stream keep the round trip short
+    // (pageable copies and a sleeping hipStreamSynchronize cost ~220 us here); everything after it is enqueued at once.
+    std::vector<double> C((size_t)l * l), V((size_t)l * l), w((size_t)l);
+    double* Wfull = h->h_pin;
+    double* Zpin = h->h_pin + 64 * 64;                    // [scores Z (L x k) | loadings Z (L x k)]
+    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * 64 * 64);
+    HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipMemcpyAsync(flagpin, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(stream_wait(h));
+    if (*flagpin) {
         char buf[160];
-        snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not positive (rank-deficient sketch)", cholflag - 1, l);
+        snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not positive (rank-deficient sketch)", *flagpin - 1, l);
         return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
     }
-    for (int a = 0; a < l; ++a) for (int c = 0; c < l; ++c) C[(size_t)a * l + c] = 0.5 * (Wfull[(size_t)a * L + c] + Wfull[(size_t)c * L + a]);
+    for (int a2 = 0; a2 < l; ++a2) for (int c = 0; c < l; ++c) C[(size_t)a2 * l + c] = 0.5 * (Wfull[(size_t)a2 * L + c] + Wfull[(size_t)c * L + a2]);
     jacobi_eigh(C, V, w, l);
     h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
     for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
     for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
-    // 4. scores = Q V_k diag(s) ; sign ; loadings = B V_k diag(sign/s)
-    std::vector<double> Z((size_t)L * k, 0.0);
-    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Z[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
-    HIPCHK(hipMemcpyAsync(h->dZ, Z.data(), sizeof(double) * L * k, hipMemcpyHostToDevice, h->st));
+    // 4. scores = Q V_k diag(s) ; sign ; loadings = B V_k diag(sign/s)   (the sign is applied to the loadings' Z on the device)
+    const size_t zk = (size_t)L * k;
+    for (size_t e = 0; e < 2 * zk; ++e) Zpin[e] = 0.0;
+    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) {
+        Zpin[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
+        Zpin[zk + (size_t)j * k + c] = h->sv[(size_t)c] > 0 ? V[(size_t)j * l + c] / h->sv[(size_t)c] : 0.0;
+    }
+    HIPCHK(hipMemcpyAsync(h->dZ, Zpin, sizeof(double) * 2 * zk, hipMemcpyHostToDevice, h->st));
     launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);   // dY = Q in f64
     HIPCHK(hipGetLastError());
     launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
     HIPCHK(hipGetLastError());
     launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
     HIPCHK(hipGetLastError());
-    std::vector<int> sign((size_t)k, 1);
-    HIPCHK(hipMemcpyAsync(sign.data(), h->d_sign, sizeof(int) * k, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(hipStreamSynchronize(h->st));  // Z (host) is rewritten below
-    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c)
-        Z[(size_t)j * k + c] = h->sv[(size_t)c] > 0 ? V[(size_t)j * l + c] * (double)sign[(size_t)c] / h->sv[(size_t)c] : 0.0;
-    HIPCHK(hipMemcpyAsync(h->dZ, Z.data(), sizeof(double) * L * k, hipMemcpyHostToDevice, h->st));
-    launch_rightmul_gather_f32(h->st, h->dT, h->d_pca_rows, h->n_pca, L, h->dZ, k, h->d_load32);
+    launch_scale_cols(h->st, h->dZ + zk, (float*)nullptr, L, k, h->d_sign);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->st));
+    launch_rightmul_gather_f32(h->st, h->dT, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);
+    HIPCHK(hipGetLastError());
+    HIPCHK(stream_wait(h));
     h->have_rsvd = true;
     return GPCA_OK;
 }
