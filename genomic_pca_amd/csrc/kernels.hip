@@ -519,23 +519,35 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
     for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
     const int64_t r0 = (int64_t)blockIdx.x * rpb;
     const int64_t r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
-    for (int64_t n = r0 + 16 * wv; n < r1; n += 64) {       // 16 rows per wave and trip: 4 MFMA k-steps
-        double x[4][G];
+    // 16 rows per wave and trip (4 MFMA k-steps); the next trip's rows are requested before this trip's MFMAs
+    float xc[4][G], xn[4][G];
+    auto load_rows = [&](int64_t n, float (&dst)[4][G]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t row = n + 4 * u + k;
 #pragma unroll
-            for (int g = 0; g < G; ++g) x[u][g] = row < r1 ? (double)X[row * L + 16 * g + i] : 0.0;
+            for (int g = 0; g < G; ++g) dst[u][g] = row < r1 ? X[row * L + 16 * g + i] : 0.f;
         }
+    };
+    load_rows(r0 + 16 * wv, xc);
+    for (int64_t n = r0 + 16 * wv; n < r1; n += 64) {
+        load_rows(n + 64, xn);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            double x[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = (double)xc[u][g];
             int t = 0;
 #pragma unroll
             for (int ga = 0; ga < G; ++ga)
 #pragma unroll
                 for (int gc = ga; gc < G; ++gc, ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][ga], x[u][gc], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ga], x[gc], acc[t], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) xc[u][g] = xn[u][g];
     }
     if (wv > 0) {
 #pragma unroll
@@ -793,17 +805,83 @@ void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, c
         hipLaunchKernelGGL((k_rightmul<double, 64>), grid, blk, lds, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
     }
 }
+// Loadings = B[rows] (V S^-1): the tall f32 factor times an L x K f64 matrix, on the f64 matrix cores (the VALU kernel
+// above is LDS-broadcast bound: 640 ds_reads per row).  One wave = 16 rows per tile: lane (i = lane & 15, kq = lane >> 4)
+// loads the E = L/4 consecutive floats X[row_i][E kq ..] (the k-order of a dot product is free, so step s pairs
+// A_s[i][kq] = X[row_i][E kq + s] with B_s[kq][j] = Z[E kq + s][j]); Z sits in registers for the whole kernel.
+// D[4 r + lane / 16][lane % 16] (probe_mfma_f64.hip): a store covers 4 rows x 64 contiguous bytes.
+template <int L, int NJ>
+__global__ __launch_bounds__(256) void k_rightmul_mfma(const float* __restrict__ X, const int64_t* __restrict__ row_ids,
+                                                       int64_t nrows, const double* __restrict__ Z, int K,
+                                                       float* __restrict__ out32, int64_t tiles_per_wave) {
+    constexpr int E = L / 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    double zb[E][NJ];
+#pragma unroll
+    for (int s2 = 0; s2 < E; ++s2)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int col = 16 * jt + i;
+            zb[s2][jt] = col < K ? Z[(E * kq + s2) * K + col] : 0.0;
+        }
+    __shared__ float osm[4][16 * 64];                   // per-wave output tile, written back as one contiguous run
+    const int64_t ntiles = (nrows + 15) >> 4;
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * tiles_per_wave;
+    const int64_t t1 = (t0 + tiles_per_wave < ntiles) ? t0 + tiles_per_wave : ntiles;
+    float xa[E], xn[E];
+    auto load_tile = [&](int64_t tile, float (&dst)[E]) {
+        const int64_t row = tile * 16 + i;
+        const bool valid = row < nrows && tile < t1;
+        const int64_t src = valid ? (row_ids ? row_ids[row] : row) : 0;
+        const float4* xp = reinterpret_cast<const float4*>(X + src * L + E * kq);
+#pragma unroll
+        for (int v = 0; v < E / 4; ++v) {
+            const float4 q = xp[v];
+            dst[4 * v] = valid ? q.x : 0.f; dst[4 * v + 1] = valid ? q.y : 0.f; dst[4 * v + 2] = valid ? q.z : 0.f; dst[4 * v + 3] = valid ? q.w : 0.f;
+        }
+    };
+    if (t0 < t1) load_tile(t0, xa);
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        load_tile(tile + 1, xn);                        // next tile's rows are in flight behind this tile's MFMAs
+        f64x4 acc[NJ];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < E; ++s2) {
+            const double a = (double)xa[s2];
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zb[s2][jt], acc[jt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int col = 16 * jt + i;
+            if (col < K) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) osm[wv][(4 * r + kq) * K + col] = (float)acc[jt][r];
+            }
+        }
+        // (one wave: its LDS operations execute in issue order, so the reads below see the writes above)
+        const int64_t rows_here = (nrows - tile * 16 < 16) ? nrows - tile * 16 : 16;
+        float* dst = out32 + tile * 16 * K;
+        for (int e = lane; e < (int)rows_here * K; e += 64) dst[e] = osm[wv][e];
+#pragma unroll
+        for (int s2 = 0; s2 < E; ++s2) xa[s2] = xn[s2];
+    }
+}
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
                                 const double* Z, int K, float* out32) {
     if (nrows == 0) return;
-    const dim3 grid((unsigned)((nrows + 255) / 256)), blk(256);
-    const size_t lds = rightmul_lds(L, K, true);
-    if (L == 32) hipLaunchKernelGGL((k_rightmul<float, 32>), grid, blk, lds, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
-    else {
-        static const int a = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        (void)a;
-        hipLaunchKernelGGL((k_rightmul<float, 64>), grid, blk, lds, st, X, row_ids, nrows, Z, K, (double*)nullptr, out32);
-    }
+    const int64_t ntiles = (nrows + 15) / 16;
+    int64_t tpw = ntiles / (4 * 2048);            // ~2048 workgroups, at least one tile per wave
+    if (tpw < 1) tpw = 1;
+    const int64_t waves = (ntiles + tpw - 1) / tpw;
+    const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+    const int nj = (K + 15) / 16;
+#define GPCA_RM(LL, NN) hipLaunchKernelGGL((k_rightmul_mfma<LL, NN>), grid, blk, 0, st, X, row_ids, nrows, Z, K, out32, tpw)
+    if (L == 32) { if (nj == 1) GPCA_RM(32, 1); else if (nj == 2) GPCA_RM(32, 2); else if (nj == 3) GPCA_RM(32, 3); else GPCA_RM(32, 4); }
+    else { if (nj == 1) GPCA_RM(64, 1); else if (nj == 2) GPCA_RM(64, 2); else if (nj == 3) GPCA_RM(64, 3); else GPCA_RM(64, 4); }
+#undef GPCA_RM
 }
 
 constexpr int kColsumRowsPerBlock = 256;
