@@ -440,6 +440,10 @@ void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int6
 // every 4th row of the tile (8 LDS reads per 16 FMAs); the four row-groups are combined through LDS at the end.
 // Rows per block adapt to the problem so that ~1024 blocks are in flight (N = 10^4 used to get 20 blocks).
 static int64_t gram_rows_per_block(int64_t rows) {
+    // the sample-side Grams of CholeskyQR (N rows, 6 per call) sit on the critical path between two GEMM passes: at most
+    // 64 parts there, so that one k_sum_partials launch finishes the reduction (two stages cost a launch + gap more
+    // than the thinner grid does)
+    if (rows <= 262144) { const int64_t q = (rows + 63) / 64; return q < 32 ? 32 : (q + 31) / 32 * 32; }
     int64_t r = (rows + 1023) / 1024;
     r = (r + 31) / 32 * 32;
     return r < 32 ? 32 : (r > 2048 ? 2048 : r);
