@@ -101,9 +101,12 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not key or not files:
         return None, None
-    d = json.load(open(files[-1])).get(key)
-    if not d or "FETCH_SIZE" not in d:
-        return None, None
+    table = json.load(open(files[-1]))
+    d = table.get(key)
+    if d is None:   # template arguments changed between profiles (k_gq_d<1> -> k_gq_d<1, 6>): match on the kernel's base name
+        base = key.split("<")[0]
+        cands = [v for k2, v in table.items() if k2.split("<")[0] == base and ("true" in k2) == ("true" in key)]
+        d = cands[0] if cands else None
     return (2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024.0, os.path.basename(files[-1])
 
 

@@ -816,10 +816,12 @@ void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& pla
 //   followed by the workgroup barrier.
 // ================================================================================================
 constexpr int kGqdSlots = 6;
-struct GqdSmem {
+template <int S>
+struct GqdSmemT {
     i32x4 q[2][4][kDigits][64];          // digit planes: [slot][step][digit][lane]          32 KiB
-    i32x4 g[4][kGqdSlots][256];          // genotype units: [wave][slot][piece i][lane]      96 KiB
+    i32x4 g[4][S][256];                  // genotype units: [wave][slot][piece i][lane]      96 KiB (S = 6) / 112 KiB (S = 7)
 };
+using GqdSmem = GqdSmemT<kGqdSlots>;
 
 template <int NT = 0>
 __device__ __forceinline__ void gqd_dma(uint32_t lds_addr, uint32_t voff, i32x4 rsrc, uint32_t soff) {
@@ -844,9 +846,9 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
     return r;
 }
 
-template <int NT>
+template <int NT, int S>
 __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
-                                          const int8_t* __restrict__ Qd, GqdSmem* sm, int wv, int lane, int c, int h,
+                                          const int8_t* __restrict__ Qd, GqdSmemT<S>* sm, int wv, int lane, int c, int h,
                                           int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
                                           float& csum, float& amax) {
@@ -862,7 +864,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     for (int t = 0; t < R; ++t) toff[t] = (uint32_t)(t < nvalid ? 32 * t : 0) * ld32;
     constexpr uint32_t QCH = kDigits * 1024;
     const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
-    const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (kGqdSlots * 4096u);
+    const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (S * 4096u);
     const char* gl = reinterpret_cast<const char*>(&sm->g[wv][0][0]);
     uint32_t loff[4];                                   // operand read: row c, chunk (2 s + h) ^ (c & 7)
 #pragma unroll
@@ -889,11 +891,15 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
             gqd_dma(lds_q + (uint32_t)(((QS) * 4 + j) * kDigits) * 1024u, qvo, rq, ((uint32_t)(ST) * 4u + j) * QCH); \
     }
     const int64_t s1 = nstage > 1 ? 1 : 0;
+    // ring of S slots: the unit consumed is re-filled with the unit S ahead; S - 4 units precede Q(0) in the prologue so
+    // that the steady-state counts hold from the first stage on (S = 6: G0 G1 Q0 G2..G5;  S = 7: G0 G1 G2 Q0 G3..G6)
     GQD_ISSUE_G(0, 0, 0) GQD_ISSUE_G(0, 1, 1)
+    if constexpr (S == 7) GQD_ISSUE_G(0, 2, 2)
     GQD_ISSUE_Q(0, 0)
-    GQD_ISSUE_G(0, 2, 2) GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5)
+    if constexpr (S == 6) { GQD_ISSUE_G(0, 2, 2) GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) }
+    else { GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) GQD_ISSUE_G(s1, 2, 6) }
     int64_t ist = s1;        // next unit to issue: (stage ist, tile it), always into the slot just consumed
-    int it = 2;
+    int it = S - 4;
     uint32_t rslot = 0;      // slot of the unit being consumed
     i32x4 gcur, gnxt;
 
@@ -909,13 +915,15 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
 #pragma unroll
         for (int t = 0; t < R; ++t) {
             const char* ub = gl + rslot * 4096u;
-            const uint32_t nslot = rslot == kGqdSlots - 1 ? 0u : rslot + 1u;
+            const uint32_t nslot = rslot == S - 1 ? 0u : rslot + 1u;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if (s4 < 3) {
                     gnxt = *reinterpret_cast<const i32x4*>(ub + loff[s4 + 1]);
                 } else {
-                    if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>();           // the next unit has landed
+                    // younger than the next unit: S - 2 unit fills + 1 plane batch (2 when a stage start falls in the window)
+                    if (S == 6) { if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>(); }
+                    else { if (t <= 1) gqd_wait_vm<28>(); else gqd_wait_vm<24>(); }
                     gnxt = *reinterpret_cast<const i32x4*>(gl + nslot * 4096u + loff[0]);
                 }
 #pragma unroll
@@ -953,14 +961,14 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     }
 }
 
-template <int NT>
+template <int NT, int S>
 __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nstage,
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
                                                   float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
-    GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
+    GqdSmemT<S>* sm = reinterpret_cast<GqdSmemT<S>*>(gqd_smem);
     i32x4 (*tds)[4][kDigits][64] = sm->q;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -976,7 +984,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
         if (rem > 8) {           // 4 tiles per wave, genotypes by LDS-DMA
             const int64_t mine = u + 4 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqd_round<NT>(G, ldg, nstage, Qd, sm, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
             u += 16;
         } else if (rem > 4) {    // tails: the register-staged rounds
             const int64_t mine = u + 2 * wv;
@@ -998,15 +1006,20 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                 int scale_out) {
-    static const int attr0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)sizeof(GqdSmem));
-    static const int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)sizeof(GqdSmem));
-    if (attr0 != 0 || attr1 != 0) return attr0 ? attr0 : attr1;
+    static const int slots = getenv("GPCA_GQ_SLOTS") ? atoi(getenv("GPCA_GQ_SLOTS")) : 6;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;
-    if (g_dma_nt) hipLaunchKernelGGL(k_gq_d<1>, grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
-    else hipLaunchKernelGGL(k_gq_d<0>, grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+#define GPCA_GQD(NTV, SV)                                                                                                       \
+    {                                                                                                                          \
+        static const int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d<NTV, SV>),                         \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GqdSmemT<SV>)); \
+        if (attr != 0) return attr;                                                                                            \
+        hipLaunchKernelGGL((k_gq_d<NTV, SV>), grid, blk, sizeof(GqdSmemT<SV>), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, \
+                           Tout, cpart, apart, scale_out);                                                                     \
+    }
+    if (slots == 7) { if (g_dma_nt) GPCA_GQD(1, 7) else GPCA_GQD(0, 7) }
+    else { if (g_dma_nt) GPCA_GQD(1, 6) else GPCA_GQD(0, 6) }
+#undef GPCA_GQD
     return 0;
 }
 
@@ -1231,14 +1244,21 @@ __device__ __forceinline__ void gtd_read_g(GttXG<false>& b, const char* unit) {
 template <int NT>
 __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Mpad, int64_t Npad,
                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t ngroups, int64_t rows_per_wave) {
+                                                   int64_t ngroups, int64_t rows_per_wave, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int64_t ngroup = blockIdx.x % ngroups;
-    const int64_t wchunk = blockIdx.x / ngroups;
+    // workgroup b runs on XCD b % 8: give the workgroups of one XCD consecutive virtual ids, so that the n-groups that
+    // share a row chunk (and its T' planes) run behind one L2
+    int64_t vb = blockIdx.x;
+    if (xcd_remap) {
+        const int64_t q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
+        vb = x * q + (x < r ? x : r) + blockIdx.x / 8;
+    }
+    const int64_t ngroup = vb % ngroups;
+    const int64_t wchunk = vb / ngroups;
     const int64_t nblock = ngroup * 4 + wv;
     int64_t n0 = nblock * 128;
     const bool live = n0 < Npad;          // a dead wave (ragged last group) still moves planes and joins the barriers
@@ -1335,8 +1355,9 @@ int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int
     if (attr0 != 0 || attr1 != 0) return attr0 ? attr0 : attr1;
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     const dim3 grid((unsigned)plan.grid), blk(256);
-    if (g_dma_nt) hipLaunchKernelGGL(k_gtt_d<1>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
-    else hipLaunchKernelGGL(k_gtt_d<0>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+    static const int remap = getenv("GPCA_GTT_XCD") ? atoi(getenv("GPCA_GTT_XCD")) : 1;   // measured 5.10 -> 5.00 ms per step
+    if (g_dma_nt) hipLaunchKernelGGL(k_gtt_d<1>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
+    else hipLaunchKernelGGL(k_gtt_d<0>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
     return 0;
 }
 
