@@ -981,11 +981,15 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
     int64_t u = u0;
     while (u < u1) {
         const int64_t rem = u1 - u;
-        if (rem > 8) {           // 4 tiles per wave, genotypes by LDS-DMA
-            const int64_t mine = u + 4 * wv;
-            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
-            u += 16;
+        if (rem > 8) {           // up to 4 tiles per wave, genotypes by LDS-DMA
+            // a short last round (9..15 units) is split evenly -- (3,3,2,2) rather than (4,4,2,0) -- so that no wave sweeps
+            // the samples for nothing while another carries a full load
+            const int64_t take = rem < 16 ? rem : 16;
+            const int64_t base = take >> 2, extra = take & 3;
+            const int64_t mine = u + wv * base + (wv < extra ? wv : extra);
+            const int nv = (int)(base + (wv < extra ? 1 : 0));
+            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            u += take;
         } else if (rem > 4) {    // tails: the register-staged rounds
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
