@@ -1350,6 +1350,137 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
     }
 }
 
+// ================================================================================================
+// K2 for packed (2-bit) genotypes by cooperative LDS-DMA.  k_gtt_x<true> keeps 4 blocks of dwords per wave in
+// registers = 16 KiB per CU in flight: at 2.8 TB/s of real traffic that is exactly one loaded HBM latency, i.e. the
+// kernel is latency-bound (matrix cores 46 % busy).  Here a stage (128 SNP rows) is brought in by the whole workgroup:
+// wave w DMAs rows 8w..8w+7 of each 32-row block as one full-line piece (8 rows x 128 B = the 512 samples of the
+// n-group) and plane w of T' -- 8 instructions per wave and stage -- into a ring of four 32-KiB stage buffers, two
+// stages (64 KiB per CU) in flight beyond the one being consumed and the one the register pipeline looks ahead into.
+// Every wave then reads its own 32-byte slab of each row from LDS (dword reads, 4 lanes per dword) and decodes as
+// before.  Per stage:  vmcnt(8) [stages s, s+1 landed; 8 DMAs of s+2 may be outstanding]; barrier; issue stage s+3.
+// ================================================================================================
+struct GtpStage { i32x4 t[4][kDigits][64]; char g[4][4096]; };     // 16 KiB of planes + 16 KiB of genotype rows
+struct GtpSmem { GtpStage stg[4]; };
+
+__global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Mpad, int64_t Npad,
+                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
+                                                   int64_t ngroups, int64_t rows_per_wave, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
+    GtpSmem* sm = reinterpret_cast<GtpSmem*>(gqd_smem);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    int64_t vb = blockIdx.x;           // XCD-aware order: the n-groups of a row chunk (same T' planes) behind one L2
+    if (xcd_remap) {
+        const int64_t q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
+        vb = x * q + (x < r ? x : r) + blockIdx.x / 8;
+    }
+    const int64_t ngroup = vb % ngroups;
+    const int64_t wchunk = vb / ngroups;
+    const int64_t n0 = (ngroup * 4 + wv) * 128;          // Npad is a multiple of 1024 in packed mode: every wave is live
+    const int64_t m_begin = wchunk * rows_per_wave;
+    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
+    const int64_t kblocks = (m_end - m_begin) >> 5;      // multiple of 4
+    const int64_t nstage = kblocks >> 2;
+
+    i32x16 acc[4][kDigits];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
+
+    constexpr uint32_t TKB = kDigits * 1024;
+    const uint8_t* gp = G2 + m_begin * ld2 + ngroup * 128;         // the n-group's 128-byte column of the row chunk
+    const int8_t* tp = Td + (m_begin >> 5) * TKB + wv * 1024;      // this wave's plane
+    const uint32_t gvo = (uint32_t)(8 * wv + (lane >> 3)) * (uint32_t)ld2 + 16u * (uint32_t)(lane & 7);
+    const uint32_t tvo = (uint32_t)(lane * 16);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->stg[0];
+    const unsigned bsh = 8u * (unsigned)(c & 3);
+    // this lane's dword of row 16 h + i of a block: + i * 128
+    const uint32_t rdo = (uint32_t)((16 * h) * 128 + 32 * wv + (c & ~3));
+
+    // stage st -> ring slot: 4 genotype pieces (one per 32-row block) + 4 plane pieces
+    auto issue_stage = [&](int64_t st, uint32_t slot) {
+        const int64_t us = st < nstage ? st : 0;
+        const i32x4 rg = gqd_rsrc(gp + us * 128 * ld2);
+        const i32x4 rt = gqd_rsrc(tp + us * 4 * TKB);
+        const uint32_t base = lds0 + slot * (uint32_t)sizeof(GtpStage);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+            gqd_dma<0>(base + 4u * TKB + (uint32_t)bb * 4096u + (uint32_t)wv * 1024u, gvo, rg, (uint32_t)(32 * bb) * (uint32_t)ld2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            gqd_dma<0>(base + (uint32_t)(j * kDigits) * 1024u + (uint32_t)wv * 1024u, tvo, rt, j * TKB);
+    };
+    auto read_g = [&](GttXG<true>& b, uint32_t slot, int bb) {
+        const char* unit = &sm->stg[slot].g[bb][0] + rdo;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b.g[i] = *reinterpret_cast<const unsigned*>(unit + i * 128);
+    };
+
+    GttXG<true> GA, GB;
+    Gtt2Ops OA, OB;
+    GttXT TA, TB;
+    issue_stage(0, 0); issue_stage(1, 1); issue_stage(2, 2);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");       // stages 0 and 1 landed for every wave
+    issue_stage(3, 3);
+    read_g(GA, 0, 0);
+    read_g(GB, 0, 1);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) TA.t[d] = sm->stg[0].t[0][d][lane];
+    gttx_decode<true>(GA, OA, bsh);
+
+    // one phase: TC/OC = operands of block b; GN (registers of block b+1) -> ON, TN (planes of block b+1 at TSLOT/TBLK);
+    // GR receives block b+2 = block RB of stage slot RS
+#define GTP_PHASE(TC, OC, GN, ON, TN, GR, TSLOT, TBLK, RS, RB)                                             \
+    {                                                                                                    \
+        read_g(GR, (RS), (RB));                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gttx_phase<true>(TC, OC, acc, GN, ON, TN, &sm->stg[(TSLOT)].t[(TBLK)][0][lane], bsh);            \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    }
+    for (int64_t st = 0; st < nstage; ++st) {
+        const uint32_t s0 = (uint32_t)(st & 3), sn = (uint32_t)((st + 1) & 3);
+        if (st > 0) {
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");   // stage st+1 landed; everyone is done with stage st-1
+            issue_stage(st + 3, (uint32_t)((st + 3) & 3));
+        }
+        GTP_PHASE(TA, OA, GB, OB, TB, GA, s0, 1, s0, 2)
+        GTP_PHASE(TB, OB, GA, OA, TA, GB, s0, 2, s0, 3)
+        GTP_PHASE(TA, OA, GB, OB, TB, GA, s0, 3, sn, 0)
+        GTP_PHASE(TB, OB, GA, OA, TA, GB, sn, 0, sn, 1)
+    }
+#undef GTP_PHASE
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // no DMA may land after this workgroup's LDS is released
+    double* yp = Ypart + (wchunk * Npad) * 32;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t n = n0 + 4 * c + t;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
+            double2 o;
+            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
+            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
+        }
+    }
+}
+
+int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
+                 const Gtt8Plan& plan) {
+    static const int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_p), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)sizeof(GtpSmem));
+    if (attr != 0) return attr;
+    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    static const int remap = getenv("GPCA_GTT_XCD") ? atoi(getenv("GPCA_GTT_XCD")) : 1;
+    hipLaunchKernelGGL(k_gtt_p, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
+                       plan.rows_per_wave, remap);
+    return 0;
+}
+
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan) {
     static const int attr0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_d<0>), hipFuncAttributeMaxDynamicSharedMemorySize,

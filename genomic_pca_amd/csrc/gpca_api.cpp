@@ -668,6 +668,10 @@ static int stage_AtT(gpca_handle* h) {
                 const int e = launch_gtt_d(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
                 if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
             }
+            else if (h->lds_planes && h->gtt_dma && h->storage == GPCA_STORE_2BIT) {
+                const int e = launch_gtt_p(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+                if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_p: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
+            }
             else if (h->lds_planes) launch_gtt_x(h->st, h->storage == GPCA_STORE_2BIT ? (const void*)h->dG2 : (const void*)h->dG, h->storage == GPCA_STORE_2BIT,
                                             h->storage == GPCA_STORE_2BIT ? h->ld2 : h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
             else if (h->storage == GPCA_STORE_2BIT) launch_gtt_2bit(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);

@@ -141,6 +141,9 @@ void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows
 // quantise X whose column abs-max partials [P][32] were already produced by the kernel that wrote it (K1 epilogue)
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
                                 double* scale, double* inv, int8_t* Xd, int layout);
+// K2 for packed genotypes: stage-wise cooperative LDS-DMA (ring of four stage buffers); returns a hipError_t value
+int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
+                 const Gtt8Plan& plan);
 // K2 with genotypes and digit planes brought in by LDS-DMA (int8-resident); returns a hipError_t value (0 = ok)
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan);
