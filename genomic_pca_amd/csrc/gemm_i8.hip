@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
     for (int64_t st = 0; st < nstage; ++st) {
         const uint32_t s0 = (uint32_t)(st & 3), sn = (uint32_t)((st + 1) & 3);
         if (st > 0) {
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");   // stage st+1 landed; everyone is done with stage st-1
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage st+1 landed; everyone is done with stage st-1
             issue_stage(st + 3, (uint32_t)((st + 3) & 3));
         }
         GTP_PHASE(TA, OA, GB, OB, TB, GA, s0, 1, s0, 2)
