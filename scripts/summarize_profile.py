@@ -46,7 +46,7 @@ if pm:
               "| kernel | FETCH_SIZE (MB) | x2 corrected (MB) | WRITE_SIZE (MB) | MFMA busy cyc / SIMD | GRBM_GUI_ACTIVE / XCD | MFMA busy % |",
               "|---|---|---|---|---|---|---|"]
     for k, v in pm.items():
-        if not any(x in k for x in ("gq_f32", "gtt_f32", "snp_stats", "gq_i8", "gtt_i8", "2bit", "gq_x", "gtt_x", "gq_d", "gtt_d")):
+        if not any(x in k for x in ("gq_f32", "gtt_f32", "snp_stats", "gq_i8", "gtt_i8", "2bit", "gq_x", "gtt_x", "gq_d", "gtt_d", "gtt_p")):
             continue
         avg = lambda n: (sum(v[n]) / len(v[n])) if v.get(n) else float("nan")
         fetch = avg("FETCH_SIZE") * 1024 / 1e6
