@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void k_snp_stats(const int8_t* __restrict__ G,
     int nmiss = 0, sum = 0, sq = 0;
     unsigned weird = 0;
     for (int64_t v0 = lane; v0 < nvec; v0 += 64) {
-        const uint4 q = p[v0];
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + v0);   // one pass, nothing re-read: nt
         const unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
