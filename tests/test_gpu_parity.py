@@ -662,3 +662,22 @@ def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
     R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=1)
     assert oracle.max_abs_dpc(res["alt"][1], R["scores"]) < TOL_PC
+
+
+@pytest.mark.parametrize("store", ["int8", "2bit"])
+@pytest.mark.parametrize("k,oversample,q", [(22, 10, 2), (6, 0, 0), (1, 3, 1)])
+def test_rsvd_i8_sketch_width_and_iteration_edges(gpca, oracle, store, k, oversample, q):
+    """l = 32 uses every column of the 32-wide tiles (no zero padding columns), l = k (no oversampling) with q = 0 is a
+    single sketch + projection, k = 1 is the narrowest call the reference accepts (main.rs:607-619)."""
+    from genomic_pca_amd import _lib
+    M, N = 5000, 600
+    th = gpca.synth_thresholds(M, 40, seed=4, fst=0.25)
+    G = oracle.synth_genotypes(M, N, 4, th)
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r, b, k, oversample, q, seed=9)
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8) as e:
+        e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, oversample, q, seed=9)
+        assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+        assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
+        assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]) < TOL_PC
