@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--no-second-path", action="store_true", help="skip the extra f32-MFMA measurement")
     ap.add_argument("--storage", default="int8", choices=["int8", "2bit"],
                     help="HBM residency of the genotypes: int8 = 1 B/genotype (the BASELINE.json configs), 2bit = 0.25 B (exact path only)")
+    ap.add_argument("--digit-planes", type=int, default=0, choices=[0, 3, 4],
+                    help="exact path: 4 (default) signed base-128 digit planes, or 3 base-256 planes (24-bit; --storage 2bit only)")
     ap.add_argument("--precision", default="i8", choices=["f32", "i8"],
                     help="i8 = exact-integer GEMMs (default, fastest parity-green path); f32 = v_mfma_f32_32x32x2_f32")
     a = ap.parse_args()
@@ -191,11 +193,14 @@ def main():
     order = [a.precision] + ([] if (a.no_second_path or a.precision == "f32" or l > 32) else ["f32"])
     if a.precision == "i8" and a.storage == "int8" and not a.no_second_path:
         order.append("i8_2bit")
+        order.append("i8_2bit_3p")
     th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
     t_stats = None
     for prec in order:
-        store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == "i8") or prec == "i8_2bit") else g._lib.STORE_INT8
-        eng = g.GpcaEngine(device=local_rank, precision=PREC["i8" if prec == "i8_2bit" else prec], storage=store)
+        packed = prec in ("i8_2bit", "i8_2bit_3p")
+        store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == "i8") or packed) else g._lib.STORE_INT8
+        planes = 3 if prec == "i8_2bit_3p" else (a.digit_planes if (prec == "i8" and store == g._lib.STORE_2BIT) else 0)
+        eng = g.GpcaEngine(device=local_rank, precision=PREC["i8" if packed else prec], storage=store, digit_planes=planes)
         eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
         t0 = time.perf_counter()
         eng.snp_stats(g.QcConfig.none(), fetch=False)
@@ -241,6 +246,14 @@ def main():
                 "value": M_total * N / (dt3 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt3 / a.steps * 1e3,
                 "roofline": roofline_of(tim3, "i8", a.steps, "2bit"),
                 "max_rel_d_eigenvalue_vs_default_path": float(np.max(np.abs(ev3 - ev) / ev))}
+        if "i8_2bit_3p" in results:
+            dt4, tim4, ev4 = results["i8_2bit_3p"]
+            out["packed_2bit_three_planes"] = {
+                "note": "2-bit residency with gpca_config.digit_planes = 3: three signed base-256 digit planes (24-bit fixed point per column, "
+                        "exact integer accumulation) instead of four base-128 planes -- a quarter less matrix-core work",
+                "value": M_total * N / (dt4 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt4 / a.steps * 1e3,
+                "all_kernels_ms_per_step": {n: t["total_ms"] / a.steps for n, t in tim4.items()},
+                "max_rel_d_eigenvalue_vs_default_path": float(np.max(np.abs(ev4 - ev) / ev))}
         if world == 1 and not a.no_cpu_baseline:
             out["parity"] = parity_check(g, PREC[a.precision], a.rfit_seed)
             out["cpu_baseline"] = cpu_baseline(N, k, a.oversample, a.power_iters, a.rfit_seed)

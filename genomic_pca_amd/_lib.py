@@ -39,7 +39,8 @@ class GpcaError(RuntimeError):
 
 
 class gpca_config(C.Structure):
-    _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("storage", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("storage", C.c_int32), ("digit_planes", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 class gpca_qc_config(C.Structure):

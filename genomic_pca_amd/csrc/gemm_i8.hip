@@ -34,8 +34,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc8(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, GPCA_RSRC_FLAGS);
 }
 
+// BITS = 7: four signed base-128 digits (28-bit fixed point, the default);  BITS = 8: three signed base-256 digits (24-bit,
+// the packed kernels' fast mode -- plane 3 is all zero and its accumulators are never touched)
+template <int BITS = 7>
 __device__ __forceinline__ double combine_digits(const i32x16 (&a)[kDigits], int e) {
     // exact: each |a| < 2^31, weights are powers of two, total < 2^53
+    if (BITS == 8) return (double)a[0][e] + 256.0 * (double)a[1][e] + 65536.0 * (double)a[2][e];
     return (double)a[0][e] + 128.0 * (double)a[1][e] + 16384.0 * (double)a[2][e] + 2097152.0 * (double)a[3][e];
 }
 
@@ -66,9 +70,10 @@ __device__ __forceinline__ void gq8_load_g(Gq8G<R>& b, __amdgpu_buffer_rsrc_t rg
 #pragma unroll
         for (int j = 0; j < 4; ++j) b.g[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], s0 + 32u * j, AUX);
 }
+template <int ND = kDigits>
 __device__ __forceinline__ void gq8_load_q(Gq8Q& b, __amdgpu_buffer_rsrc_t rq, uint32_t qvo, uint32_t qoff) {
 #pragma unroll
-    for (int d = 0; d < kDigits; ++d) b.q[d] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, qoff + d * 1024, 0);
+    for (int d = 0; d < ND; ++d) b.q[d] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, qoff + d * 1024, 0);
 }
 template <int R>
 __device__ __forceinline__ void gq8_compute(const i32x4 (&g)[R], const Gq8Q& q, i32x16 (&acc)[R][kDigits]) {
@@ -379,14 +384,15 @@ __device__ __forceinline__ int spread4(unsigned w, int q) {   // byte q of w (4 
 }
 // The R x 4 int8 MFMAs of the current step, each followed by one micro-step (5 VALU ops = one output dword) of the
 // NEXT step's decode; sched_barrier(0) pins the order so the VALU work issues in the shadow of the matrix pipe.
-template <int R, int SN>
+template <int R, int SN, int ND = kDigits>
 __device__ __forceinline__ void gq2_mfma_decode(const i32x4 (&op)[R], const Gq8Q& q, i32x16 (&acc)[R][kDigits],
                                                 const i32x4 (&gn)[R], i32x4 (&opn)[R], const unsigned* lut) {
 #pragma unroll
     for (int d = 0; d < kDigits; ++d)
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-            if (GPCA_ABLATE & 8) acc[t][d][0] ^= op[t][d] ^ q.q[d][t & 3];
+            if (d >= ND) { /* three-plane mode: this slot carries only its look-up */ }
+            else if (GPCA_ABLATE & 8) acc[t][d][0] ^= op[t][d] ^ q.q[d][t & 3];
             else acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], q.q[d], acc[t][d], 0, 0, 0);
             const int m = d * R + t;          // 4R MFMAs <-> 4R output dwords (tile m / 4, dword m % 4)
             if (GPCA_ABLATE & 1) opn[m >> 2][m & 3] = gn[m >> 2][SN];
@@ -395,7 +401,7 @@ __device__ __forceinline__ void gq2_mfma_decode(const i32x4 (&op)[R], const Gq8Q
         }
 }
 
-template <int R>
+template <int R, int ND = kDigits>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
@@ -421,7 +427,7 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     i32x4 opA[R], opB[R];
     const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd);   // digit planes are < 2 GiB: one descriptor
     gq2_load_g<R>(GA, rg, gvo, 0u);
-    gq8_load_q(Q0, rq, qvo, 0u); gq8_load_q(Q1, rq, qvo, QCH); gq8_load_q(Q2, rq, qvo, 2 * QCH);
+    gq8_load_q<ND>(Q0, rq, qvo, 0u); gq8_load_q<ND>(Q1, rq, qvo, QCH); gq8_load_q<ND>(Q2, rq, qvo, 2 * QCH);
     if (GPCA_ABLATE & 2) Q3 = Q0;
     if (GPCA_ABLATE & 4) GB = GA;
     gq2_decode<R, 0>(GA.g[0], opA);
@@ -430,9 +436,9 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     // that they interleave.  Operand sets alternate opA / opB.
 #define GQ2_PHASE(OPCUR, OPNXT, GNXT, BN, SN, QCUR, QNEXT, STEP)                            \
     { const uint32_t nst_ = (STEP) + 3u;                                                     \
-      if (!(GPCA_ABLATE & 2)) gq8_load_q(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }  \
+      if (!(GPCA_ABLATE & 2)) gq8_load_q<ND>(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }  \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    gq2_mfma_decode<R, SN>(OPCUR, QCUR, acc, GNXT.g[BN], OPNXT, lut);                        \
+    gq2_mfma_decode<R, SN, ND>(OPCUR, QCUR, acc, GNXT.g[BN], OPNXT, lut);                        \
     __builtin_amdgcn_sched_barrier(0);
     // block B of buffer GCUR: steps (B,0..3); the step after (B,3) is (BNX,0) of buffer GNX
 #define GQ2_BLOCK(GCUR, B, GNX, BNX, STEP0)                                   \
@@ -458,7 +464,7 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
         for (int e = 0; e < 16; ++e) {
             const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
             const float ri = rv[row], bi = bv[row];
-            const float gq = (float)(combine_digits(acc[t], e) * qs);
+            const float gq = (float)(combine_digits<ND == 3 ? 8 : 7>(acc[t], e) * qs);
             const float tv = ri * gq + bi * sj;
             csum += bi * tv;
             const float ov = scale_out ? ri * tv : tv;
@@ -468,6 +474,7 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     }
 }
 
+template <int ND>
 __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ G2, int64_t ld2, int64_t units, int64_t nsuper,
                                                      const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                      const float* __restrict__ rv, const float* __restrict__ bv,
@@ -490,9 +497,9 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
 #if GPCA_ABLATE & 16
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (; u + 4 <= u_end; u += 4) gq2_group<4>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut);
-    if (u + 2 <= u_end) { gq2_group<2>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 2; }
-    if (u + 1 <= u_end) { gq2_group<1>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 1; }
+    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut);
+    if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 2; }
+    if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 1; }
     const float o = csum + __shfl_xor(csum, 32);
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
     if (h == 0) { cpart[wave * 32 + c] = o; apart[wave * 32 + c] = (double)am; }
@@ -506,10 +513,11 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
 
 void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                     const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                    double* apart, int scale_out) {
+                    double* apart, int scale_out, int nd) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nsuper = Npad / 512;   // Npad is a multiple of 1024 in 2-bit mode -> even
-    hipLaunchKernelGGL(k_gq_2bit, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+    if (nd == 3) hipLaunchKernelGGL(k_gq_2bit<3>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+    else hipLaunchKernelGGL(k_gq_2bit<kDigits>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
 }
 
 // ---- K2, packed.  Lane (c, h) loads ONE byte (4 samples) from each of its 16 SNP rows; the four waves of a workgroup
@@ -1081,7 +1089,7 @@ __device__ __forceinline__ void gttx_decode(const GttXG<PACKED>& b, Gtt2Ops& o, 
 struct GttXT { i32x4 t[kDigits]; };
 // the 16 MFMAs of the current block; after each one a micro-step of the next block's decode, and (first four slots) the
 // LDS reads of the next block's digit operands
-template <bool PACKED>
+template <bool PACKED, int ND = kDigits>
 __device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i32x16 (&acc)[4][kDigits],
                                            const GttXG<PACKED>& gn, Gtt2Ops& on, GttXT& tn, const i32x4* lds_next, unsigned bsh) {
     unsigned x[4], y[4];
@@ -1089,9 +1097,9 @@ __device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i
     for (int d = 0; d < kDigits; ++d)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tc.t[d], oc.bt[t], acc[t][d], 0, 0, 0);
+            if (d < ND) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tc.t[d], oc.bt[t], acc[t][d], 0, 0, 0);   // (three-plane mode: the last four slots carry only decode work)
             const int m = d * 4 + t;
-            if (m < kDigits) tn.t[m] = lds_next[m * 64];
+            if (m < ND) tn.t[m] = lds_next[m * 64];
             gttx_decode_step<PACKED>(gn, on, x, y, m, bsh);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1363,6 +1371,7 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
 struct GtpStage { i32x4 t[4][kDigits][64]; char g[4][4096]; };     // 16 KiB of planes + 16 KiB of genotype rows
 struct GtpSmem { GtpStage stg[4]; };
 
+template <int ND>
 __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Mpad, int64_t Npad,
                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
                                                    int64_t ngroups, int64_t rows_per_wave, int xcd_remap) {
@@ -1430,7 +1439,7 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
     read_g(GA, 0, 0);
     read_g(GB, 0, 1);
 #pragma unroll
-    for (int d = 0; d < kDigits; ++d) TA.t[d] = sm->stg[0].t[0][d][lane];
+    for (int d = 0; d < ND; ++d) TA.t[d] = sm->stg[0].t[0][d][lane];
     gttx_decode<true>(GA, OA, bsh);
 
     // one phase: TC/OC = operands of block b; GN (registers of block b+1) -> ON, TN (planes of block b+1 at TSLOT/TBLK);
@@ -1439,7 +1448,7 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
     {                                                                                                    \
         read_g(GR, (RS), (RB));                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                               \
-        gttx_phase<true>(TC, OC, acc, GN, ON, TN, &sm->stg[(TSLOT)].t[(TBLK)][0][lane], bsh);            \
+        gttx_phase<true, ND>(TC, OC, acc, GN, ON, TN, &sm->stg[(TSLOT)].t[(TBLK)][0][lane], bsh);            \
         __builtin_amdgcn_sched_barrier(0);                                                               \
     }
     for (int64_t st = 0; st < nstage; ++st) {
@@ -1463,21 +1472,25 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
         for (int e = 0; e < 16; e += 2) {
             const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
             double2 o;
-            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
+            o.x = combine_digits<ND == 3 ? 8 : 7>(acc[t], e); o.y = combine_digits<ND == 3 ? 8 : 7>(acc[t], e + 1);
             *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
         }
     }
 }
 
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
-                 const Gtt8Plan& plan) {
-    static const int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_p), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)sizeof(GtpSmem));
-    if (attr != 0) return attr;
+                 const Gtt8Plan& plan, int nd) {
+    static const int attr4 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_p<kDigits>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)sizeof(GtpSmem));
+    static const int attr3 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_p<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)sizeof(GtpSmem));
+    if (attr4 != 0 || attr3 != 0) return attr4 ? attr4 : attr3;
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     static const int remap = getenv("GPCA_GTT_XCD") ? atoi(getenv("GPCA_GTT_XCD")) : 1;
-    hipLaunchKernelGGL(k_gtt_p, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
-                       plan.rows_per_wave, remap);
+    if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
+                                    plan.rows_per_wave, remap);
+    else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
+                            plan.rows_per_wave, remap);
     return 0;
 }
 
@@ -1529,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_col_absmax(const T* __restrict__ X, int
 }
 // scale[j] = colmax_j / S (multiplier back to real units), inv[j] = S / colmax_j; colmax 0 -> scale 0, inv 0
 __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict__ part, int64_t P, double* __restrict__ scale,
-                                                       double* __restrict__ inv) {
+                                                       double* __restrict__ inv, double S) {
     __shared__ double red[1024];
     const int cc = threadIdx.x & 31, pg = threadIdx.x >> 5;   // 32 part-groups
     double a = 0.0;
@@ -1538,7 +1551,6 @@ __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict_
     __syncthreads();
     if (pg != 0) return;
     for (int g = 1; g < 32; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
-    const double S = kDigitScale;
     scale[cc] = a > 0.0 ? a / S : 0.0;
     inv[cc] = a > 0.0 ? S / a : 0.0;
 }
@@ -1547,7 +1559,7 @@ __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict_
 // layout 1 (packed K1): block = MFMA step (b, s) of a 128-row group -> row 128*(blk/4) + 64*hh + 16*(blk%4) + j
 template <typename T>
 __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64_t rows, int64_t rows_pad,
-                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout) {
+                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int nd) {
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk * 32 >= rows_pad) return;
@@ -1566,7 +1578,8 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
 #pragma unroll
         for (int d = 0; d < kDigits; ++d) {
             long long dg;
-            if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
+            if (nd == 3) { if (d < 2) { dg = ((v + 128) & 255) - 128; v = (v - dg) >> 8; } else { dg = v; v = 0; } }    // base 256, plane 3 = 0
+            else if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
             w[d][j >> 2] |= ((unsigned)(dg & 0xff)) << (8 * (j & 3));
         }
     }
@@ -1577,28 +1590,29 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
 
 template <typename T>
 static void quantize_t(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, double* part, double* scale, double* inv,
-                       int8_t* Xd, int layout) {
+                       int8_t* Xd, int layout, int nd) {
     const int64_t P = absmax_num_parts(rows);
     hipLaunchKernelGGL((k_col_absmax<T>), dim3((unsigned)P), dim3(256), 0, st, X, rows, part);
-    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv);
+    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv, digit_scale(nd));
     const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout);
+    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd);
 }
 // abs-max partials already produced by the kernel that wrote X (K1 epilogue): finish the scale and quantise
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
-                                double* scale, double* inv, int8_t* Xd, int layout) {
-    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, apart, P, scale, inv);
+                                double* scale, double* inv, int8_t* Xd, int layout, int nd) {
+    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, apart, P, scale, inv, digit_scale(nd));
     const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<float>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout);
+    hipLaunchKernelGGL((k_quantize<float>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd);
 }
 // quantise X (f64) with a column scale that is already on the device (k_finish_q)
-void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout) {
+void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout,
+                                   int nd) {
     const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<double>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, inv, Xd, layout);
+    hipLaunchKernelGGL((k_quantize<double>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, inv, Xd, layout, nd);
 }
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout); }
+                         double* inv, int8_t* Xd, int layout, int nd) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd); }
 void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd, layout); }
+                         double* inv, int8_t* Xd, int layout, int nd) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd); }
 
 }  // namespace gpca

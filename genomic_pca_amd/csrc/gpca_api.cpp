@@ -96,6 +96,7 @@ struct gpca_handle {
     double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false; int64_t apart_parts = 0;   // column abs-max partials of T' from the K1 epilogue
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
+    int nd = 4;           // digit planes of the exact path (gpca_config.digit_planes): 4 x base 128, or 3 x base 256 (packed storage)
     int gtt_dma = 1;      // K2 (int8-resident) by LDS-DMA (GPCA_GTT_DMA=0: register-staged k_gtt_x)
     int gq_dma = 1;       // K1 (int8-resident) genotype loads by LDS-DMA, full-line pieces (GPCA_GQ_DMA=0: register-staged k_gq_x)
     int lds_planes = 1;   // share the digit planes of the exact GEMMs through LDS (GPCA_LDS_PLANES=0 disables)
@@ -197,6 +198,12 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     h->storage = cfg ? cfg->storage : GPCA_STORE_INT8;
     if (h->storage != GPCA_STORE_INT8 && h->storage != GPCA_STORE_2BIT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown storage mode"); }
     if (h->storage == GPCA_STORE_2BIT && h->precision != GPCA_PREC_I8_EXACT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: GPCA_STORE_2BIT requires GPCA_PREC_I8_EXACT"); }
+    {
+        const int dp = cfg ? cfg->digit_planes : 0;
+        if (dp != 0 && dp != 3 && dp != 4) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes must be 0, 3 or 4"); }
+        if (dp == 3 && !(h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT)) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes = 3 is implemented for GPCA_PREC_I8_EXACT with GPCA_STORE_2BIT"); }
+        h->nd = dp == 3 ? 3 : 4;
+    }
     // tuning knobs (resident-wave targets of the two GEMM grids); defaults are the tuned values
     if (const char* e = getenv("GPCA_GQ_WAVES")) h->gq_waves_target = std::max(4, atoi(e));
     if (const char* e = getenv("GPCA_GTT_WAVES")) h->gtt_waves_target = std::max(4, atoi(e));
@@ -658,8 +665,8 @@ static int stage_AtT(gpca_handle* h) {
     const double elems = (double)h->M * (double)h->N;
     if (h->precision == GPCA_PREC_I8_EXACT) {
         // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64
-        if (h->apart_valid) launch_quantize_f32_premax(h->st, h->dT, h->Mpad, h->Mpad, h->d_apart, h->apart_parts, h->d_tscale, h->d_tinv, h->dTd, 0);
-        else launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd);
+        if (h->apart_valid) launch_quantize_f32_premax(h->st, h->dT, h->Mpad, h->Mpad, h->d_apart, h->apart_parts, h->d_tscale, h->d_tinv, h->dTd, 0, h->nd);
+        else launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd, 0, h->nd);
         h->apart_valid = false;
         HIPCHK(hipGetLastError());
         {
@@ -668,8 +675,8 @@ static int stage_AtT(gpca_handle* h) {
                 const int e = launch_gtt_d(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
                 if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
             }
-            else if (h->lds_planes && h->gtt_dma && h->storage == GPCA_STORE_2BIT) {
-                const int e = launch_gtt_p(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+            else if (((h->lds_planes && h->gtt_dma) || h->nd == 3) && h->storage == GPCA_STORE_2BIT) {   // (three planes: only this kernel)
+                const int e = launch_gtt_p(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8, h->nd);
                 if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_p: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
             }
             else if (h->lds_planes) launch_gtt_x(h->st, h->storage == GPCA_STORE_2BIT ? (const void*)h->dG2 : (const void*)h->dG, h->storage == GPCA_STORE_2BIT,
@@ -698,7 +705,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     if (h->precision == GPCA_PREC_I8_EXACT) {
         {
             ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves; }
+            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out, h->nd); h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves; }
             else if (h->lds_planes && h->gq_dma) {
                 const int e = launch_gq_d(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out);
                 if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
@@ -738,10 +745,10 @@ static int stage_orth(gpca_handle* h) {
     // dY now holds the orthonormal basis in f64: s = Q^T 1 and (exact-integer path) the digit scale of Q, then its planes
     const bool i8 = h->precision == GPCA_PREC_I8_EXACT;
     launch_finish_q(h->st, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L, tail_num_parts(h->ldg), L, h->d_s64, h->d_s32,
-                    i8 ? h->d_qscale : nullptr, i8 ? h->d_qinv : nullptr);
+                    i8 ? h->d_qscale : nullptr, i8 ? h->d_qinv : nullptr, h->nd);
     HIPCHK(hipGetLastError());
     if (i8) {
-        launch_quantize_f64_prescaled(h->st, h->dY, h->N, h->ldg, h->d_qinv, h->dQd, h->storage == GPCA_STORE_2BIT ? 1 : 0);
+        launch_quantize_f64_prescaled(h->st, h->dY, h->N, h->ldg, h->d_qinv, h->dQd, h->storage == GPCA_STORE_2BIT ? 1 : 0, h->nd);
         HIPCHK(hipGetLastError());
     }
     return GPCA_OK;

@@ -74,12 +74,15 @@ void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double
 // X[n][:] <- X[n][:] * Z  (Z: [L][L] f64, in place); optionally also the blocked f32 basis Qb (rows_pad rows, pad rows zeroed)
 // the digit planes hold round(x * S / colmax): S = 0.49 * 128^4 keeps every digit of the signed base-128 expansion in int8
 constexpr double kDigitScale = 0.49 * 268435456.0;
+// three-plane mode (packed kernels only): round(x * S3 / colmax) in three signed base-256 digits, S3 = 0.49 * 256^3
+constexpr double kDigitScale3 = 0.49 * 16777216.0;
+inline double digit_scale(int nd) { return nd == 3 ? kDigitScale3 : kDigitScale; }
 // last right-multiplication of CholeskyQR2 + partials of Q^T 1 and of the column abs-max; k_finish_q reduces them
 int64_t tail_num_parts(int64_t rows_pad);
 void launch_apply_right_tail(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout, int64_t rows_pad,
                              double* csum_part, double* amax_part);
 void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax_part, int64_t P, int L, double* s64, float* s32,
-                     double* scale, double* inv);
+                     double* scale, double* inv, int nd = 4);
 // W = R^T R (n x n, pitch ld <= 64), Z = R^-1; *flag = j + 1 on a non-positive pivot (first failure wins)
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag);
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qb,
@@ -120,9 +123,9 @@ int64_t absmax_num_parts(int64_t rows);
 // X [rows][32] row-major -> digit planes Xd [rows_pad/32][kDigits][64][16 B]; scale[j] = colmax_j / S, inv = 1/scale
 // layout 0: 32 consecutive rows per block; layout 1: the MFMA-step order of the packed (2-bit) G Q kernel
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout = 0);
+                         double* inv, int8_t* Xd, int layout = 0, int nd = 4);
 void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout = 0);
+                         double* inv, int8_t* Xd, int layout = 0, int nd = 4);
 
 // ---- 2-bit resident genotypes (store2bit.hip, gemm_i8.hip) -----------------------------------------------------
 constexpr int64_t kSamplePad2bit = 1024;   // samples per row padded to this (ld2 = Npad / 4 bytes)
@@ -136,14 +139,14 @@ void launch_standardize_block_2bit(hipStream_t st, const uint8_t* G2, int64_t ld
                                    unsigned long long* err_idx);
 void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                     const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                    double* apart, int scale_out);
-void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout);
+                    double* apart, int scale_out, int nd = 4);
+void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd = 4);
 // quantise X whose column abs-max partials [P][32] were already produced by the kernel that wrote it (K1 epilogue)
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
-                                double* scale, double* inv, int8_t* Xd, int layout);
+                                double* scale, double* inv, int8_t* Xd, int layout, int nd = 4);
 // K2 for packed genotypes: stage-wise cooperative LDS-DMA (ring of four stage buffers); returns a hipError_t value
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
-                 const Gtt8Plan& plan);
+                 const Gtt8Plan& plan, int nd = 4);
 // K2 with genotypes and digit planes brought in by LDS-DMA (int8-resident); returns a hipError_t value (0 = ok)
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan);

@@ -649,7 +649,7 @@ void launch_apply_right_tail(hipStream_t st, double* X, int64_t rows, int L, con
 // scale = max / S, inv = S / max (0 for an all-zero column), S = kDigitScale.  One workgroup.
 __global__ __launch_bounds__(1024) void k_finish_q(const double* __restrict__ csum_part, const double* __restrict__ amax_part,
                                                    int64_t P, int L, double* __restrict__ s64, float* __restrict__ s32,
-                                                   double* __restrict__ scale, double* __restrict__ inv) {
+                                                   double* __restrict__ scale, double* __restrict__ inv, double S) {
     __shared__ double rs[1024], rm[1024];
     const int cc = threadIdx.x % L, pg = threadIdx.x / L, G = 1024 / L;
     double a = 0.0, m = 0.0;
@@ -659,11 +659,11 @@ __global__ __launch_bounds__(1024) void k_finish_q(const double* __restrict__ cs
     if (pg != 0) return;
     for (int g = 1; g < G; ++g) { a += rs[g * L + cc]; m = fmax(m, rm[g * L + cc]); }
     s64[cc] = a; s32[cc] = (float)a;
-    if (scale) { scale[cc] = m > 0.0 ? m / kDigitScale : 0.0; inv[cc] = m > 0.0 ? kDigitScale / m : 0.0; }
+    if (scale) { scale[cc] = m > 0.0 ? m / S : 0.0; inv[cc] = m > 0.0 ? S / m : 0.0; }
 }
 void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax_part, int64_t P, int L, double* s64, float* s32,
-                     double* scale, double* inv) {
-    hipLaunchKernelGGL(k_finish_q, dim3(1), dim3(1024), 0, st, csum_part, amax_part, P, L, s64, s32, scale, inv);
+                     double* scale, double* inv, int nd) {
+    hipLaunchKernelGGL(k_finish_q, dim3(1), dim3(1024), 0, st, csum_part, amax_part, P, L, s64, s32, scale, inv, digit_scale(nd));
 }
 
 // CholeskyQR's small factorisation on the device: W (n x n, pitch NN, upper triangle used) = R^T R, Z = R^-1 (upper,

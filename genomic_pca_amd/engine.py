@@ -47,10 +47,11 @@ class QcConfig:
 class GpcaEngine:
     """One opaque ``gpca_handle``: one GPU, one SNP-row shard of the genotype matrix."""
 
-    def __init__(self, device: int = -1, precision: int = _lib.PREC_F32_MFMA, storage: int = _lib.STORE_INT8):
+    def __init__(self, device: int = -1, precision: int = _lib.PREC_F32_MFMA, storage: int = _lib.STORE_INT8,
+                 digit_planes: int = 0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        cfg = _lib.gpca_config(device=device, precision=precision, storage=storage)
+        cfg = _lib.gpca_config(device=device, precision=precision, storage=storage, digit_planes=digit_planes)
         rc = self._lib.gpca_create(C.byref(cfg), C.byref(self._h))
         if rc != _lib.GPCA_OK:
             raise GpcaError(rc, self._lib.gpca_last_error(None).decode())

@@ -69,7 +69,11 @@ typedef struct gpca_config {
     int32_t device;    /* HIP ordinal; -1 = current device */
     int32_t precision; /* gpca_precision */
     int32_t storage;   /* gpca_storage */
-    int32_t reserved[5];
+    int32_t digit_planes; /* GPCA_PREC_I8_EXACT only.  0 or 4: four signed base-128 digit planes of the skinny operand (28-bit
+                             fixed point per column, the default).  3: three signed base-256 planes (24-bit, about f32
+                             accuracy; exact integer accumulation as before) -- a quarter less matrix-core work; implemented
+                             for GPCA_STORE_2BIT, whose kernels are matrix-core bound. */
+    int32_t reserved[4];
 } gpca_config;
 
 /* SNP QC thresholds = MicroarrayDataPreparerConfig, main.rs:302-309 / prepare.rs:1281-1311,1363.

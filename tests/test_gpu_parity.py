@@ -681,3 +681,29 @@ def test_rsvd_i8_sketch_width_and_iteration_edges(gpca, oracle, store, k, oversa
         assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
         assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
         assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]) < TOL_PC
+
+
+# ------------------------------------------------------------------------------------------------
+# three digit planes (gpca_config.digit_planes = 3): packed residency, 24-bit fixed point, exact integer accumulation
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,P,k", [(20000, 1000, 16, 10), (3000, 1500, 10, 6), (130, 70, 4, 3)])
+def test_rsvd_parity_2bit_three_planes(gpca, oracle, M, N, P, k):
+    from genomic_pca_amd import _lib
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT, digit_planes=3) as e3, \
+         gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT) as e4:
+        G, r, b, R = _rsvd_case(gpca, oracle, e3, M, N, P, k, seed=1, fst=0.2)
+        assert np.max(np.abs(e3.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+        assert oracle.max_abs_dpc(e3.scores(f64=True), R["scores"]) < TOL_PC
+        assert oracle.max_abs_dpc(e3.loadings().astype(np.float64), R["loadings"]) < TOL_PC
+        # against the four-plane engine: the same integers, a coarser fixed point (2^-24 instead of 2^-28 of the column max)
+        e4.upload_genotypes_i8(G); e4.snp_stats(gpca.QcConfig.none()); e4.rsvd(k, 10, 2, seed=1)
+        assert oracle.max_abs_dpc(e3.scores(f64=True), e4.scores(f64=True)) < 2e-6
+        assert oracle.max_abs_dpc(e3.transform(), e4.transform()) < 2e-6
+
+
+def test_three_planes_need_packed_exact_path(gpca):
+    from genomic_pca_amd import _lib
+    with pytest.raises(gpca.GpcaError):
+        gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_INT8, digit_planes=3)
+    with pytest.raises(gpca.GpcaError):
+        gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT, digit_planes=5)
