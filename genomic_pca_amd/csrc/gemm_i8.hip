@@ -396,7 +396,7 @@ __device__ __forceinline__ void gq2_mfma_decode(const i32x4 (&op)[R], const Gq8Q
             else acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[t], q.q[d], acc[t][d], 0, 0, 0);
             const int m = d * R + t;          // 4R MFMAs <-> 4R output dwords (tile m / 4, dword m % 4)
             if (GPCA_ABLATE & 1) opn[m >> 2][m & 3] = gn[m >> 2][SN];
-            else opn[m >> 2][m & 3] = (int)lut[((unsigned)gn[m >> 2][SN] >> (8 * (m & 3))) & 0xffu];   // 2 VALU + 1 LDS read
+            else opn[m >> 2][m & 3] = (int)lut[((((unsigned)gn[m >> 2][SN] >> (8 * (m & 3))) & 0xffu) << 5)];   // 2 VALU + 1 LDS read (lut = this lane's copy)
             __builtin_amdgcn_sched_barrier(0);
         }
 }
@@ -491,8 +491,11 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
     const float sj = sv[c];
     const double qs = qscale[c];
     // byte (4 two-bit codes) -> 4 int8 bytes: 256-entry table in LDS; the spread then costs 2 VALU + 1 ds_read per dword
-    __shared__ unsigned lut[256];
-    lut[threadIdx.x] = (unsigned)spread4(threadIdx.x, 0);
+    // 32 interleaved copies (entry v of copy j at word 32 v + j): lane l reads copy l % 32, i.e. always bank l % 32 -- a single
+    // 1-KiB table made 69 % of this kernel's LDS cycles bank conflicts (random bytes of 32 lanes over 32 banks)
+    __shared__ unsigned lut_all[256 * 32];
+    for (int e = threadIdx.x; e < 256 * 32; e += 256) lut_all[e] = (unsigned)spread4((unsigned)(e >> 5), 0);
+    const unsigned* lut = lut_all + (lane & 31);
     __syncthreads();
 #if GPCA_ABLATE & 16
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -808,8 +811,9 @@ void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& pla
 // arrives as 8-row x 128-byte pieces written straight into LDS by `buffer_load_dwordx4 ... lds` (1 KiB per wave
 // instruction, no VGPR destination) and is read back in operand shape with ds_read_b128.
 //   * unit = one 32-row tile x one 128-sample stage = 4 KiB = 4 pieces.  The LDS image of a piece is lane-linear
-//     (lane l -> base + 16 l); lane l fetches row 8 i + (l >> 3), 16-byte chunk (l & 7) ^ (l >> 3), so row r keeps chunk
-//     k at position k ^ (r & 7) and the operand read (row c, chunk 2 s + h) is bank-conflict free.
+//     (lane l -> base + 16 l); lane l fetches row r = 8 i + (l >> 3), 16-byte chunk (l & 7) ^ ((r >> 1) & 7), so row r keeps
+//     chunk k at position k ^ ((r >> 1) & 7) and the operand read (row c, chunk 2 s + h) is bank-conflict free for
+//     ds_read_b128's lane groups.
 //   * each wave owns a ring of 6 unit slots and walks its R = 4 tiles tile-outer inside a stage (the 16 digit-plane
 //     operands of the stage sit in registers), so units are consumed strictly in order; the unit just finished is
 //     re-filled with the unit 6 ahead.  The digit planes of stage s+1 are DMA-ed (wave w: plane w) at the start of
@@ -865,7 +869,11 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     const i32x4 rg = gqd_rsrc(G + row0 * ldg);
     const i32x4 rq = gqd_rsrc(Qd + wv * 1024);
     const uint32_t ld32 = (uint32_t)ldg;
-    const uint32_t gvo = (uint32_t)(lane >> 3) * ld32 + 16u * (uint32_t)((lane & 7) ^ (lane >> 3));
+    // row r keeps chunk k at position k ^ ((r >> 1) & 7): with ds_read_b128's lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...)
+    // the 8 even and the 8 odd rows of a group then land on 16 distinct bank quads (k ^ (r & 7) was 2-way: SQ_LDS_BANK_CONFLICT =
+    // a third of the LDS cycles).  Piece i holds rows 8 i + (l >> 3), so (r >> 1) & 7 = (4 i + (l >> 4)) & 7: one offset per parity of i.
+    const uint32_t gvo_e = (uint32_t)(lane >> 3) * ld32 + 16u * (uint32_t)((lane & 7) ^ (lane >> 4));
+    const uint32_t gvo_o = (uint32_t)(lane >> 3) * ld32 + 16u * (uint32_t)((lane & 7) ^ (lane >> 4) ^ 4);
     const uint32_t qvo = (uint32_t)(lane * 16);
     uint32_t toff[R];                                   // wave-uniform byte offset of tile t (tiles past the range: tile 0)
 #pragma unroll
@@ -874,9 +882,9 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
     const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (S * 4096u);
     const char* gl = reinterpret_cast<const char*>(&sm->g[wv][0][0]);
-    uint32_t loff[4];                                   // operand read: row c, chunk (2 s + h) ^ (c & 7)
+    uint32_t loff[4];                                   // operand read: row c, chunk 2 s + h at position (2 s + h) ^ ((c >> 1) & 7)
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) loff[s4] = (uint32_t)(c * 128 + (((2 * s4 + h) ^ (c & 7)) * 16));
+    for (int s4 = 0; s4 < 4; ++s4) loff[s4] = (uint32_t)(c * 128 + (((2 * s4 + h) ^ ((c >> 1) & 7)) * 16));
 
     i32x16 acc[R][kDigits];
 #pragma unroll
@@ -891,7 +899,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     {                                                                                                     \
         const uint32_t so_ = toff[(T)] + (uint32_t)(ST) * 128u;                                           \
         const uint32_t la_ = lds_g + (uint32_t)(SLOT) * 4096u;                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma<NT>(la_ + 1024u * i, gvo, rg, so_ + 8u * i * ld32); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma<NT>(la_ + 1024u * i, (i & 1) ? gvo_o : gvo_e, rg, so_ + 8u * i * ld32); \
     }
 #define GQD_ISSUE_Q(ST, QS)                                                                               \
     {                                                                                                     \

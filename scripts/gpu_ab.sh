@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for cfg in "$@"; do
   set -- $cfg
-  GPCA_GQ_WAVES=$1 GPCA_GTT_WAVES=$2 timeout -k 10 200 python bench.py --precision $3 $4 $5 --steps ${STEPS:-5} --warmup 1 --no-cpu-baseline --no-second-path > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
+  GPCA_GQ_WAVES=$1 GPCA_GTT_WAVES=$2 timeout -k 10 200 python bench.py --precision $3 $4 $5 $6 $7 --steps ${STEPS:-5} --warmup 1 --no-cpu-baseline --no-second-path > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
   python - "$cfg" <<'PY'
 import json, sys
 d = json.load(open('gpurun_out/ab.json'))

@@ -15,6 +15,6 @@ for r in csv.DictReader(open(f)):
     agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
     dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
 for k, v in agg.items():
-    if 'gq_f32' in k or 'gtt_f32' in k or 'snp_stats' in k:
+    if any(x in k for x in ('gq_f32', 'gtt_f32', 'snp_stats', 'gq_d', 'gtt_d', 'gq_2bit', 'gtt_p')):
         print(k, 'avg_ms=%.3f' % (sum(dur[k]) / len(dur[k])), {c: round(sum(x) / len(x)) for c, x in v.items()})
 PY
