@@ -927,20 +927,28 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int d = 0; d < kDigits; ++d) q[s4][d] = sm->q[st & 1][s4][d][lane];
-        if (st == 0) gcur = *reinterpret_cast<const i32x4*>(gl + loff[0]);     // unit 0 (slot 0) landed with Q(0)
+        if (st == 0) {                                   // unit 0 (slot 0) landed with Q(0)
+            gcur = *reinterpret_cast<const i32x4*>(gl + loff[0]);
+            gnxt = *reinterpret_cast<const i32x4*>(gl + loff[1]);
+        }
 #pragma unroll
         for (int t = 0; t < R; ++t) {
             const char* ub = gl + rslot * 4096u;
             const uint32_t nslot = rslot == S - 1 ? 0u : rslot + 1u;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                if (s4 < 3) {
-                    gnxt = *reinterpret_cast<const i32x4*>(ub + loff[s4 + 1]);
+                // operand reads run two MFMA groups ahead of their use (one group = 128 cycles did not always cover the LDS
+                // latency beside the DMA writes): steps 2 and 3 already read steps 0 and 1 of the next unit
+                i32x4 gfar;
+                if (s4 < 2) {
+                    gfar = *reinterpret_cast<const i32x4*>(ub + loff[s4 + 2]);
                 } else {
-                    // younger than the next unit: S - 2 unit fills + 1 plane batch (2 when a stage start falls in the window)
-                    if (S == 6) { if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>(); }
-                    else { if (t <= 1) gqd_wait_vm<28>(); else gqd_wait_vm<24>(); }
-                    gnxt = *reinterpret_cast<const i32x4*>(gl + nslot * 4096u + loff[0]);
+                    if (s4 == 2) {
+                        // younger than the next unit: S - 2 unit fills + 1 plane batch (2 when a stage start falls in the window)
+                        if (S == 6) { if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>(); }
+                        else { if (t <= 1) gqd_wait_vm<28>(); else gqd_wait_vm<24>(); }
+                    }
+                    gfar = *reinterpret_cast<const i32x4*>(gl + nslot * 4096u + loff[s4 - 2]);
                 }
 #pragma unroll
                 for (int d = 0; d < kDigits; ++d)
@@ -951,7 +959,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                     GQD_ISSUE_G(ist, it, rslot)
                     if (++it == R) { it = 0; ist = ist + 1 < nstage ? ist + 1 : 0; }
                 }
-                gcur = gnxt;
+                gcur = gnxt; gnxt = gfar;
             }
             rslot = nslot;
         }
