@@ -177,8 +177,8 @@ def main():
 
     M_local, N, k = a.snps, a.samples, a.components
     l = k + a.oversample
-    if a.precision == "i8" and l > 32:
-        a.precision = "f32"      # the exact-integer path covers l <= 32
+    if a.precision == "i8" and l > 64:
+        a.precision = "f32"      # (neither path goes beyond 64 columns; the f32 one gives the clearer error)
     M_total = M_local * world
     snp_offset = rank * M_local
     PREC = {"f32": g._lib.PREC_F32_MFMA, "i8": g._lib.PREC_I8_EXACT}

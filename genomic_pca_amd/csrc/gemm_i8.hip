@@ -86,7 +86,7 @@ __device__ __forceinline__ void gq8_compute(const i32x4 (&g)[R], const Gq8Q& q, 
 template <int R, int AUX>
 __device__ __forceinline__ void gq8_group(const int8_t* __restrict__ G, int64_t ldg, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
-                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float& csum, int64_t row0, int c, int h, int lane) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
     uint32_t gvo[R];
@@ -141,7 +141,7 @@ __device__ __forceinline__ void gq8_group(const int8_t* __restrict__ G, int64_t 
             const float gq = (float)(combine_digits(acc[t], e) * qs);
             const float tv = ri * gq + bi * sj;
             csum += bi * tv;
-            Tout[row * 32 + c] = scale_out ? ri * tv : tv;
+            Tout[row * ldt + c] = scale_out ? ri * tv : tv;
         }
     }
 }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_i8(const int8_t* __restrict__ G, 
                                                    const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                    const float* __restrict__ rv, const float* __restrict__ bv,
                                                    const float* __restrict__ sv, float* __restrict__ Tout,
-                                                   float* __restrict__ cpart, int scale_out) {
+                                                   float* __restrict__ cpart, int scale_out, int64_t ldt) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -162,20 +162,20 @@ __global__ __launch_bounds__(256, 1) void k_gq_i8(const int8_t* __restrict__ G, 
     float csum = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
-    for (; u + 4 <= u_end; u += 4) gq8_group<4, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane);
-    if (u + 2 <= u_end) { gq8_group<2, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 2; }
-    if (u + 1 <= u_end) { gq8_group<1, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, u * 32, c, h, lane); u += 1; }
+    for (; u + 4 <= u_end; u += 4) gq8_group<4, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, u * 32, c, h, lane);
+    if (u + 2 <= u_end) { gq8_group<2, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, u * 32, c, h, lane); u += 2; }
+    if (u + 1 <= u_end) { gq8_group<1, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, u * 32, c, h, lane); u += 1; }
     const float o = csum + __shfl_xor(csum, 32);
     if (h == 0) cpart[wave * 32 + c] = o;
 }
 
 void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
                   const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                  int scale_out) {
+                  int scale_out, int64_t ldt) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nsuper = (N + 255) / 256 * 2;   // 128-sample super-chunks, even count (= Npad / 128)
-    if (g_stream_nt) hipLaunchKernelGGL((k_gq_i8<2>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out);
-    else hipLaunchKernelGGL((k_gq_i8<0>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out);
+    if (g_stream_nt) hipLaunchKernelGGL((k_gq_i8<2>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
+    else hipLaunchKernelGGL((k_gq_i8<0>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,19 +316,19 @@ void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, i
 // Y[n][j] = c[j] + tscale[j] * sum_w Ypart[w][n][j]    (the integer sum is exact and order-independent)
 __global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
                                                      const double* __restrict__ cvec, const double* __restrict__ tscale,
-                                                     double* __restrict__ Y) {
+                                                     double* __restrict__ Y, int64_t ldy) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= N * 32) return;
     const int j = (int)(e & 31);
     const int64_t stride = Npad * 32;
     double s = 0.0;
     for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
-    Y[e] = cvec[j] + tscale[j] * s;
+    Y[(e >> 5) * ldy + j] = cvec[j] + tscale[j] * s;
 }
 void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
-                        const double* tscale, double* Y) {
+                        const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
-    hipLaunchKernelGGL(k_reduce_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y);
+    hipLaunchKernelGGL(k_reduce_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
 }
 
 // ================================================================================================
@@ -404,7 +404,7 @@ __device__ __forceinline__ void gq2_mfma_decode(const i32x4 (&op)[R], const Gq8Q
 template <int R, int ND = kDigits>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
-                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float& csum, float& amax, int64_t row0, int c, int h, int lane, const unsigned* lut) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
     uint32_t gvo[R];
@@ -469,7 +469,7 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
             csum += bi * tv;
             const float ov = scale_out ? ri * tv : tv;
             amax = fmaxf(amax, fabsf(ov));
-            Tout[row * 32 + c] = ov;
+            Tout[row * ldt + c] = ov;
         }
     }
 }
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
                                                      const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                      const float* __restrict__ rv, const float* __restrict__ bv,
                                                      const float* __restrict__ sv, float* __restrict__ Tout,
-                                                     float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
+                                                     float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -500,9 +500,9 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
 #if GPCA_ABLATE & 16
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut);
-    if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 2; }
-    if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, csum, amax, u * 32, c, h, lane, lut); u += 1; }
+    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax, u * 32, c, h, lane, lut);
+    if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax, u * 32, c, h, lane, lut); u += 2; }
+    if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax, u * 32, c, h, lane, lut); u += 1; }
     const float o = csum + __shfl_xor(csum, 32);
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
     if (h == 0) { cpart[wave * 32 + c] = o; apart[wave * 32 + c] = (double)am; }
@@ -516,11 +516,11 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
 
 void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                     const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                    double* apart, int scale_out, int nd) {
+                    double* apart, int scale_out, int nd, int64_t ldt) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nsuper = Npad / 512;   // Npad is a multiple of 1024 in 2-bit mode -> even
-    if (nd == 3) hipLaunchKernelGGL(k_gq_2bit<3>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
-    else hipLaunchKernelGGL(k_gq_2bit<kDigits>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out);
+    if (nd == 3) hipLaunchKernelGGL(k_gq_2bit<3>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
+    else hipLaunchKernelGGL(k_gq_2bit<kDigits>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
 }
 
 // ---- K2, packed.  Lane (c, h) loads ONE byte (4 samples) from each of its 16 SNP rows; the four waves of a workgroup
@@ -675,7 +675,7 @@ template <int R>
 __device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
                                           const int8_t* __restrict__ Qd, i32x4 (*tds)[4][kDigits][64], int wv, int lane, int c,
                                           int h, int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
-                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float& csum, float& amax) {
     const int64_t row0 = unit0 * 32;
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
@@ -750,7 +750,7 @@ __device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t 
                 csum += bi * tv;
                 const float ov = scale_out ? ri * tv : tv;
                 amax = fmaxf(amax, fabsf(ov));
-                Tout[row * 32 + c] = ov;
+                Tout[row * ldt + c] = ov;
             }
         }
     }
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
                                                   float* __restrict__ cpart, double* __restrict__ apart, int scale_out,
-                                                  int rmax) {
+                                                  int rmax, int64_t ldt) {
     __shared__ i32x4 tds[2][4][kDigits][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -777,17 +777,17 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
         if (rem > 8 && rmax >= 4) {           // 4 tiles per wave
             const int64_t mine = u + 4 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
             u += 16;
         } else if (rem > 4 && rmax >= 2) {    // 2 tiles per wave
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
             u += 8;
         } else {                 // 1 tile per wave
             const int64_t mine = u + wv;
             const int nv = mine < u1 ? 1 : 0;
-            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
             u += 4;
         }
     }
@@ -798,11 +798,11 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
 
 void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                 int scale_out) {
+                 int scale_out, int64_t ldt) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;    // Npad is a multiple of 256 -> even
     static const int rmax = getenv("GPCA_GQ_R") ? atoi(getenv("GPCA_GQ_R")) : 4;
-    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, rmax);
+    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, rmax, ldt);
 }
 
 // ================================================================================================
@@ -862,7 +862,7 @@ template <int NT, int S>
 __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
                                           const int8_t* __restrict__ Qd, GqdSmemT<S>* sm, int wv, int lane, int c, int h,
                                           int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
-                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out,
+                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float& csum, float& amax) {
     constexpr int R = 4;
     const int64_t row0 = unit0 * 32;
@@ -979,7 +979,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                 csum += bi * tv;
                 const float ov = scale_out ? ri * tv : tv;
                 amax = fmaxf(amax, fabsf(ov));
-                Tout[row * 32 + c] = ov;
+                Tout[row * ldt + c] = ov;
             }
         }
     }
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
-                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out) {
+                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmemT<S>* sm = reinterpret_cast<GqdSmemT<S>*>(gqd_smem);
     i32x4 (*tds)[4][kDigits][64] = sm->q;
@@ -1012,17 +1012,17 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
             const int64_t base = take >> 2, extra = take & 3;
             const int64_t mine = u + wv * base + (wv < extra ? wv : extra);
             const int nv = (int)(base + (wv < extra ? 1 : 0));
-            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
             u += take;
         } else if (rem > 4) {    // tails: the register-staged rounds
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
             u += 8;
         } else {
             const int64_t mine = u + wv;
             const int nv = mine < u1 ? 1 : 0;
-            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, csum, amax);
+            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
             u += 4;
         }
     }
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
 
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                int scale_out) {
+                int scale_out, int64_t ldt) {
     static const int slots = getenv("GPCA_GQ_SLOTS") ? atoi(getenv("GPCA_GQ_SLOTS")) : 6;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;
@@ -1043,7 +1043,7 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GqdSmemT<SV>)); \
         if (attr != 0) return attr;                                                                                            \
         hipLaunchKernelGGL((k_gq_d<NTV, SV>), grid, blk, sizeof(GqdSmemT<SV>), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, \
-                           Tout, cpart, apart, scale_out);                                                                     \
+                           Tout, cpart, apart, scale_out, ldt);                                                                \
     }
     if (slots == 7) { if (g_dma_nt) GPCA_GQD(1, 7) else GPCA_GQD(0, 7) }
     else { if (g_dma_nt) GPCA_GQD(1, 6) else GPCA_GQD(0, 6) }
@@ -1542,13 +1542,13 @@ constexpr int kAbsmaxRowsPerBlock = 1024;
 int64_t absmax_num_parts(int64_t rows) { return (rows + kAbsmaxRowsPerBlock - 1) / kAbsmaxRowsPerBlock; }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_col_absmax(const T* __restrict__ X, int64_t rows, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_col_absmax(const T* __restrict__ X, int64_t rows, double* __restrict__ part, int64_t ldx) {
     __shared__ double red[256];
     const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int64_t r0 = (int64_t)blockIdx.x * kAbsmaxRowsPerBlock;
     const int64_t r1 = (r0 + kAbsmaxRowsPerBlock < rows) ? r0 + kAbsmaxRowsPerBlock : rows;
     double a = 0.0;
-    for (int64_t n = r0 + rg; n < r1; n += 8) { const double v = fabs((double)X[n * 32 + cc]); a = v > a ? v : a; }
+    for (int64_t n = r0 + rg; n < r1; n += 8) { const double v = fabs((double)X[n * ldx + cc]); a = v > a ? v : a; }
     red[threadIdx.x] = a;
     __syncthreads();
     if (rg == 0) {
@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict_
 // layout 1 (packed K1): block = MFMA step (b, s) of a 128-row group -> row 128*(blk/4) + 64*hh + 16*(blk%4) + j
 template <typename T>
 __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64_t rows, int64_t rows_pad,
-                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int nd) {
+                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int nd, int64_t ldx) {
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk * 32 >= rows_pad) return;
@@ -1589,7 +1589,7 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int64_t row = layout ? (blk >> 2) * 128 + 64 * hh + 16 * (blk & 3) + j : blk * 32 + 16 * hh + j;
-        const double x = row < rows ? (double)X[row * 32 + cc] : 0.0;
+        const double x = row < rows ? (double)X[row * ldx + cc] : 0.0;
         long long v = __double2ll_rn(x * sc);
 #pragma unroll
         for (int d = 0; d < kDigits; ++d) {
@@ -1606,29 +1606,29 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
 
 template <typename T>
 static void quantize_t(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, double* part, double* scale, double* inv,
-                       int8_t* Xd, int layout, int nd) {
+                       int8_t* Xd, int layout, int nd, int64_t ldx) {
     const int64_t P = absmax_num_parts(rows);
-    hipLaunchKernelGGL((k_col_absmax<T>), dim3((unsigned)P), dim3(256), 0, st, X, rows, part);
+    hipLaunchKernelGGL((k_col_absmax<T>), dim3((unsigned)P), dim3(256), 0, st, X, rows, part, ldx);
     hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv, digit_scale(nd));
     const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd);
+    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
 }
 // abs-max partials already produced by the kernel that wrote X (K1 epilogue): finish the scale and quantise
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
-                                double* scale, double* inv, int8_t* Xd, int layout, int nd) {
+                                double* scale, double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) {
     hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, apart, P, scale, inv, digit_scale(nd));
     const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<float>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd);
+    hipLaunchKernelGGL((k_quantize<float>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
 }
 // quantise X (f64) with a column scale that is already on the device (k_finish_q)
 void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout,
-                                   int nd) {
+                                   int nd, int64_t ldx) {
     const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<double>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, inv, Xd, layout, nd);
+    hipLaunchKernelGGL((k_quantize<double>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, inv, Xd, layout, nd, ldx);
 }
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout, int nd) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd); }
+                         double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd, ldx); }
 void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout, int nd) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd); }
+                         double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd, ldx); }
 
 }  // namespace gpca

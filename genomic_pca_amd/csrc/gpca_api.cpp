@@ -664,29 +664,36 @@ static int stage_sum_c(gpca_handle* h, int64_t parts) {
 static int stage_AtT(gpca_handle* h) {
     const double elems = (double)h->M * (double)h->N;
     if (h->precision == GPCA_PREC_I8_EXACT) {
-        // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64
-        if (h->apart_valid) launch_quantize_f32_premax(h->st, h->dT, h->Mpad, h->Mpad, h->d_apart, h->apart_parts, h->d_tscale, h->d_tinv, h->dTd, 0, h->nd);
-        else launch_quantize_f32(h->st, h->dT, h->Mpad, h->Mpad, h->d_part64, h->d_tscale, h->d_tinv, h->dTd, 0, h->nd);
-        h->apart_valid = false;
-        HIPCHK(hipGetLastError());
-        {
-            ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->lds_planes && h->gtt_dma && h->storage != GPCA_STORE_2BIT) {
-                const int e = launch_gtt_d(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
-                if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
+        // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64.
+        // The kernels are 32 columns wide: a 64-column sketch (32 < l <= 64) runs as two column halves over the same genotypes.
+        const int L = h->L, halves = L / 32;
+        const size_t aphalf = (size_t)h->gqplan.waves * 32;
+        for (int hf = 0; hf < halves; ++hf) {
+            const float* Th = h->dT + 32 * hf;
+            double* tsc = h->d_tscale + 32 * hf; double* tin = h->d_tinv + 32 * hf;
+            if (h->apart_valid) launch_quantize_f32_premax(h->st, Th, h->Mpad, h->Mpad, h->d_apart + hf * aphalf, h->apart_parts, tsc, tin, h->dTd, 0, h->nd, L);
+            else launch_quantize_f32(h->st, Th, h->Mpad, h->Mpad, h->d_part64, tsc, tin, h->dTd, 0, h->nd, L);
+            HIPCHK(hipGetLastError());
+            {
+                ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l / halves, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
+                if (h->lds_planes && h->gtt_dma && h->storage != GPCA_STORE_2BIT) {
+                    const int e = launch_gtt_d(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
+                }
+                else if (((h->lds_planes && h->gtt_dma) || h->nd == 3) && h->storage == GPCA_STORE_2BIT) {   // (three planes: only this kernel)
+                    const int e = launch_gtt_p(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8, h->nd);
+                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_p: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
+                }
+                else if (h->lds_planes) launch_gtt_x(h->st, h->storage == GPCA_STORE_2BIT ? (const void*)h->dG2 : (const void*)h->dG, h->storage == GPCA_STORE_2BIT,
+                                                h->storage == GPCA_STORE_2BIT ? h->ld2 : h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+                else if (h->storage == GPCA_STORE_2BIT) launch_gtt_2bit(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+                else launch_gtt_i8(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
             }
-            else if (((h->lds_planes && h->gtt_dma) || h->nd == 3) && h->storage == GPCA_STORE_2BIT) {   // (three planes: only this kernel)
-                const int e = launch_gtt_p(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8, h->nd);
-                if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_p: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
-            }
-            else if (h->lds_planes) launch_gtt_x(h->st, h->storage == GPCA_STORE_2BIT ? (const void*)h->dG2 : (const void*)h->dG, h->storage == GPCA_STORE_2BIT,
-                                            h->storage == GPCA_STORE_2BIT ? h->ld2 : h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
-            else if (h->storage == GPCA_STORE_2BIT) launch_gtt_2bit(h->st, h->dG2, h->ld2, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
-            else launch_gtt_i8(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTd, h->dYpart64, h->plan8);
+            HIPCHK(hipGetLastError());
+            launch_reduce_y_i8(h->st, h->dYpart64, h->plan8.W, h->ldg, h->N, h->d_c + 32 * hf, tsc, h->dY + 32 * hf, L);
+            HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipGetLastError());
-        launch_reduce_y_i8(h->st, h->dYpart64, h->plan8.W, h->ldg, h->N, h->d_c, h->d_tscale, h->dY);
-        HIPCHK(hipGetLastError());
+        h->apart_valid = false;
         return allreduce_f64(h, h->dY, h->N * h->L);
     }
     {
@@ -703,19 +710,34 @@ static int stage_AtT(gpca_handle* h) {
 static int stage_AQ(gpca_handle* h, int scale_out) {
     const double elems = (double)h->M * (double)h->N;
     if (h->precision == GPCA_PREC_I8_EXACT) {
-        {
-            ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
-            if (h->storage == GPCA_STORE_2BIT) { launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out, h->nd); h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves; }
-            else if (h->lds_planes && h->gq_dma) {
-                const int e = launch_gq_d(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out);
-                if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
-                h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves;
+        const int L = h->L, halves = L / 32;
+        const size_t qhalf = (size_t)h->ldg * 32 * kDigits;            // digit planes of one 32-column half of Q
+        const size_t phalf = (size_t)h->gqplan.waves * 32;             // per-wave partials of one half
+        for (int hf = 0; hf < halves; ++hf) {
+            const int8_t* Qd = h->dQd + hf * qhalf;
+            const double* qsc = h->d_qscale + 32 * hf;
+            const float* s32 = h->d_s32 + 32 * hf;
+            float* Th = h->dT + 32 * hf;
+            float* cp = h->d_cpart + hf * phalf;
+            double* ap = h->d_apart + hf * phalf;
+            {
+                ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l / halves, h->storage == GPCA_STORE_2BIT ? elems / 4 : elems);
+                if (h->storage == GPCA_STORE_2BIT) launch_gq_2bit(h->st, h->dG2, h->ld2, h->gqplan, h->ldg, Qd, qsc, h->d_r, h->d_b, s32, Th, cp, ap, scale_out, h->nd, L);
+                else if (h->lds_planes && h->gq_dma) {
+                    const int e = launch_gq_d(h->st, h->dG, h->ldg, h->gqplan, h->ldg, Qd, qsc, h->d_r, h->d_b, s32, Th, cp, ap, scale_out, L);
+                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d: cannot reserve 128 KiB of LDS (hip error " + std::to_string(e) + ")");
+                }
+                else if (h->lds_planes) launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, Qd, qsc, h->d_r, h->d_b, s32, Th, cp, ap, scale_out, L);
+                else launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, Qd, qsc, h->d_r, h->d_b, s32, Th, cp, scale_out, L);
             }
-            else if (h->lds_planes) { launch_gq_x(h->st, h->dG, h->ldg, h->gqplan, h->ldg, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, h->d_apart, scale_out); h->apart_valid = scale_out != 0; h->apart_parts = h->gqplan.waves; }
-            else launch_gq_i8(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQd, h->d_qscale, h->d_r, h->d_b, h->d_s32, h->dT, h->d_cpart, scale_out);
+            HIPCHK(hipGetLastError());
+            if (scale_out) {   // c = b^T T of this half: its per-wave partials are [waves][32]
+                launch_sum_partials_f32(h->st, cp, h->gqplan.waves, 32, h->d_c + 32 * hf, h->d_scratch64);
+                HIPCHK(hipGetLastError());
+            }
         }
-        HIPCHK(hipGetLastError());
-        if (scale_out) CHK(stage_sum_c(h, h->gqplan.waves));
+        h->apart_valid = scale_out != 0 && (h->storage == GPCA_STORE_2BIT || h->lds_planes);   // (k_gq_i8 has no abs-max epilogue)
+        h->apart_parts = h->gqplan.waves;
         return GPCA_OK;
     }
     {
@@ -748,8 +770,11 @@ static int stage_orth(gpca_handle* h) {
                     i8 ? h->d_qscale : nullptr, i8 ? h->d_qinv : nullptr, h->nd);
     HIPCHK(hipGetLastError());
     if (i8) {
-        launch_quantize_f64_prescaled(h->st, h->dY, h->N, h->ldg, h->d_qinv, h->dQd, h->storage == GPCA_STORE_2BIT ? 1 : 0, h->nd);
-        HIPCHK(hipGetLastError());
+        for (int hf = 0; hf < L / 32; ++hf) {
+            launch_quantize_f64_prescaled(h->st, h->dY + 32 * hf, h->N, h->ldg, h->d_qinv + 32 * hf, h->dQd + (size_t)hf * h->ldg * 32 * kDigits,
+                                          h->storage == GPCA_STORE_2BIT ? 1 : 0, h->nd, L);
+            HIPCHK(hipGetLastError());
+        }
     }
     return GPCA_OK;
 }
@@ -779,13 +804,13 @@ static int ensure_workspace(gpca_handle* h) {
     }
     if (h->precision == GPCA_PREC_I8_EXACT) {
         h->plan8 = gtt8_plan(h->Mpad, Npad, h->gtt_waves_target);
-        CHK(ensure(h, h->dQd, h->cap_Qd, (size_t)Npad * 32 * kDigits));
+        CHK(ensure(h, h->dQd, h->cap_Qd, (size_t)Npad * 32 * kDigits * (size_t)(L / 32)));
         CHK(ensure(h, h->dTd, h->cap_Td, (size_t)h->Mpad * 32 * kDigits));
         CHK(ensure(h, h->dYpart64, h->cap_Ypart64, (size_t)h->plan8.W * (size_t)Npad * 32));
-        CHK(ensure(h, h->d_apart, h->cap_apart, (size_t)h->gqplan.waves * 32));
+        CHK(ensure(h, h->d_apart, h->cap_apart, (size_t)h->gqplan.waves * 32 * (size_t)(L / 32)));
         if (!h->d_qscale) {
-            HIPCHK(hipMalloc((void**)&h->d_qscale, 32 * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, 32 * 8));
-            HIPCHK(hipMalloc((void**)&h->d_tscale, 32 * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, 32 * 8));
+            HIPCHK(hipMalloc((void**)&h->d_qscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, 64 * 8));
+            HIPCHK(hipMalloc((void**)&h->d_tscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, 64 * 8));
         }
     }
     size_t cap2 = h->cap_scores;
@@ -810,7 +835,6 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         "Unexpected missing genotype (-127i8) in a PCA SNP. This should have been filtered by QC.");  // prepare.rs:1909-1911
     if (h->flags & 2u) return fail(h, GPCA_ERR_INVALID_GENOTYPE, "a PCA SNP holds a dosage outside {0,1,2}");
     if (h->precision != GPCA_PREC_F32_MFMA && h->precision != GPCA_PREC_I8_EXACT) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: unsupported precision mode");
-    if (h->precision == GPCA_PREC_I8_EXACT && l > 32) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: GPCA_PREC_I8_EXACT supports k + oversample <= 32 (use GPCA_PREC_F32_MFMA)");
     HIPCHK(hipSetDevice(h->device));
     h->k = k; h->l = l; h->L = l <= 32 ? 32 : 64;
     h->have_rsvd = false;
@@ -822,7 +846,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     {
         ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
         if (h->precision == GPCA_PREC_I8_EXACT) HIPCHK(hipMemsetAsync(h->d_apart, 0, 32 * 8, h->st));
-        if (h->precision == GPCA_PREC_I8_EXACT) { launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart, h->d_apart, 0); h->apart_valid = true; h->apart_parts = 1; }
+        if (h->precision == GPCA_PREC_I8_EXACT) { launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart, L == 32 ? h->d_apart : nullptr, 0); h->apart_valid = L == 32; h->apart_parts = 1; }
         else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart, nullptr, 1);
     }
     HIPCHK(hipGetLastError());

@@ -112,20 +112,20 @@ void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, 
 constexpr int kDigits = 4;   // signed base-128 digits of the skinny operand
 void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
                   const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                  int scale_out);
+                  int scale_out, int64_t ldt = 32);
 struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; };
 Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves);
 void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
                    double* Ypart, const Gtt8Plan& plan);
 void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
-                        const double* tscale, double* Y);
+                        const double* tscale, double* Y, int64_t ldy = 32);
 int64_t absmax_num_parts(int64_t rows);
 // X [rows][32] row-major -> digit planes Xd [rows_pad/32][kDigits][64][16 B]; scale[j] = colmax_j / S, inv = 1/scale
 // layout 0: 32 consecutive rows per block; layout 1: the MFMA-step order of the packed (2-bit) G Q kernel
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout = 0, int nd = 4);
+                         double* inv, int8_t* Xd, int layout = 0, int nd = 4, int64_t ldx = 32);
 void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout = 0, int nd = 4);
+                         double* inv, int8_t* Xd, int layout = 0, int nd = 4, int64_t ldx = 32);
 
 // ---- 2-bit resident genotypes (store2bit.hip, gemm_i8.hip) -----------------------------------------------------
 constexpr int64_t kSamplePad2bit = 1024;   // samples per row padded to this (ld2 = Npad / 4 bytes)
@@ -139,11 +139,11 @@ void launch_standardize_block_2bit(hipStream_t st, const uint8_t* G2, int64_t ld
                                    unsigned long long* err_idx);
 void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                     const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                    double* apart, int scale_out, int nd = 4);
-void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd = 4);
+                    double* apart, int scale_out, int nd = 4, int64_t ldt = 32);
+void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd = 4, int64_t ldx = 32);
 // quantise X whose column abs-max partials [P][32] were already produced by the kernel that wrote it (K1 epilogue)
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
-                                double* scale, double* inv, int8_t* Xd, int layout, int nd = 4);
+                                double* scale, double* inv, int8_t* Xd, int layout, int nd = 4, int64_t ldx = 32);
 // K2 for packed genotypes: stage-wise cooperative LDS-DMA (ring of four stage buffers); returns a hipError_t value
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, int nd = 4);
@@ -153,11 +153,11 @@ int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int
 // K1 with the genotypes brought in by LDS-DMA (full-line pieces); returns a hipError_t value (0 = ok)
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                int scale_out);
+                int scale_out, int64_t ldt = 32);
 // K1 with the digit planes of Q shared through LDS (int8-resident genotypes)
 void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                 int scale_out);
+                 int scale_out, int64_t ldt = 32);
 // K2 with the digit planes shared through LDS (packed = 0: int8 rows of pitch ldr, 1: 2-bit rows of pitch ldr)
 void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const int8_t* Td,
                   double* Ypart, const Gtt8Plan& plan);

@@ -471,11 +471,31 @@ def test_i8_matches_f32_and_is_partition_independent(gpca, oracle, engine, engin
         assert oracle.max_abs_dpc(e2.scores(f64=True), out["i8"][1]) < 1e-8
 
 
-def test_i8_rejects_wide_sketch(gpca, engine_i8):
-    engine_i8.upload_genotypes_i8(np.random.default_rng(0).integers(0, 3, size=(500, 100), dtype=np.int8))
-    engine_i8.snp_stats()
+@pytest.mark.parametrize("store,planes", [("int8", 0), ("2bit", 0), ("2bit", 3)])
+def test_i8_wide_sketch_two_column_halves(gpca, oracle, store, planes):
+    """32 < l <= 64 on the exact path: the 32-column kernels run over the two halves of the sketch (k = 40 -> l = 50, the
+    shape class of BASELINE config 5), same answers as the oracle and as the f32-MFMA path."""
+    from genomic_pca_amd import _lib
+    M, N, k = 6000, 700, 40
+    th = gpca.synth_thresholds(M, 48, seed=3, fst=0.3)
+    G = oracle.synth_genotypes(M, N, 3, th)
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=3)
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8,
+                         digit_planes=planes) as e:
+        e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 10, 2, seed=3)
+        assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+        # the trailing PCs of this small case sit in the noise bulk: compare the structured ones (as test_rsvd_l64_path does)
+        assert oracle.max_abs_dpc(e.scores(f64=True)[:, :20], R["scores"][:, :20]) < TOL_PC
+        assert oracle.max_abs_dpc(e.loadings().astype(np.float64)[:, :20], R["loadings"][:, :20]) < TOL_PC
+        tr = e.transform()
+    with gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA) as f:      # PCA::transform on the wide sketch: same numbers as the f32 path
+        f.upload_genotypes_i8(G); f.snp_stats(gpca.QcConfig.none()); f.rsvd(k, 10, 2, seed=3)
+        assert oracle.max_abs_dpc(tr[:, :20], f.transform()[:, :20]) < TOL_PC
     with pytest.raises(gpca.GpcaError):
-        engine_i8.rsvd(30, 10)        # l = 40 > 32
+        with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e2:
+            e2.upload_genotypes_i8(G); e2.snp_stats(gpca.QcConfig.none()); e2.rsvd(60, 10)      # l = 70 > 64
 
 
 # ------------------------------------------------------------------------------------------------
