@@ -96,7 +96,7 @@ def pmc_traffic(kernel):
     scripts/gpu_profile.sh: separate rocprofv3 --pmc runs).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950 wide coalesced reads (calibrated on k_snp_stats: 2 x 5120.1 MB = the 10 240 MB it streams)."""
     import glob
-    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit", "gemm_GtT_2bit": "gpca::k_gtt_p", "gemm_GQ_i8": "gpca::k_gq_d<1, 6>", "gemm_GtT_i8": "gpca::k_gtt_d<1>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
+    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit<4>", "gemm_GtT_2bit": "gpca::k_gtt_p<4>", "gemm_GQ_i8": "gpca::k_gq_d<1, 6>", "gemm_GtT_i8": "gpca::k_gtt_d<1>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
            "gemm_GtT_f32": "gpca::k_gtt_f32<1>"}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not key or not files:
@@ -105,7 +105,7 @@ def pmc_traffic(kernel):
     d = table.get(key)
     if d is None:   # template arguments changed between profiles (k_gq_d<1> -> k_gq_d<1, 6>): match on the kernel's base name
         base = key.split("<")[0]
-        cands = [v for k2, v in table.items() if k2.split("<")[0] == base and ("true" in k2) == ("true" in key)]
+        cands = [v for k2, v in sorted(table.items(), reverse=True) if k2.split("<")[0] == base and ("true" in k2) == ("true" in key)]
         d = cands[0] if cands else None
     if not d or "FETCH_SIZE" not in d:
         return None, None
