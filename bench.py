@@ -190,8 +190,10 @@ def main():
 
     uid = None
     results = {}
-    order = [a.precision] + ([] if (a.no_second_path or a.precision == "f32" or l > 32) else ["f32"])
-    if a.precision == "i8" and a.storage == "int8" and not a.no_second_path:
+    # the extra measurements (f32-MFMA path, 2-bit residency) are single-GPU information: multi-rank runs time the headline only
+    extras = not a.no_second_path and world == 1
+    order = [a.precision] + ([] if (not extras or a.precision == "f32" or l > 32) else ["f32"])
+    if a.precision == "i8" and a.storage == "int8" and extras:
         order.append("i8_2bit")
         order.append("i8_2bit_3p")
     th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
