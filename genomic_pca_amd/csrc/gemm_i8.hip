@@ -878,6 +878,14 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     uint32_t toff[R];                                   // wave-uniform byte offset of tile t (tiles past the range: tile 0)
 #pragma unroll
     for (int t = 0; t < R; ++t) toff[t] = (uint32_t)(t < nvalid ? 32 * t : 0) * ld32;
+    // r and b of the round's rows, one row per lane (row 32 t + c), requested before anything else: the epilogue picks them up
+    // with a cross-lane read instead of 32 dependent global loads per tile at the end of the round
+    float rrow[R], brow[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int64_t rix = row0 + (t < nvalid ? 32 * t : 0) + c;
+        rrow[t] = rv[rix]; brow[t] = bv[rix];
+    }
     constexpr uint32_t QCH = kDigits * 1024;
     const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
     const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (S * 4096u);
@@ -972,8 +980,9 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
         if (t < nvalid) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float ri = rv[row], bi = bv[row];
+                const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
+                const int64_t row = row0 + 32 * t + rin;
+                const float ri = __shfl(rrow[t], rin), bi = __shfl(brow[t], rin);
                 const float gq = (float)(combine_digits(acc[t], e) * qs);
                 const float tv = ri * gq + bi * sj;
                 csum += bi * tv;
