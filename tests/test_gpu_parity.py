@@ -727,3 +727,30 @@ def test_three_planes_need_packed_exact_path(gpca):
         gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_INT8, digit_planes=3)
     with pytest.raises(gpca.GpcaError):
         gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT, digit_planes=5)
+
+
+@pytest.mark.parametrize("store,planes", [("int8", 0), ("2bit", 0), ("2bit", 3)])
+def test_exact_path_with_qc_dropped_and_missing_rows(gpca, oracle, store, planes):
+    """SNP rows that QC drops (monomorphic, low call rate with -127 / packed code 3 in them) stay resident but carry r = b = 0:
+    the exact kernels must ignore whatever bytes they hold (for packed rows the decode turns code 3 into the value 3)."""
+    from genomic_pca_amd import _lib
+    M, N = 3000, 400
+    th = gpca.synth_thresholds(M, 6, seed=4, fst=0.2)
+    G = oracle.synth_genotypes(M, N, 4, th)
+    G[::7] = 0
+    G[5::11, :3] = -127
+    G[6::13, 100:140] = -127
+    qc = gpca.QcConfig(0.999, 0.02, 1e-6)
+    ref = oracle.snp_stats(G, N, qc.min_snp_call_rate, qc.min_snp_maf, qc.max_snp_hwe_p_value)
+    r, b = oracle.scale_shift(ref["mu"], ref["sigma"], ref["keep"])
+    R = oracle.rsvd(G, N, r, b, 5, 10, 2, seed=8)
+    kept = np.nonzero(ref["keep"])[0]
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8,
+                         digit_planes=planes) as e:
+        e.upload_genotypes_i8(G)
+        st = e.snp_stats(qc)
+        assert np.array_equal(st["keep"], ref["keep"]) and 0 < ref["keep"].sum() < M
+        e.rsvd(5, 10, 2, seed=8)
+        assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"][kept]) < TOL_PC
+        assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
+        assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
