@@ -41,7 +41,7 @@ def cpu_baseline(N, k, oversample, q, seed, target_s=15.0):
         st = O.snp_stats(G, N, 0.0, 0.0, 1.0)
         r, b = O.scale_shift(st["mu"], st["sigma"], st["keep"])
         t0 = time.perf_counter()
-        O.rsvd(G, N, r, b, k, oversample, q, seed=seed, real="f32")
+        O.rsvd_port(G, N, r, b, k, oversample, q, seed=seed, real="f32")
         return time.perf_counter() - t0
     Ms = 25000
     t = run(Ms)
@@ -66,8 +66,8 @@ def parity_check(g, precision, seed):
         st = e.snp_stats(g.QcConfig.none())
         e.rsvd(k, 10, 2, seed=seed)
         r, b = O.scale_shift(st["mu"], st["sigma"], st["keep"])
-        R = O.rsvd(G, N, r, b, k, 10, 2, seed=seed)
-        return {"case": f"{M}x{N} k={k} vs oracle f64 (same seed)",
+        R = O.rsvd(G, N, r, b, k, 10, 2, seed=seed)     # the checker: LAPACK QR / SVD, no small-dense code shared with the product
+        return {"case": f"{M}x{N} k={k} vs oracle f64 (same sketch; Householder QR + LAPACK SVD)",
                 "max_abs_dPC_scores": O.max_abs_dpc(e.scores(f64=True), R["scores"]),
                 "max_abs_dPC_loadings": O.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]),
                 "max_rel_d_eigenvalue": float(np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"])),
@@ -77,6 +77,7 @@ def parity_check(g, precision, seed):
 def timed_run(eng, a, k, barrier, dist, torch):
     for _ in range(a.warmup):
         eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+    eng.enable_timings(True)       # HIP events on the engine's own stream (off by default in the library)
     eng.reset_timings()
     barrier()
     t0 = time.perf_counter()
@@ -139,6 +140,101 @@ def roofline_of(timings, precision, steps, storage="int8"):
             "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "hbm_GBs_algorithmic": gbs, **common}
 
 
+def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn=None, steps=None, warmup=None):
+    """One out-of-core job: stats sweep + `steps` timed gpca_rsvd calls over panels that are regenerated on every sweep."""
+    steps = a.steps if steps is None else steps
+    warmup = a.warmup if warmup is None else warmup
+    th16 = g.synth_thresholds16(M, 3, seed=a.rfit_seed, snp_offset=snp_offset)
+    eng = g.GpcaEngine(device=device, precision=g._lib.PREC_I8_EXACT, storage=g._lib.STORE_2BIT if storage == "2bit" else g._lib.STORE_INT8,
+                       digit_planes=a.digit_planes if storage == "2bit" else 0)
+    eng.stream_open(g.PanelSource.synth16(th16, a.rfit_seed, snp_offset=snp_offset), M, N, panel_rows=a.panel_rows, ring_slots=a.ring)
+    del th16
+    t0 = time.perf_counter()
+    eng.snp_stats(g.QcConfig.none(), fetch=False)
+    t_stats = time.perf_counter() - t0
+    if uid_fn is not None:
+        uid_fn(eng)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        eng.synchronize()
+    for _ in range(warmup):
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+    eng.enable_timings(True); eng.reset_timings()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    tim = eng.timings()
+    ev = eng.eigenvalues()
+    eng.close()
+    return dt, tim, ev, t_stats
+
+
+def streamed_summary(tim, steps, M, N, l, storage):
+    """Per-step times of the streamed sweeps.  gemm_* records span a whole sweep over the panels on the compute stream (waits
+    for panels included); panel_fill records are the generator's own kernel times on the fill stream."""
+    fill = tim.get("panel_fill", {"total_ms": 0.0, "launches": 0, "bytes": 0.0})
+    gq, gt = tim["gemm_GQ"], tim["gemm_GtT"]
+    sweeps = (gq["launches"] + gt["launches"]) / steps
+    per_b = 0.25 if storage == "2bit" else 1.0
+    gemm_ms = (gq["total_ms"] + gt["total_ms"]) / steps
+    return {"sweeps_per_step": sweeps, "panel_fills_per_step": fill["launches"] / steps,
+            "generator_ms_per_step": fill["total_ms"] / steps,
+            "generator_rate_genotypes_per_s": (fill["bytes"] / (fill["total_ms"] * 1e-3)) if fill["total_ms"] else None,
+            "gemm_sweeps_ms_per_step": gemm_ms, "gemm_GQ_ms_per_sweep": gq["total_ms"] / gq["launches"],
+            "gemm_GtT_ms_per_sweep": gt["total_ms"] / gt["launches"],
+            "hbm_GBs_per_sweep_algorithmic": M * N * per_b * (1 if l <= 32 else 2) / (gemm_ms / sweeps * 1e-3) / 1e9,
+            "note": "fills run one panel ahead on a second stream; a sweep's span includes any wait for the generator"}
+
+
+def streamed_main(a, g, rank, world, local_rank, dist, torch):
+    M_local, N, k = a.snps, a.samples, a.components
+    l = k + a.oversample
+    snp_offset = rank * M_local
+    uid_fn = None
+    if dist is not None:
+        def uid_fn(eng):
+            uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
+            eng.comm_init(world, rank, uid, snp_offset)
+    dt, tim, ev, t_stats = streamed_run(g, a, M_local, N, k, a.storage, local_rank, snp_offset, dist, torch, uid_fn)
+    if rank == 0:
+        M_total = M_local * world
+        per_step = dt / a.steps
+        ssum = streamed_summary(tim, a.steps, M_local, N, l, a.storage)
+        # dominant "kernel" of a streamed run = one sweep of the slower GEMM over all panels of this rank
+        dom = max(("gemm_GQ", "gemm_GtT"), key=lambda n_: tim[n_]["total_ms"] / tim[n_]["launches"])
+        sweep_ms = tim[dom]["total_ms"] / tim[dom]["launches"]
+        by = tim[dom]["bytes"] / tim[dom]["launches"]
+        out = {"metric": "SNPs x samples / sec through rSVD at k=%d (streamed panels); max|dPC| vs ref" % k,
+               "value": M_total * N / per_step, "unit": "SNPs*samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "i8 (exact-integer GEMMs, f64 recombination)", "data": "synthetic (device generator, regenerated on every sweep)",
+               "config": {"workload": f"out-of-core: synthetic {M_total} SNPs x {N} samples (never resident), k={k}, l={l}, q={a.power_iters}, "
+                                      f"panels generated on the device by Philox (GPCA_PANEL_SYNTH16) into a ring of {a.ring} HBM buffers",
+                          "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample, "power_iters": a.power_iters,
+                          "parallelism": f"snp-row-shards x{world}", "gemm_path": "i8", "residency": f"streamed/{a.storage}",
+                          "panel_rows": a.panel_rows, "ring": a.ring},
+               "roofline": {"bound": "hbm" if a.storage == "int8" else "mfma", "kernel": dom + " sweep over all panels",
+                            "avg_launch_ms": sweep_ms, "achieved": by / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": by / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "note": "sweep-level (all panels, waits for the generator included); the per-launch roofline of the same kernels is "
+                                    "the resident bench line"},
+               "streaming": ssum, "snp_stats_s": t_stats, "top_eigenvalues": [float(x) for x in ev[:3]], "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,9 +254,13 @@ def main():
                     help="exact path: 4 (default) signed base-128 digit planes, or 3 base-256 planes (24-bit; --storage 2bit only)")
     ap.add_argument("--precision", default="i8", choices=["f32", "i8"],
                     help="i8 = exact-integer GEMMs (default, fastest parity-green path); f32 = v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--streamed", action="store_true",
+                    help="BASELINE.json configs[4] mode: the matrix is never resident; panels come from the device generator "
+                         "(GPCA_PANEL_SYNTH16) through a ring of HBM buffers, one panel ahead of the GEMMs")
+    ap.add_argument("--panel-rows", type=int, default=0, help="--streamed: SNP rows per panel (0 = ~1 GiB panels)")
+    ap.add_argument("--ring", type=int, default=3, help="--streamed: panel buffers in the ring")
     a = ap.parse_args()
 
-    import torch
     import genomic_pca_amd as g
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,13 +268,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and a.gpus > 1:
         sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
-    dist = None
+    # One GPU: no second GPU runtime in the process -- libgpca.so is torch-free and so is this harness.  torch is imported only
+    # under torch.distributed.run, where it carries the rendezvous and the max-over-ranks of the timing.
+    dist = torch = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run (also with one rank: same code path)
+        import torch
         import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if a.streamed:
+        return streamed_main(a, g, rank, world, local_rank, dist, torch)
     M_local, N, k = a.snps, a.samples, a.components
     l = k + a.oversample
     if a.precision == "i8" and l > 64:
@@ -183,10 +288,14 @@ def main():
     snp_offset = rank * M_local
     PREC = {"f32": g._lib.PREC_F32_MFMA, "i8": g._lib.PREC_I8_EXACT}
 
+    engines = []
+
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+        for e_ in engines:          # = hipStreamSynchronize on the engine's streams (the only GPU work of this process)
+            e_.synchronize()
 
     uid = None
     results = {}
@@ -203,6 +312,7 @@ def main():
         store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == "i8") or packed) else g._lib.STORE_INT8
         planes = 3 if prec == "i8_2bit_3p" else (a.digit_planes if (prec == "i8" and store == g._lib.STORE_2BIT) else 0)
         eng = g.GpcaEngine(device=local_rank, precision=PREC["i8" if packed else prec], storage=store, digit_planes=planes)
+        engines[:] = [eng]
         eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
         t0 = time.perf_counter()
         eng.snp_stats(g.QcConfig.none(), fetch=False)
@@ -256,6 +366,14 @@ def main():
                 "value": M_total * N / (dt4 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt4 / a.steps * 1e3,
                 "all_kernels_ms_per_step": {n: t["total_ms"] / a.steps for n, t in tim4.items()},
                 "max_rel_d_eigenvalue_vs_default_path": float(np.max(np.abs(ev4 - ev) / ev))}
+        if extras and a.precision == "i8":
+            # the headline matrix shape again, never resident: 8 panels of 131 072 rows regenerated by the device generator on every sweep
+            a2 = argparse.Namespace(**vars(a)); a2.panel_rows = 131072; a2.ring = 3; a2.digit_planes = 0
+            dts, tims, evs, _ = streamed_run(g, a2, M_local, N, k, a.storage, local_rank, 0, None, None, steps=min(a.steps, 3), warmup=1)
+            out["streamed_panels"] = {"note": "same shape out-of-core (BASELINE.json configs[4] mode at configs[1] size): panels come from the "
+                                              "Philox device generator (a different synthetic draw than the resident matrix)",
+                                      "value": M_local * N / (dts / min(a.steps, 3)), "unit": "SNPs*samples/s",
+                                      "ms_per_step": dts / min(a.steps, 3) * 1e3, **streamed_summary(tims, min(a.steps, 3), M_local, N, l, a.storage)}
         if world == 1 and not a.no_cpu_baseline:
             out["parity"] = parity_check(g, PREC[a.precision], a.rfit_seed)
             out["cpu_baseline"] = cpu_baseline(N, k, a.oversample, a.power_iters, a.rfit_seed)

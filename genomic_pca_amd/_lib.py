@@ -53,6 +53,17 @@ class gpca_kernel_timing(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+PANEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64)
+PANEL_HOST_I8 = 0
+PANEL_HOST_BED = 1
+PANEL_SYNTH = 2
+PANEL_SYNTH16 = 3
+
+
+class gpca_panel_source(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_pop", C.c_int32), ("fill", PANEL_FN), ("user", C.c_void_p),
+                ("thresh", C.c_void_p), ("seed", C.c_uint64), ("snp_offset", C.c_int64), ("reserved", C.c_int64 * 2)]
+
 
 # name -> (restype, argtypes); the "not gpu" test checks every one of these is exported
 _H = C.c_void_p
@@ -66,10 +77,13 @@ PROTOTYPES = {
     "gpca_upload_bed2bit": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int64]),
     "gpca_synth_genotypes": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int32, C.c_int64]),
     "gpca_download_genotypes_i8": (C.c_int, [_H, C.c_void_p, C.c_int64]),
+    "gpca_load_from_source": (C.c_int, [_H, C.POINTER(gpca_panel_source), C.c_int64, C.c_int64]),
+    "gpca_stream_open": (C.c_int, [_H, C.POINTER(gpca_panel_source), C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "gpca_dims": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gpca_snp_stats": (C.c_int, [_H, C.POINTER(gpca_qc_config), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_get_snp_qc_detail": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "gpca_set_standardization": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpca_get_standardization": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_hwe_chi_squared_p_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "gpca_standardize_block": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gpca_num_pca_snps": (C.c_int64, [_H]),

@@ -57,7 +57,16 @@ def build_parser() -> argparse.ArgumentParser:
     # extensions
     p.add_argument("--device", type=int, default=-1, help="HIP device ordinal")
     p.add_argument("--write-eigenvalues", action="store_true", help="VCF workflow: fill P.eigenvalues.tsv (the reference leaves it header-only)")
+    # engine selection (extensions; the defaults are the path bench.py's headline times)
+    p.add_argument("--gpca-precision", default="i8", choices=["i8", "f32"], help="i8 = exact-integer GEMMs (default); f32 = f32 matrix cores")
+    p.add_argument("--gpca-storage", default="int8", choices=["int8", "2bit"], help="HBM residency of the genotypes (2bit needs --gpca-precision i8)")
     return p
+
+
+def _engine_modes(a):
+    from . import _lib
+    return (_lib.PREC_I8_EXACT if a.gpca_precision == "i8" else _lib.PREC_F32_MFMA,
+            _lib.STORE_2BIT if a.gpca_storage == "2bit" else _lib.STORE_INT8)
 
 
 def _log(msg: str):
@@ -91,7 +100,8 @@ def run_vcf_workflow(a) -> int:
     _log(f"{len(files)} VCF files, {G.shape[0]} variants x {len(samples or [])} samples in {time.time() - t0:.2f}s")
     if G.shape[0] == 0:
         raise SystemExit("No variants available to build matrix.")                  # vcf.rs:321-323
-    model = PCA(device=a.device)
+    prec, store = _engine_modes(a)
+    model = PCA(device=a.device, precision=prec, storage=store)
     model.rfit(G.T, a.components, 10, a.rfit_seed, None)                            # main.rs:636-656 (x = samples x variants)
     pcs = model.transform()
     _ensure_parent(a.output_prefix)
@@ -106,7 +116,8 @@ def run_eigensnp_workflow(a) -> int:
         raise SystemExit("error: --bed-file and --ld-block-file are required when --eigensnp is used")   # main.rs:296-301
     t0 = time.time()
     fs = gio.read_plink(a.bed_file)
-    eng = GpcaEngine(device=a.device)
+    prec, store = _engine_modes(a)
+    eng = GpcaEngine(device=a.device, precision=prec, storage=store)
     sample_ids = fs.sample_ids
     if a.eigensnp_sample_keep_file:                                                  # prepare.rs:1058-1096
         keep_ids = set(gio.read_sample_keep_file(a.eigensnp_sample_keep_file))
@@ -119,7 +130,7 @@ def run_eigensnp_workflow(a) -> int:
         eng.upload_genotypes_i8(np.ascontiguousarray(G))
         sample_ids = [fs.sample_ids[i] for i in cols]
     else:
-        eng.upload_bed2bit(np.asarray(fs.bed_rows), fs.n_samples)                    # decoded on the GPU
+        eng.upload_bed2bit(fs.bed_rows, fs.n_samples)    # the memory-mapped payload goes up in 256 MiB row chunks, decoded on the GPU
     st = eng.snp_stats(QcConfig(a.eigensnp_min_call_rate, a.eigensnp_min_maf, a.eigensnp_max_hwe_p))
     blocks = gio.parse_ld_block_file(a.ld_block_file)
     keep, by_tag = gio.map_snps_to_ld_blocks(blocks, fs.chromosomes, fs.positions, st["keep"])

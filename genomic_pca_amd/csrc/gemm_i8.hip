@@ -20,11 +20,10 @@
 
 namespace gpca {
 
-// cache policy of the once-read genotype stream: 0 = default, 2 = non-temporal (GPCA_STREAM_NT=1)
-static const bool g_stream_nt = [] { const char* e = getenv("GPCA_STREAM_NT"); return e && atoi(e) != 0; }();
-// the LDS-DMA genotype stream of k_gq_d: full-line pieces read once per pass -> non-temporal by default (measured
-// 1.82 -> 1.71 ms per pass; GPCA_GQ_DMA_NT=0 restores the default cache policy)
-static const bool g_dma_nt = [] { const char* e = getenv("GPCA_GQ_DMA_NT"); return !e || atoi(e) != 0; }();
+// Kernel switches travel in KernelOpts (kernels.h), read from the environment once per handle at gpca_create:
+//   stream_nt : cache policy of the once-read genotype stream of the per-wave-plane kernels (0 = default, 1 = non-temporal)
+//   dma_nt    : the LDS-DMA genotype streams are full-line pieces read once per pass -> non-temporal by default (measured
+//               1.82 -> 1.71 ms per pass; GPCA_GQ_DMA_NT=0 restores the default cache policy)
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +35,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc8(const void* p) {
 
 // BITS = 7: four signed base-128 digits (28-bit fixed point, the default);  BITS = 8: three signed base-256 digits (24-bit,
 // the packed kernels' fast mode -- plane 3 is all zero and its accumulators are never touched)
+// c = b^T T is summed per 32-row unit (fixed order: 16 rows per lane half, then the two halves), one partial per unit at
+// cunit[unit][32]: whichever wave of whichever launch computes a unit writes the same bits, so resident, sharded and
+// streamed-panel runs agree on c exactly
+#define GPCA_STORE_CUNIT(UNIT) { const float co_ = ct + __shfl_xor(ct, 32); if (h == 0) cunit[(int64_t)(UNIT) * 32 + c] = co_; }
+
 template <int BITS = 7>
 __device__ __forceinline__ double combine_digits(const i32x16 (&a)[kDigits], int e) {
     // exact: each |a| < 2^31, weights are powers of two, total < 2^53
@@ -87,7 +91,7 @@ template <int R, int AUX>
 __device__ __forceinline__ void gq8_group(const int8_t* __restrict__ G, int64_t ldg, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float& csum, int64_t row0, int c, int h, int lane) {
+                                          float* __restrict__ cunit, int64_t row0, int c, int h, int lane) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
     uint32_t gvo[R];
 #pragma unroll
@@ -134,15 +138,17 @@ __device__ __forceinline__ void gq8_group(const int8_t* __restrict__ G, int64_t 
 #undef GQ8_PHASE
 #pragma unroll
     for (int t = 0; t < R; ++t) {
+        float ct = 0.f;     // this tile's share of c = b^T T: one partial per 32-row unit, so c does not depend on the grid partition
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
             const float ri = rv[row], bi = bv[row];
             const float gq = (float)(combine_digits(acc[t], e) * qs);
             const float tv = ri * gq + bi * sj;
-            csum += bi * tv;
+            ct += bi * tv;
             Tout[row * ldt + c] = scale_out ? ri * tv : tv;
         }
+        GPCA_STORE_CUNIT(row0 / 32 + t)
     }
 }
 
@@ -159,22 +165,19 @@ __global__ __launch_bounds__(256, 1) void k_gq_i8(const int8_t* __restrict__ G, 
     const int64_t waves = (int64_t)gridDim.x * 4;
     int64_t u = (units * wave) / waves;
     const int64_t u_end = (units * (wave + 1)) / waves;
-    float csum = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
-    for (; u + 4 <= u_end; u += 4) gq8_group<4, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, u * 32, c, h, lane);
-    if (u + 2 <= u_end) { gq8_group<2, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, u * 32, c, h, lane); u += 2; }
-    if (u + 1 <= u_end) { gq8_group<1, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, u * 32, c, h, lane); u += 1; }
-    const float o = csum + __shfl_xor(csum, 32);
-    if (h == 0) cpart[wave * 32 + c] = o;
+    for (; u + 4 <= u_end; u += 4) gq8_group<4, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, u * 32, c, h, lane);
+    if (u + 2 <= u_end) { gq8_group<2, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, u * 32, c, h, lane); u += 2; }
+    if (u + 1 <= u_end) { gq8_group<1, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, u * 32, c, h, lane); u += 1; }
 }
 
 void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
                   const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                  int scale_out, int64_t ldt) {
+                  int scale_out, int64_t ldt, const KernelOpts& ko) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nsuper = (N + 255) / 256 * 2;   // 128-sample super-chunks, even count (= Npad / 128)
-    if (g_stream_nt) hipLaunchKernelGGL((k_gq_i8<2>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
+    if (ko.stream_nt) hipLaunchKernelGGL((k_gq_i8<2>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
     else hipLaunchKernelGGL((k_gq_i8<0>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
 }
 
@@ -307,9 +310,9 @@ __global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G,
 }
 
 void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                   double* Ypart, const Gtt8Plan& plan) {
+                   double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko) {
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
-    if (g_stream_nt) hipLaunchKernelGGL((k_gtt_i8<2>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
+    if (ko.stream_nt) hipLaunchKernelGGL((k_gtt_i8<2>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
     else hipLaunchKernelGGL((k_gtt_i8<0>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
 }
 
@@ -329,6 +332,49 @@ void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad
                         const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
     hipLaunchKernelGGL(k_reduce_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
+}
+
+// Streamed panels: the integer partial sums of every panel are added into Yint (exact in f64 while |sum| < 2^53, so the
+// order of the panels does not matter) and scaled once at the end -- the same value, bit for bit, as the one-launch reduce.
+__global__ __launch_bounds__(256) void k_accum_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
+                                                    double* __restrict__ Yint, int first) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * 32) return;
+    const int64_t stride = Npad * 32;
+    double s = first ? 0.0 : Yint[e];
+    for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
+    Yint[e] = s;
+}
+__global__ __launch_bounds__(256) void k_finish_y_i8(const double* __restrict__ Yint, int64_t N, const double* __restrict__ cvec,
+                                                     const double* __restrict__ tscale, double* __restrict__ Y, int64_t ldy) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * 32) return;
+    const int j = (int)(e & 31);
+    Y[(e >> 5) * ldy + j] = cvec[j] + tscale[j] * Yint[e];
+}
+void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first) {
+    const int64_t total = N * 32;
+    hipLaunchKernelGGL(k_accum_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
+}
+void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy) {
+    const int64_t total = N * 32;
+    hipLaunchKernelGGL(k_finish_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Yint, N, c, tscale, Y, ldy);
+}
+// run[c] = max(run[c], max_p apart[p][c]): the column abs-max of T' over the panels seen so far (max is exact in any order)
+__global__ __launch_bounds__(1024) void k_absmax_fold(const double* __restrict__ apart, int64_t P, double* __restrict__ run) {
+    __shared__ double red[1024];
+    const int cc = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    double a = 0.0;
+    for (int64_t p = pg; p < P; p += 32) { const double v = apart[p * 32 + cc]; a = v > a ? v : a; }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (pg != 0) return;
+    for (int g = 1; g < 32; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
+    const double r = run[cc];
+    run[cc] = a > r ? a : r;
+}
+void launch_absmax_fold(hipStream_t st, const double* apart, int64_t P, double* run) {
+    hipLaunchKernelGGL(k_absmax_fold, dim3(1), dim3(1024), 0, st, apart, P, run);
 }
 
 // ================================================================================================
@@ -405,7 +451,7 @@ template <int R, int ND = kDigits>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float& csum, float& amax, int64_t row0, int c, int h, int lane, const unsigned* lut) {
+                                          float* __restrict__ cunit, float& amax, int64_t row0, int c, int h, int lane, const unsigned* lut) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
     uint32_t gvo[R];
 #pragma unroll
@@ -460,17 +506,19 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
 #undef GQ2_PHASE
 #pragma unroll
     for (int t = 0; t < R; ++t) {
+        float ct = 0.f;     // this tile's share of c = b^T T: one partial per 32-row unit, so c does not depend on the grid partition
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
             const float ri = rv[row], bi = bv[row];
             const float gq = (float)(combine_digits<ND == 3 ? 8 : 7>(acc[t], e) * qs);
             const float tv = ri * gq + bi * sj;
-            csum += bi * tv;
+            ct += bi * tv;
             const float ov = scale_out ? ri * tv : tv;
             amax = fmaxf(amax, fabsf(ov));
             Tout[row * ldt + c] = ov;
         }
+        GPCA_STORE_CUNIT(row0 / 32 + t)
     }
 }
 
@@ -487,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
     const int64_t waves = (int64_t)gridDim.x * 4;
     int64_t u = (units * wave) / waves;
     const int64_t u_end = (units * (wave + 1)) / waves;
-    float csum = 0.f, amax = 0.f;
+    float amax = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
     // byte (4 two-bit codes) -> 4 int8 bytes: 256-entry table in LDS; the spread then costs 2 VALU + 1 ds_read per dword
@@ -500,12 +548,11 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
 #if GPCA_ABLATE & 16
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax, u * 32, c, h, lane, lut);
-    if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax, u * 32, c, h, lane, lut); u += 2; }
-    if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax, u * 32, c, h, lane, lut); u += 1; }
-    const float o = csum + __shfl_xor(csum, 32);
+    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut);
+    if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 2; }
+    if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 1; }
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
-    if (h == 0) { cpart[wave * 32 + c] = o; apart[wave * 32 + c] = (double)am; }
+    if (h == 0) apart[wave * 32 + c] = (double)am;
 #if GPCA_ABLATE & 16
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         g_kbench_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
@@ -676,7 +723,7 @@ __device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t 
                                           const int8_t* __restrict__ Qd, i32x4 (*tds)[4][kDigits][64], int wv, int lane, int c,
                                           int h, int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float& csum, float& amax) {
+                                          float* __restrict__ cunit, float& amax) {
     const int64_t row0 = unit0 * 32;
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
     uint32_t gvo[R];
@@ -741,17 +788,19 @@ __device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t 
 #pragma unroll
     for (int t = 0; t < R; ++t) {
         if (t < nvalid) {
+            float ct = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const float ri = rv[row], bi = bv[row];
                 const float gq = (float)(combine_digits(acc[t], e) * qs);
                 const float tv = ri * gq + bi * sj;
-                csum += bi * tv;
+                ct += bi * tv;
                 const float ov = scale_out ? ri * tv : tv;
                 amax = fmaxf(amax, fabsf(ov));
                 Tout[row * ldt + c] = ov;
             }
+            GPCA_STORE_CUNIT(unit0 + t)
         }
     }
 }
@@ -768,7 +817,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
     const int c = lane & 31, h = lane >> 5;
     const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
     const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
-    float csum = 0.f, amax = 0.f;
+    float amax = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
     int64_t u = u0;
@@ -777,31 +826,30 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
         if (rem > 8 && rmax >= 4) {           // 4 tiles per wave
             const int64_t mine = u + 4 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
+            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
             u += 16;
         } else if (rem > 4 && rmax >= 2) {    // 2 tiles per wave
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
+            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
             u += 8;
         } else {                 // 1 tile per wave
             const int64_t mine = u + wv;
             const int nv = mine < u1 ? 1 : 0;
-            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
+            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
             u += 4;
         }
     }
-    const float o = csum + __shfl_xor(csum, 32);
     const float am = fmaxf(amax, __shfl_xor(amax, 32));   // column abs-max of this wave's output rows (for the digit scale)
-    if (h == 0) { cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o; apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am; }
+    if (h == 0) apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am;
 }
 
 void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                 int scale_out, int64_t ldt) {
+                 int scale_out, int64_t ldt, const KernelOpts& ko) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;    // Npad is a multiple of 256 -> even
-    static const int rmax = getenv("GPCA_GQ_R") ? atoi(getenv("GPCA_GQ_R")) : 4;
+    const int rmax = ko.gq_r;
     hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, rmax, ldt);
 }
 
@@ -863,7 +911,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                                           const int8_t* __restrict__ Qd, GqdSmemT<S>* sm, int wv, int lane, int c, int h,
                                           int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float& csum, float& amax) {
+                                          float* __restrict__ cunit, float& amax) {
     constexpr int R = 4;
     const int64_t row0 = unit0 * 32;
     const i32x4 rg = gqd_rsrc(G + row0 * ldg);
@@ -978,6 +1026,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
 #pragma unroll
     for (int t = 0; t < R; ++t) {
         if (t < nvalid) {
+            float ct = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
@@ -985,11 +1034,12 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                 const float ri = __shfl(rrow[t], rin), bi = __shfl(brow[t], rin);
                 const float gq = (float)(combine_digits(acc[t], e) * qs);
                 const float tv = ri * gq + bi * sj;
-                csum += bi * tv;
+                ct += bi * tv;
                 const float ov = scale_out ? ri * tv : tv;
                 amax = fmaxf(amax, fabsf(ov));
                 Tout[row * ldt + c] = ov;
             }
+            GPCA_STORE_CUNIT(unit0 + t)
         }
     }
 }
@@ -1008,7 +1058,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
     const int c = lane & 31, h = lane >> 5;
     const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
     const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
-    float csum = 0.f, amax = 0.f;
+    float amax = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
     int64_t u = u0;
@@ -1021,36 +1071,33 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
             const int64_t base = take >> 2, extra = take & 3;
             const int64_t mine = u + wv * base + (wv < extra ? wv : extra);
             const int nv = (int)(base + (wv < extra ? 1 : 0));
-            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
+            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
             u += take;
         } else if (rem > 4) {    // tails: the register-staged rounds
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
+            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
             u += 8;
         } else {
             const int64_t mine = u + wv;
             const int nv = mine < u1 ? 1 : 0;
-            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, csum, amax);
+            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
             u += 4;
         }
     }
-    const float o = csum + __shfl_xor(csum, 32);
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
-    if (h == 0) { cpart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = o; apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am; }
+    if (h == 0) apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am;
 }
 
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                int scale_out, int64_t ldt) {
-    static const int slots = getenv("GPCA_GQ_SLOTS") ? atoi(getenv("GPCA_GQ_SLOTS")) : 6;
+                int scale_out, int64_t ldt, const KernelOpts& ko) {
+    const int slots = ko.gq_slots;
+    const bool g_dma_nt = ko.dma_nt != 0;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;
 #define GPCA_GQD(NTV, SV)                                                                                                       \
     {                                                                                                                          \
-        static const int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_d<NTV, SV>),                         \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GqdSmemT<SV>)); \
-        if (attr != 0) return attr;                                                                                            \
         hipLaunchKernelGGL((k_gq_d<NTV, SV>), grid, blk, sizeof(GqdSmemT<SV>), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, \
                            Tout, cpart, apart, scale_out, ldt);                                                                \
     }
@@ -1504,14 +1551,9 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
 }
 
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
-                 const Gtt8Plan& plan, int nd) {
-    static const int attr4 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_p<kDigits>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)sizeof(GtpSmem));
-    static const int attr3 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_p<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)sizeof(GtpSmem));
-    if (attr4 != 0 || attr3 != 0) return attr4 ? attr4 : attr3;
+                 const Gtt8Plan& plan, int nd, const KernelOpts& ko) {
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
-    static const int remap = getenv("GPCA_GTT_XCD") ? atoi(getenv("GPCA_GTT_XCD")) : 1;
+    const int remap = ko.gtt_xcd;
     if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
                                     plan.rows_per_wave, remap);
     else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
@@ -1520,27 +1562,37 @@ int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, i
 }
 
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
-                 const Gtt8Plan& plan) {
-    static const int attr0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_d<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)sizeof(GqdSmem));
-    static const int attr1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtt_d<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)sizeof(GqdSmem));
-    if (attr0 != 0 || attr1 != 0) return attr0 ? attr0 : attr1;
+                 const Gtt8Plan& plan, const KernelOpts& ko) {
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     const dim3 grid((unsigned)plan.grid), blk(256);
-    static const int remap = getenv("GPCA_GTT_XCD") ? atoi(getenv("GPCA_GTT_XCD")) : 1;   // measured 5.10 -> 5.00 ms per step
-    if (g_dma_nt) hipLaunchKernelGGL(k_gtt_d<1>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
+    const int remap = ko.gtt_xcd;   // measured 5.10 -> 5.00 ms per step
+    if (ko.dma_nt) hipLaunchKernelGGL(k_gtt_d<1>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
     else hipLaunchKernelGGL(k_gtt_d<0>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
     return 0;
 }
 
 void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                  double* Ypart, const Gtt8Plan& plan) {
+                  double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko) {
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     const dim3 grid((unsigned)plan.grid), blk(256);
-    static const int remap = getenv("GPCA_GTT_XCD") ? atoi(getenv("GPCA_GTT_XCD")) : 0;
+    const int remap = ko.gttx_xcd;
     if (packed) hipLaunchKernelGGL((k_gtt_x<true>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
     else hipLaunchKernelGGL((k_gtt_x<false>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
+}
+
+// The LDS-DMA kernels use more than 64 KiB of dynamic LDS: the opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is recorded
+// per device by the runtime, so gpca_create calls this once per handle after hipSetDevice (a process may open handles on
+// several GPUs).  Returns a hipError_t value (0 = ok).
+int init_device_kernels_i8() {
+    int e = 0;
+#define GPCA_OPT_IN(KERNEL, BYTES) \
+    if (e == 0) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));
+    GPCA_OPT_IN((k_gq_d<0, 6>), sizeof(GqdSmemT<6>)) GPCA_OPT_IN((k_gq_d<1, 6>), sizeof(GqdSmemT<6>))
+    GPCA_OPT_IN((k_gq_d<0, 7>), sizeof(GqdSmemT<7>)) GPCA_OPT_IN((k_gq_d<1, 7>), sizeof(GqdSmemT<7>))
+    GPCA_OPT_IN((k_gtt_p<kDigits>), sizeof(GtpSmem)) GPCA_OPT_IN((k_gtt_p<3>), sizeof(GtpSmem))
+    GPCA_OPT_IN((k_gtt_d<0>), sizeof(GqdSmem)) GPCA_OPT_IN((k_gtt_d<1>), sizeof(GqdSmem))
+#undef GPCA_OPT_IN
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------

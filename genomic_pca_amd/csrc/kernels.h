@@ -12,6 +12,20 @@ constexpr int kGQRowsPerWave = 128;   // SNP rows per wave in the G Q kernel (R 
 
 struct QcParams { double min_call_rate, min_maf, max_hwe_p; };
 
+// Kernel-selection switches of one handle (read from the environment at gpca_create; defaults = the measured best).
+struct KernelOpts {
+    int stream_nt = 0;   // GPCA_STREAM_NT  : nt loads in the per-wave-plane kernels k_gq_i8 / k_gtt_i8
+    int dma_nt = 1;      // GPCA_GQ_DMA_NT  : nt on the LDS-DMA genotype streams (k_gq_d, k_gtt_d)
+    int gq_r = 4;        // GPCA_GQ_R       : max tiles per wave in k_gq_x
+    int gq_slots = 6;    // GPCA_GQ_SLOTS   : ring slots per wave in k_gq_d (6 or 7)
+    int gtt_xcd = 1;     // GPCA_GTT_XCD    : XCD-aware n-group order in k_gtt_d / k_gtt_p
+    int gttx_xcd = 0;    // GPCA_GTTX_XCD   : the same in the register-staged k_gtt_x (measured: no gain there)
+};
+// Opt-in to > 64 KiB of dynamic LDS for every kernel that needs it, on the CURRENT device (the attribute is per device).
+// Return a hipError_t value (0 = ok).
+int init_device_kernels_i8();
+int init_device_kernels_common();
+
 // Blocked layouts of the skinny GEMM operands (gemm_f32.hip): a lane's 8 / 16 k-steps are contiguous.
 //   Tb [group = row/16][lt][lane = 32*(row&1) + col%32][u = (row%16)/2]      (8 floats per lane)
 //   Qb [chunk = n/32][lt][lane = 32*((n%32)/16) + col%32][u = n%16]           (16 floats per lane)
@@ -28,6 +42,11 @@ __host__ __device__ inline int64_t blocked_q_index(int64_t n, int col, int LT) {
 
 void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset,
                   uint64_t seed, const uint32_t* d_thresh, int P);
+// Fast panel generator (GPCA_PANEL_SYNTH16): one 16-bit uniform per genotype, g = (u < t1) + (u < t2) with the 16-bit
+// thresholds t2 = P(g = 2) (low half) and t1 = P(g >= 1) (high half) of thresh16[row][n % P]; 8 genotypes per Philox call.
+// packed = 0: int8 rows of pitch ld; 1: 2-bit dosage codes, rows of pitch ld bytes.  snp0 = global index of row 0.
+void launch_synth16(hipStream_t st, void* G, int packed, int64_t rows, int64_t N, int64_t ld, int64_t snp0, uint64_t seed,
+                    const uint32_t* d_thresh16, int P);
 void launch_bed_decode(hipStream_t st, const uint8_t* bed, int64_t bytes_per_row, int8_t* G, int64_t M,
                        int64_t N, int64_t ld);
 // a1: per-SNP {n_valid,n0,n1,n2}, mu, sigma, r = 1/sigma, b = -mu r, keep, reason; flags[0] |= 1 if any
@@ -108,17 +127,21 @@ void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, 
                        float* Tb, float* cpart, int blocked = 1);
 
 
-// ---- exact-integer path (gemm_i8.hip), L = 32 only ----------------------------------------------------------
+// ---- exact-integer path (gemm_i8.hip), 32 columns per launch.  Every K1 here writes cpart[unit][32] = the unit's share of
+// b^T T (one partial per 32-row unit of the launch, partition-independent) and, except k_gq_i8, apart[wave][32] = column abs-max. ----------------------------------------------------------
 constexpr int kDigits = 4;   // signed base-128 digits of the skinny operand
 void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
                   const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                  int scale_out, int64_t ldt = 32);
+                  int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
 struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; };
 Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves);
 void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                   double* Ypart, const Gtt8Plan& plan);
+                   double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko = KernelOpts());
 void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
                         const double* tscale, double* Y, int64_t ldy = 32);
+void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first);
+void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy = 32);
+void launch_absmax_fold(hipStream_t st, const double* apart, int64_t P, double* run);
 int64_t absmax_num_parts(int64_t rows);
 // X [rows][32] row-major -> digit planes Xd [rows_pad/32][kDigits][64][16 B]; scale[j] = colmax_j / S, inv = 1/scale
 // layout 0: 32 consecutive rows per block; layout 1: the MFMA-step order of the packed (2-bit) G Q kernel
@@ -146,21 +169,21 @@ void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, in
                                 double* scale, double* inv, int8_t* Xd, int layout, int nd = 4, int64_t ldx = 32);
 // K2 for packed genotypes: stage-wise cooperative LDS-DMA (ring of four stage buffers); returns a hipError_t value
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
-                 const Gtt8Plan& plan, int nd = 4);
+                 const Gtt8Plan& plan, int nd = 4, const KernelOpts& ko = KernelOpts());
 // K2 with genotypes and digit planes brought in by LDS-DMA (int8-resident); returns a hipError_t value (0 = ok)
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
-                 const Gtt8Plan& plan);
+                 const Gtt8Plan& plan, const KernelOpts& ko = KernelOpts());
 // K1 with the genotypes brought in by LDS-DMA (full-line pieces); returns a hipError_t value (0 = ok)
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                int scale_out, int64_t ldt = 32);
+                int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
 // K1 with the digit planes of Q shared through LDS (int8-resident genotypes)
 void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                 int scale_out, int64_t ldt = 32);
+                 int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
 // K2 with the digit planes shared through LDS (packed = 0: int8 rows of pitch ldr, 1: 2-bit rows of pitch ldr)
 void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                  double* Ypart, const Gtt8Plan& plan);
+                  double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko = KernelOpts());
 void launch_gtt_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td,
                      double* Ypart, const Gtt8Plan& plan);
 

@@ -60,6 +60,51 @@ void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, i
                        d_thresh, P);
 }
 
+// Fast generator for streamed panels: thread = 16 consecutive samples of one SNP row = two Philox calls; writes 16 int8
+// bytes or one 32-bit word of 2-bit dosage codes (no int8 scratch + pack pass).  Bit-identical to
+// oracle/gpca_oracle.c:orc_synth16_genotypes.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_synth16(void* __restrict__ Gv, int64_t rows, int64_t N, int64_t ld, int64_t snp0,
+                                                  uint64_t seed, const uint32_t* __restrict__ thresh, int P) {
+    const int64_t per_row = PACKED ? (ld >> 2) : (ld >> 4);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * per_row) return;
+    const int64_t i = t / per_row;
+    const int64_t n0 = (t - i * per_row) << 4;
+    const uint64_t gi = (uint64_t)(i + snp0);
+    const uint32_t* th = thresh + i * P;
+    int pop = (int)(n0 % P);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    uint32_t codes = 0u;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        if (n0 + 8 * hf < N) {
+            const philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)((n0 >> 3) + hf), GPCA_STREAM_GEN16,
+                                               (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int s = 8 * hf + j;
+                const uint32_t tw = th[pop];
+                pop = pop + 1 == P ? 0 : pop + 1;
+                const uint32_t u = (o.v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                uint32_t g = (uint32_t)(u < (tw >> 16)) + (uint32_t)(u < (tw & 0xffffu));
+                if (n0 + s >= N) g = 0u;
+                if (PACKED) codes |= g << (2 * s);
+                else w[s >> 2] |= g << (8 * (s & 3));
+            }
+        }
+    }
+    if (PACKED) *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(Gv) + i * ld + (n0 >> 2)) = codes;
+    else *reinterpret_cast<uint4*>(static_cast<int8_t*>(Gv) + i * ld + n0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+void launch_synth16(hipStream_t st, void* G, int packed, int64_t rows, int64_t N, int64_t ld, int64_t snp0, uint64_t seed,
+                    const uint32_t* d_thresh16, int P) {
+    const int64_t total = rows * (packed ? (ld >> 2) : (ld >> 4));
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    if (packed) hipLaunchKernelGGL(k_synth16<true>, grid, blk, 0, st, G, rows, N, ld, snp0, seed, d_thresh16, P);
+    else hipLaunchKernelGGL(k_synth16<false>, grid, blk, 0, st, G, rows, N, ld, snp0, seed, d_thresh16, P);
+}
+
 // ------------------------------------------------------------------------------------------------
 // PLINK .bed 2-bit -> int8 dosage, count_a1 semantics (prepare.rs:622-629: .i8().count_a1()):
 //   code 00 -> 2, 10 -> 1, 11 -> 0, 01 -> missing (-127).  One thread = 4 packed bytes = 16 samples.
@@ -804,15 +849,16 @@ __global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, cons
     float* dst = out32 + n0 * K;
     for (int e = threadIdx.x; e < total; e += 256) dst[e] = osm[(e / K) * KP + (e % K)];
 }
+int init_device_kernels_common() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+}
 static size_t rightmul_lds(int L, int K, bool f32out) { return sizeof(double) * L * K + (f32out ? sizeof(float) * 256 * (size_t)(K | 1) : 0); }
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
                          float* out32) {
     const dim3 grid((unsigned)((rows + 255) / 256)), blk(256);
     const size_t lds = rightmul_lds(L, K, out32 != nullptr);
     if (L == 32) hipLaunchKernelGGL((k_rightmul<double, 32>), grid, blk, lds, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
-    else {
-        static const int a = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        (void)a;
+    else {   // (> 64 KiB of dynamic LDS: opted in per device by init_device_kernels_common)
         hipLaunchKernelGGL((k_rightmul<double, 64>), grid, blk, lds, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
     }
 }

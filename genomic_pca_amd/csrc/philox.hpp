@@ -2,6 +2,7 @@
 // Streams used by the engine (4th counter word):
 //   0x47454E4F  synthetic genotypes  counter = (snp_lo, snp_hi, sample/2)
 //   0x4F4D4547  sketch matrix Omega  counter = (snp_lo, snp_hi, column/4)
+//   0x47454E31  fast panel generator counter = (snp_lo, snp_hi, sample/8): eight 16-bit uniforms per call
 #pragma once
 #include <stdint.h>
 
@@ -31,3 +32,4 @@ GPCA_HD philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
 
 #define GPCA_STREAM_GENO 0x47454E4Fu
 #define GPCA_STREAM_OMEGA 0x4F4D4547u
+#define GPCA_STREAM_GEN16 0x47454E31u   // fast panel generator: counter = (snp_lo, snp_hi, sample/8)

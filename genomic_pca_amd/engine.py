@@ -44,10 +44,72 @@ class QcConfig:
         return QcConfig(0.0, 0.0, 1.0)
 
 
-class GpcaEngine:
-    """One opaque ``gpca_handle``: one GPU, one SNP-row shard of the genotype matrix."""
+class PanelSource:
+    """``gpca_panel_source``: where the SNP rows of a matrix come from, panel by panel.
 
-    def __init__(self, device: int = -1, precision: int = _lib.PREC_F32_MFMA, storage: int = _lib.STORE_INT8,
+    * ``PanelSource.host_i8(fn)``  -- ``fn(row0, rows) -> int8 [rows, N]`` (0/1/2, -127 missing)
+    * ``PanelSource.host_bed(fn)`` -- ``fn(row0, rows) -> uint8 [rows, ceil(N/4)]`` PLINK .bed rows
+    * ``PanelSource.synth(thresh, seed, snp_offset)`` / ``.synth16(...)`` -- device generators
+
+    Used for resident loading (``GpcaEngine.load_from_source``) and for out-of-core streaming
+    (``GpcaEngine.stream_open``; BASELINE.json configs[4]).  The reference's analogue is the accessor's strip pull loop
+    (main.rs:322,584; prepare.rs:1839-2022)."""
+
+    def __init__(self, kind: int, fill=None, thresh: Optional[np.ndarray] = None, seed: int = 0, snp_offset: int = 0):
+        self.kind = kind
+        self.thresh = None if thresh is None else np.ascontiguousarray(thresh, np.uint32)
+        self.seed, self.snp_offset = int(seed), int(snp_offset)
+        self._fill = fill
+        self._cb = _lib.PANEL_FN(self._tramp) if fill is not None else _lib.PANEL_FN()
+        self.error: Optional[BaseException] = None
+
+    def _tramp(self, _user, row0, rows, dst, ld):
+        try:
+            a = np.asarray(self._fill(int(row0), int(rows)))
+            want = np.int8 if self.kind == _lib.PANEL_HOST_I8 else np.uint8
+            if a.dtype != want or a.shape != (rows, ld):
+                raise ValueError(f"panel callback must return {np.dtype(want).name} [{rows}, {ld}], got {a.dtype} {a.shape}")
+            view = np.ctypeslib.as_array(C.cast(dst, C.POINTER(C.c_uint8)), shape=(rows, ld))
+            view[...] = a.view(np.uint8)
+            return 0
+        except BaseException as e:  # noqa: BLE001 -- reported through the C status
+            self.error = e
+            return 1
+
+    def c_struct(self) -> "_lib.gpca_panel_source":
+        st = _lib.gpca_panel_source()
+        st.kind = self.kind
+        st.fill = self._cb
+        st.seed, st.snp_offset = self.seed, self.snp_offset
+        if self.thresh is not None:
+            st.n_pop = self.thresh.shape[1]
+            st.thresh = self.thresh.ctypes.data_as(C.c_void_p)
+        return st
+
+    @staticmethod
+    def host_i8(fn):
+        return PanelSource(_lib.PANEL_HOST_I8, fill=fn)
+
+    @staticmethod
+    def host_bed(fn):
+        return PanelSource(_lib.PANEL_HOST_BED, fill=fn)
+
+    @staticmethod
+    def synth(thresh, seed, snp_offset=0):
+        return PanelSource(_lib.PANEL_SYNTH, thresh=thresh, seed=seed, snp_offset=snp_offset)
+
+    @staticmethod
+    def synth16(thresh16, seed, snp_offset=0):
+        return PanelSource(_lib.PANEL_SYNTH16, thresh=thresh16, seed=seed, snp_offset=snp_offset)
+
+
+class GpcaEngine:
+    """One opaque ``gpca_handle``: one GPU, one SNP-row shard of the genotype matrix.
+
+    Default = the exact-integer GEMM path on int8-resident genotypes (``PREC_I8_EXACT`` / ``STORE_INT8``), the path
+    bench.py's headline times; ``PREC_F32_MFMA`` selects the f32 matrix-core path, ``STORE_2BIT`` packed residency."""
+
+    def __init__(self, device: int = -1, precision: int = _lib.PREC_I8_EXACT, storage: int = _lib.STORE_INT8,
                  digit_planes: int = 0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
@@ -56,10 +118,15 @@ class GpcaEngine:
         if rc != _lib.GPCA_OK:
             raise GpcaError(rc, self._lib.gpca_last_error(None).decode())
         self._hook_ref = None
+        self._source_ref = None
 
     # -- plumbing
     def _chk(self, rc: int):
         if rc != _lib.GPCA_OK:
+            src = self._source_ref[0] if self._source_ref else None
+            if src is not None and src.error is not None:      # a panel callback raised: show its exception
+                err, src.error = src.error, None
+                raise err
             raise GpcaError(rc, self._lib.gpca_last_error(self._h).decode())
 
     def close(self):
@@ -101,6 +168,25 @@ class GpcaEngine:
             raise ValueError("thresh must be uint32 [M, P]")
         self._chk(self._lib.gpca_synth_genotypes(self._h, M, N, seed, _vp(t), t.shape[1], snp_offset))
 
+    def load_from_source(self, src: "PanelSource", M: int, N: int):
+        """Resident load through a panel source, chunked through bounded staging."""
+        cs = src.c_struct()
+        if src.thresh is not None and src.thresh.shape[0] != M:
+            raise ValueError("thresh must be uint32 [M, P]")
+        rc = self._lib.gpca_load_from_source(self._h, C.byref(cs), M, N)
+        if rc != _lib.GPCA_OK and src.error is not None:
+            raise src.error
+        self._chk(rc)
+
+    def stream_open(self, src: "PanelSource", M: int, N: int, panel_rows: int = 0, ring_slots: int = 3):
+        """Out-of-core mode: later snp_stats / rsvd / transform calls walk the matrix panel by panel through a ring of
+        HBM buffers (the source object must outlive them; it is kept referenced here)."""
+        cs = src.c_struct()
+        if src.thresh is not None and src.thresh.shape[0] != M:
+            raise ValueError("thresh must be uint32 [M, P]")
+        self._source_ref = (src, cs)
+        self._chk(self._lib.gpca_stream_open(self._h, C.byref(cs), M, N, panel_rows, ring_slots))
+
     def download_genotypes_i8(self) -> np.ndarray:
         M, N = self.dims()
         out = np.empty((M, N), np.int8)
@@ -134,6 +220,12 @@ class GpcaEngine:
         mu = np.ascontiguousarray(mu, np.float32); sigma = np.ascontiguousarray(sigma, np.float32)
         keep = None if keep is None else np.ascontiguousarray(keep, np.uint8)
         self._chk(self._lib.gpca_set_standardization(self._h, _vp(mu), _vp(sigma), _vp(keep)))
+
+    def get_standardization(self):
+        M, _ = self.dims()
+        mu = np.empty(M, np.float32); sg = np.empty(M, np.float32); keep = np.empty(M, np.uint8)
+        self._chk(self._lib.gpca_get_standardization(self._h, _vp(mu), _vp(sg), _vp(keep)))
+        return dict(mu=mu, sigma=sg, keep=keep)
 
     @staticmethod
     def hwe_chi_squared_p_value(n_hom1: int, n_het: int, n_hom2: int) -> float:
@@ -224,7 +316,7 @@ class GpcaEngine:
     def timings(self) -> dict:
         n = C.c_int32()
         arr = (_lib.gpca_kernel_timing * 32)()
-        self._chk(self._lib.gpca_get_timings(self._h, arr, 32, C.byref(n)))
+        self._chk(self._lib.gpca_get_timings(self._h, arr, 32, C.byref(n)))   # (timings are off until enable_timings(True))
         return {arr[i].name.decode(): dict(launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops,
                                            bytes=arr[i].bytes) for i in range(min(n.value, 32))}
 
@@ -245,8 +337,8 @@ class PCA:
     accepted for signature parity and ignored (main.rs:638 always passes None).
     """
 
-    def __init__(self, device: int = -1):
-        self._eng = GpcaEngine(device=device)
+    def __init__(self, device: int = -1, precision: int = _lib.PREC_I8_EXACT, storage: int = _lib.STORE_INT8):
+        self._eng = GpcaEngine(device=device, precision=precision, storage=storage)
         self._fitted = False
 
     def rfit(self, x: np.ndarray, k: int, n_oversamples: int = 10, seed: Optional[int] = None, tol=None,
@@ -346,20 +438,60 @@ class EigenSNPCoreOutput:
 class EigenSNPCoreAlgorithm:
     """``EigenSNPCoreAlgorithm::new(cfg).compute_pca(&accessor, &blocks)`` (main.rs:359-365).
 
-    Implements the GLOBAL randomized-PCA stage on the whole standardised matrix (all SNPs of all
-    blocks), which is what the reference's own README usage -- one genome-wide block -- reduces to.
-    The per-LD-block local basis stage is defined only in the un-vendored crate (SURVEY.md 8f
-    rank 3) and is not reproduced; block membership only restricts which SNPs enter the PCA.
+    Implements the GLOBAL randomized-PCA stage on the standardised matrix restricted to the SNPs the caller's
+    ``ld_blocks`` name (``LdBlockSpecification.pca_snp_ids_in_block``, prepare.rs:1540-1543): a PCA SNP that appears in
+    no block does not enter the PCA, exactly as in the reference, where ``D`` = SNPs that passed QC and fell in a block
+    (prepare.rs:1465-1469).  With the README's one genome-wide block this is the plain randomized PCA of all PCA SNPs.
+
+    Which of the 14 config fields (main.rs:311-327) act here:
+
+    * used: ``target_num_global_pcs``, ``global_pca_sketch_oversampling``, ``global_pca_num_power_iterations``, ``random_seed``;
+    * no-ops by construction: ``snp_processing_strip_size`` (the strips the reference pulls through the accessor are the
+      HBM-resident rows / streamed panels here), ``collect_diagnostics`` / ``diagnostic_block_list_id_to_trace`` (the
+      second return value is a small dict of what ran, not the crate's diagnostics struct);
+    * NOT implemented (accepted for signature parity, ignored): ``components_per_ld_block``,
+      ``subset_factor_/min_/max_subset_size_for_local_basis_learning``, ``local_rsvd_*`` and ``refine_pass_count`` --
+      they parameterise the per-LD-block local basis stage and the refinement passes, which are defined only in the
+      un-vendored ``efficient_pca`` crate.
     """
 
     def __init__(self, config: EigenSNPCoreAlgorithmConfig):
         self.config = config
 
+    @staticmethod
+    def _union_of_blocks(ld_blocks: Sequence[LdBlockSpecification], n_pca: int) -> np.ndarray:
+        if len(ld_blocks) == 0:
+            raise ValueError("compute_pca: ld_block_specifications is empty")
+        ids = np.unique(np.concatenate([np.asarray(b.pca_snp_ids_in_block, np.int64).reshape(-1) for b in ld_blocks]))
+        if ids.size == 0:
+            raise ValueError("compute_pca: the LD blocks hold no PCA SNP")
+        if ids[0] < 0 or ids[-1] >= n_pca:
+            raise ValueError(f"compute_pca: PcaSnpId {int(ids[0] if ids[0] < 0 else ids[-1])} out of range [0, {n_pca})")
+        return ids
+
     def compute_pca(self, accessor: MicroarrayGenotypeAccessor, ld_blocks: Sequence[LdBlockSpecification]):
         eng = accessor.engine
         cfg = self.config
-        eng.rsvd(cfg.target_num_global_pcs, cfg.global_pca_sketch_oversampling, cfg.global_pca_num_power_iterations,
-                 cfg.random_seed)
-        out = EigenSNPCoreOutput(eng.scores(), eng.eigenvalues(), eng.loadings(), accessor.num_qc_samples(),
-                                 accessor.num_pca_snps(), cfg.target_num_global_pcs)
-        return out, None
+        n_pca = accessor.num_pca_snps()
+        ids = self._union_of_blocks(ld_blocks, n_pca)
+        restore = None
+        if ids.size < n_pca:
+            # SNPs outside every block leave the PCA: keep mask = union of the blocks (same mu/sigma); the accessor's
+            # own PCA-SNP numbering is restored afterwards, as the reference never mutates its accessor
+            st = eng.get_standardization()
+            rows = eng.pca_snp_rows()
+            keep2 = np.zeros_like(st["keep"])
+            keep2[rows[ids]] = 1
+            eng.set_standardization(st["mu"], st["sigma"], keep2)
+            restore = st
+        try:
+            eng.rsvd(cfg.target_num_global_pcs, cfg.global_pca_sketch_oversampling, cfg.global_pca_num_power_iterations,
+                     cfg.random_seed)
+            out = EigenSNPCoreOutput(eng.scores(), eng.eigenvalues(), eng.loadings(), accessor.num_qc_samples(),
+                                     int(ids.size), cfg.target_num_global_pcs)
+        finally:
+            if restore is not None:
+                eng.set_standardization(restore["mu"], restore["sigma"], restore["keep"])
+        diag = dict(stage="global", num_ld_blocks=len(ld_blocks), num_pca_snps_in_blocks=int(ids.size),
+                    pca_snp_ids_used=ids) if cfg.collect_diagnostics else None
+        return out, diag

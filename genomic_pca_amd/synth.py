@@ -33,3 +33,22 @@ def synth_thresholds(M: int, P: int = 3, seed: int = 1, fst: float = 0.05, snp_o
         out[done:done + take] = np.minimum(np.floor(pc * 4294967296.0), 4294967295.0).astype(np.uint32)
         done += take
     return out
+
+
+def synth_thresholds16(M: int, P: int = 3, seed: int = 1, fst: float = 0.05, snp_offset: int = 0) -> np.ndarray:
+    """uint32 [M, P] for the fast panel generator (GPCA_PANEL_SYNTH16): one 16-bit uniform u per genotype,
+    g = (u < t1) + (u < t2) with t2 = floor(p^2 * 65536) in the low half (P(g = 2)) and
+    t1 = floor((1 - (1 - p)^2) * 65536) in the high half (P(g >= 1)): Hardy-Weinberg proportions of the same
+    per-population allele frequencies synth_thresholds() uses."""
+    out = np.empty((M, P), np.uint32)
+    done = 0
+    while done < M:
+        g = snp_offset + done
+        blk, off = divmod(g, _BLOCK)
+        take = min(M - done, _BLOCK - off)
+        pc = _block_table(seed, blk, P, fst)[off:off + take]
+        t2 = np.minimum(np.floor(pc * pc * 65536.0), 65535.0).astype(np.uint32)
+        t1 = np.minimum(np.floor((1.0 - (1.0 - pc) ** 2) * 65536.0), 65535.0).astype(np.uint32)
+        out[done:done + take] = (t1 << np.uint32(16)) | t2
+        done += take
+    return out

@@ -14,8 +14,12 @@
  * HBM, and every pass over them runs on the device; the pull API survives as
  * gpca_standardize_block() for boundary parity.
  *
- * Threading: a handle is single-owner (one host thread, one GPU).  Functions return
- * GPCA_OK (0) or a negative gpca_status; gpca_last_error() gives the human string.
+ * Threading: one handle = one GPU.  Every entry point takes the handle's (recursive) lock, so a handle may be shared
+ * between host threads the way the reference shares its `Clone + Send + Sync` accessor between rayon workers
+ * (prepare.rs:1770-1779, 1838): calls are serialised per handle, different handles run concurrently.  gpca_destroy
+ * must not race with other calls on the same handle; gpca_last_error() returns the handle's last message (read it
+ * before another thread's call on the same handle overwrites it).  Functions return GPCA_OK (0) or a negative
+ * gpca_status.
  */
 #ifndef GPCA_H
 #define GPCA_H
@@ -33,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GPCA_VERSION 100 /* 0.1.0 */
+#define GPCA_VERSION 200 /* 0.2.0 */
 #define GPCA_MISSING_I8 (-127) /* bed_reader i8 missing code, prepare.rs:1224 */
 
 typedef struct gpca_handle gpca_handle;
@@ -104,6 +108,38 @@ GPCA_API int gpca_upload_bed2bit(gpca_handle* h, const uint8_t* bed_rows, int64_
 GPCA_API int gpca_synth_genotypes(gpca_handle* h, int64_t M, int64_t N, uint64_t seed, const uint32_t* thresh,
                          int32_t P, int64_t snp_offset);
 GPCA_API int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t ld);
+
+/* ---- g: panel sources and out-of-core streaming (BASELINE.json configs[4]; the reference never holds the matrix either:
+ *      its solver pulls snp_processing_strip_size-row strips through the accessor, main.rs:322,584, prepare.rs:1839-2022) */
+typedef enum gpca_panel_kind {
+    GPCA_PANEL_HOST_I8 = 0,  /* `fill` writes int8 SNP-major rows (0/1/2, -127 missing), row pitch ld = N */
+    GPCA_PANEL_HOST_BED = 1, /* `fill` writes PLINK .bed rows (2 bits/sample, count_a1 decode), row pitch ld = ceil(N/4) */
+    GPCA_PANEL_SYNTH = 2,    /* device generator of gpca_synth_genotypes: thresh = uint32 [M][n_pop] = floor(p * 2^32) */
+    GPCA_PANEL_SYNTH16 = 3   /* fast device generator, one 16-bit uniform per genotype: thresh = uint32 [M][n_pop],
+                                high half = floor(P(g >= 1) * 65536), low half = floor(P(g = 2) * 65536) */
+} gpca_panel_kind;
+/* Write rows [row0, row0 + rows) of the matrix into dst (pinned host memory owned by the library).  Return 0, or
+ * non-zero to abort the pass (reported as GPCA_ERR_BAD_ARG with the row range in the message). */
+typedef int (*gpca_panel_fn)(void* user, int64_t row0, int64_t rows, void* dst, int64_t ld);
+typedef struct gpca_panel_source {
+    int32_t kind;           /* gpca_panel_kind */
+    int32_t n_pop;          /* SYNTH*: populations (columns of thresh) */
+    gpca_panel_fn fill;     /* HOST_*: called from the thread that runs the pass, once per panel per pass, rows ascending */
+    void* user;
+    const uint32_t* thresh; /* SYNTH*: host table, copied to the device at open */
+    uint64_t seed;          /* SYNTH* */
+    int64_t snp_offset;     /* SYNTH*: global index of row 0 (row shards of one matrix draw the rows they would unsharded) */
+    int64_t reserved[2];
+} gpca_panel_source;
+/* Resident load through a panel source (chunked through bounded staging: a 250 GB .bed needs no second device copy). */
+GPCA_API int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N);
+/* Out-of-core mode: the matrix is never resident.  Every pass of gpca_snp_stats / gpca_rsvd / gpca_transform walks
+ * ceil(M / panel_rows) panels through a ring of `ring_slots` (>= 2) HBM panel buffers; panel p + 1 is generated or
+ * copied on a second stream while panel p is multiplied.  panel_rows is rounded up to a multiple of 128; 0 picks
+ * ~1 GiB panels.  Requires GPCA_PREC_I8_EXACT (either storage).  Results are bit-identical to the resident engine on the
+ * same matrix.  The pull API (gpca_standardize_block) and gpca_download_genotypes_i8 need a resident matrix. */
+GPCA_API int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N, int64_t panel_rows,
+                              int32_t ring_slots);
 GPCA_API int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N);
 
 /* ---- a1/a3: SNP QC + standardisation parameters (prepare.rs:1100-1422, 1641-1745) -------- */
@@ -115,6 +151,8 @@ GPCA_API int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* mu,
 GPCA_API int gpca_get_snp_qc_detail(gpca_handle* h, uint32_t* counts, uint8_t* reason);
 /* Caller-supplied parameters instead of gpca_snp_stats (e.g. LD-block restriction via keep). */
 GPCA_API int gpca_set_standardization(gpca_handle* h, const float* mu, const float* sigma, const uint8_t* keep);
+/* Current parameters, length M each (any may be NULL): what gpca_snp_stats computed or gpca_set_standardization set. */
+GPCA_API int gpca_get_standardization(gpca_handle* h, float* mu, float* sigma, uint8_t* keep);
 /* Host helper, same branches as prepare.rs:1641-1745. */
 GPCA_API double gpca_hwe_chi_squared_p_value(uint64_t n_hom1, uint64_t n_het, uint64_t n_hom2);
 
@@ -130,7 +168,10 @@ GPCA_API int gpca_get_pca_snp_rows(gpca_handle* h, int64_t* rows);
 
 /* ---- a5/a6: randomized PCA (PCA::rfit main.rs:648-656; compute_pca main.rs:365) ---------- */
 /* l = k + oversample columns (<= 64); power_iters QR-stabilised iterations; Omega from
- * Philox4x32-10 keyed by seed.  Requires stats.  Results stay on the device until fetched. */
+ * Philox4x32-10 keyed by seed.  Requires stats.  Results stay on the device until fetched.
+ * Row-sharded runs (gpca_comm_init / gpca_set_allreduce_hook): the ranks agree on a status word before the first and after
+ * the last exchange of the call, so a rank-local failure (missing genotype in one shard, out of memory, a failed launch)
+ * is returned by EVERY rank instead of leaving the others inside a collective. */
 GPCA_API int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed);
 GPCA_API int gpca_get_scores(gpca_handle* h, float* out /* [N][k] */);       /* main.rs:389 */
 GPCA_API int gpca_get_scores_f64(gpca_handle* h, double* out /* [N][k] */);  /* main.rs:659 (f64 path) */
@@ -160,7 +201,9 @@ typedef struct gpca_kernel_timing {
     double flops;      /* algorithmic (un-padded) flops summed over those launches */
     double bytes;      /* algorithmic HBM bytes summed over those launches */
 } gpca_kernel_timing;
-/* Timings accumulated since the last gpca_reset_timings (events resolved lazily here). */
+/* Timings are OFF by default (gpca_enable_timings(h, 1) turns them on); records are folded into per-name totals
+ * once 32768 are pending, so a long-running host never accumulates events.
+ * Timings accumulated since the last gpca_reset_timings (events resolved lazily here). */
 GPCA_API int gpca_get_timings(gpca_handle* h, gpca_kernel_timing* out, int32_t cap, int32_t* n);
 GPCA_API int gpca_reset_timings(gpca_handle* h);
 GPCA_API int gpca_enable_timings(gpca_handle* h, int32_t on);

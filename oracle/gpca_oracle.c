@@ -16,6 +16,11 @@
  *     q = 2 (main.rs:318), seed (main.rs:637), standardisation (g-mu)/sigma with sample (n-1)
  *     sigma (prepare.rs:1294,1357-1364,1948-1988), eigenvalues s^2/(N-1).
  *
+ *   - orc_rsvd below is the SAME recipe the HIP engine runs (CholeskyQR2 + cyclic Jacobi): it is the timed CPU baseline
+ *     ("port") and a cross-check.  The parity CHECKER of tests/ is oracle.py:rsvd(method="lapack"): the same sketch and the
+ *     same two products (orc_prod_AQ / orc_prod_AtT), but Householder QR (LAPACK geqrf) for the tall orthonormalisation and
+ *     LAPACK gesdd for the small factorisation -- no small-dense code in common with the product.
+ *
  * Build: see oracle/Makefile (REAL=double -> checker, REAL=float -> timed CPU baseline).
  */
 #include <math.h>
@@ -76,6 +81,29 @@ void orc_synth_genotypes(int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t sn
             if (n + 1 < N) {
                 t = thresh[i * P + ((n + 1) % P)];
                 G[i * ld + n + 1] = (int8_t)((o[2] < t) + (o[3] < t));
+            }
+        }
+    }
+}
+
+/* Fast panel generator (GPCA_PANEL_SYNTH16; device twin: genomic_pca_amd/csrc/kernels.hip:k_synth16).  One 16-bit
+ * uniform per genotype: counter = (snp_lo, snp_hi, n/8, stream 0x47454E31), key = seed; sample n = 8q + j takes
+ * u = 16-bit field (j & 1) of output word j >> 1;  g = (u < t1) + (u < t2) with the thresholds of population n % P packed
+ * in thresh[i*P + n%P]: high half t1 = floor(P(g >= 1) * 65536), low half t2 = floor(P(g = 2) * 65536). */
+void orc_synth16_genotypes(int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset,
+                           uint64_t seed, const uint32_t* thresh, int P) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        uint64_t gi = (uint64_t)(i + snp_offset);
+        for (int64_t q = 0; q < (N + 7) / 8; ++q) {
+            uint32_t o[4];
+            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)q, 0x47454E31u,
+                          (uint32_t)seed, (uint32_t)(seed >> 32), o);
+            for (int j = 0; j < 8 && 8 * q + j < N; ++j) {
+                int64_t n = 8 * q + j;
+                uint32_t tw = thresh[i * P + (n % P)];
+                uint32_t u = (o[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                G[i * ld + n] = (int8_t)((u < (tw >> 16)) + (u < (tw & 0xffffu)));
             }
         }
     }

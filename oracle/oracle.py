@@ -11,7 +11,10 @@ Two layers:
     normalisation ``(g - mu) / sigma`` (``prepare.rs:1294,1357-1364,1948-1988``).
 
 Parity status: rSVD is "parity unpinned" (algorithm lives in the un-vendored ``efficient_pca``
-crate, ``Cargo.toml:30``; the reference holds no golden vectors).
+crate, ``Cargo.toml:30``; the reference holds no golden vectors).  What stands in for the pin:
+``rsvd()`` shares no small-dense code with the product (LAPACK QR / SVD vs CholeskyQR2 / Jacobi), and
+tests/test_oracle.py checks it against ``scipy.linalg.svd`` of the dense standardised matrix and against
+``sklearn.utils.extmath.randomized_svd``.
 """
 from __future__ import annotations
 
@@ -73,6 +76,16 @@ def synth_genotypes(M: int, N: int, seed: int, thresh: np.ndarray, snp_offset: i
     thresh = np.ascontiguousarray(thresh, np.uint32)
     lib().orc_synth_genotypes(_p(G, C.c_int8), C.c_int64(M), C.c_int64(N), C.c_int64(ld), C.c_int64(snp_offset),
                               C.c_uint64(seed), _p(thresh, C.c_uint32), C.c_int(thresh.shape[1]))
+    return G
+
+
+def synth16_genotypes(M: int, N: int, seed: int, thresh16: np.ndarray, snp_offset: int = 0, ld: int | None = None) -> np.ndarray:
+    """Fast panel generator (GPCA_PANEL_SYNTH16), restated in gpca_oracle.c:orc_synth16_genotypes."""
+    ld = ld or N
+    G = np.zeros((M, ld), np.int8)
+    thresh16 = np.ascontiguousarray(thresh16, np.uint32)
+    lib().orc_synth16_genotypes(_p(G, C.c_int8), C.c_int64(M), C.c_int64(N), C.c_int64(ld), C.c_int64(snp_offset),
+                                C.c_uint64(seed), _p(thresh16, C.c_uint32), C.c_int(thresh16.shape[1]))
     return G
 
 
@@ -171,8 +184,9 @@ def cholqr2(Y, real="f64"):
     return Q
 
 
-def rsvd(G, N, r, b, k, oversample=10, power_iters=2, seed=1, snp_offset=0, real="f64"):
-    """The restated randomized PCA (oracle/gpca_oracle.c:orc_rsvd).  Returns dict of f64 arrays."""
+def rsvd_port(G, N, r, b, k, oversample=10, power_iters=2, seed=1, snp_offset=0, real="f64"):
+    """The recipe the HIP engine runs, restated in C (oracle/gpca_oracle.c:orc_rsvd: CholeskyQR2 + cyclic Jacobi).
+    Timed as bench.py's cpu_baseline ("port", real="f32"); cross-checked against rsvd() in tests/test_oracle.py."""
     G = np.ascontiguousarray(G, np.int8); M, ld = G.shape
     r = np.ascontiguousarray(r, np.float32); b = np.ascontiguousarray(b, np.float32)
     l = k + oversample
@@ -183,6 +197,31 @@ def rsvd(G, N, r, b, k, oversample=10, power_iters=2, seed=1, snp_offset=0, real
     if rc:
         raise np.linalg.LinAlgError(f"orc_rsvd failed rc={rc}")
     return dict(scores=scores, eigenvalues=ev, loadings=load, singular_values=sv)
+
+
+def rsvd(G, N, r, b, k, oversample=10, power_iters=2, seed=1, snp_offset=0, real="f64", method="lapack"):
+    """THE PARITY CHECKER: randomized PCA with the engine's sketch (same Philox Omega) and the plain-loop f64 products
+    of gpca_oracle.c, but with LAPACK for every small-dense step -- Householder QR (numpy.linalg.qr -> geqrf/orgqr) for
+    the tall orthonormalisation and an SVD of the projection B = A Q (numpy.linalg.svd -> gesdd) instead of the
+    product's CholeskyQR2 + Jacobi.  The product shares no small-dense code with this function, so a defect in either
+    side's factorisations cannot cancel in a parity test.  (method="port" = rsvd_port, the same-recipe C restatement.)
+
+    Q from Householder QR spans the same subspace as the product's CholeskyQR2 basis; scores = Q W s, loadings = U and
+    eigenvalues = s^2/(N-1) do not depend on the basis chosen inside that subspace."""
+    if method == "port" or real != "f64":
+        return rsvd_port(G, N, r, b, k, oversample, power_iters, seed, snp_offset, real)
+    G = np.ascontiguousarray(G, np.int8); M = G.shape[0]
+    r = np.ascontiguousarray(r, np.float32); b = np.ascontiguousarray(b, np.float32)
+    l = k + oversample
+    Y = prod_AtT(G, N, r, b, omega(M, l, seed, snp_offset))            # N x l sketch  A^T Omega
+    Q, _ = np.linalg.qr(Y)
+    for _ in range(power_iters):
+        Q, _ = np.linalg.qr(prod_AtT(G, N, r, b, prod_AQ(G, N, r, b, Q)))
+    B = prod_AQ(G, N, r, b, Q)                                         # M x l
+    U, s, Wt = np.linalg.svd(B, full_matrices=False)                   # B = U diag(s) Wt
+    scores = (Q @ Wt.T[:, :k]) * s[:k]
+    sgn = np.sign(scores[np.abs(scores).argmax(axis=0), np.arange(k)]); sgn[sgn == 0] = 1
+    return dict(scores=scores * sgn, eigenvalues=s[:k] ** 2 / (N - 1), loadings=U[:, :k] * sgn, singular_values=s)
 
 
 def standardized_dense(G, N, r, b) -> np.ndarray:

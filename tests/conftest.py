@@ -28,6 +28,8 @@ def gpca():
 
 @pytest.fixture()
 def engine(gpca):
-    e = gpca.GpcaEngine()
+    """The f32-MFMA path on int8-resident genotypes, named explicitly (GpcaEngine's own default is the exact-integer path)."""
+    from genomic_pca_amd import _lib
+    e = gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA, storage=_lib.STORE_INT8)
     yield e
     e.close()

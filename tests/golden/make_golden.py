@@ -6,8 +6,11 @@ this path, so these fixtures pin the ORACLE's outputs on seeded i
 oracle or to the synthetic generator that alters any number is caught by tests/test_oracle.py, and the GPU
 parity tests compare against the same arrays.  Run from the repo root:  python tests/golden/make_golden.py
 
-Also extracts a 2000-SNP slice of the reference's own data fixture data/chr22_subset50.bed(.zip)
-(64 samples; a data file, not source) when /root/reference is present, with its decoded int8 dosages.
+Also extracts two slices of the reference's own data fixture data/chr22_subset50.bed(.zip) (64 samples; a data
+file, not source) when /root/reference is present: 2000 SNPs with their decoded int8 dosages, and 120 000 SNPs (1.9 MB
+of .bed bytes, BASELINE.json configs[2]'s data at a size the CPU oracle handles in seconds) with the .fam sample ids
+and the oracle's QC + randomized-PCA + exact-PCA outputs on it.  data/chr22_subset50.bim.zip is missing from the
+reference checkout (.MISSING_LARGE_BLOBS), so the tests synthesise a .bim (chromosome 22, increasing positions).
 """
 import io
 import os
@@ -67,6 +70,21 @@ def bed_fixture():
     np.savez_compressed(os.path.join(HERE, "chr22_subset50_slice.npz"), bed_rows=rows, n_samples=n, snp_start=start,
                         m_total=m_total, dosage_count_a1=G, iids=np.array([l.split()[1] for l in fam]))
     print("chr22_subset50_slice.npz", os.path.getsize(os.path.join(HERE, "chr22_subset50_slice.npz")), "N =", n, "M_total =", m_total)
+    # configs[2] at test size: 120 000 consecutive SNPs, QC with the reference's effective defaults, k = 20
+    start, count, k, seed = 300_000, 120_000, 20, 2025
+    rows = np.frombuffer(bed, np.uint8, count * bpr, 3 + start * bpr).reshape(count, bpr).copy()
+    G = decode_bed_rows(rows, n)
+    st = O.snp_stats(G, n, 0.98, 0.01, 1e-6)
+    r, b = O.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = O.rsvd(G, n, r, b, k, 10, 2, seed=seed)
+    E = O.exact_pca(G, n, r, b, k)
+    np.savez_compressed(os.path.join(HERE, "chr22_subset50_120k.npz"), bed_rows=rows, n_samples=n, snp_start=start,
+                        iids=np.array([l.split()[1] for l in fam]), fids=np.array([l.split()[0] for l in fam]),
+                        keep=st["keep"], reason=st["reason"], mu=st["mu"], sigma=st["sigma"], k=k, seed=seed,
+                        eigenvalues=R["eigenvalues"], scores=R["scores"], exact_eigenvalues=E["eigenvalues"],
+                        exact_scores=E["scores"])
+    print("chr22_subset50_120k.npz", os.path.getsize(os.path.join(HERE, "chr22_subset50_120k.npz")), "kept", int(st["keep"].sum()),
+          "rel d(eigenvalue) rsvd vs exact", float(np.max(np.abs(R["eigenvalues"] - E["eigenvalues"]) / E["eigenvalues"])))
 
 
 if __name__ == "__main__":

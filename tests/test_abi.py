@@ -31,9 +31,17 @@ def test_no_undeclared_exports(gpca):
 
 def test_version_and_strings(gpca):
     lib = gpca.load()
-    assert lib.gpca_version() == 100
+    assert lib.gpca_version() == 200
     assert lib.gpca_status_string(0) == b"ok"
     assert b"missing genotype" in lib.gpca_status_string(-5)
+
+
+def test_header_cites_the_reference_interfaces():
+    """Every entry point group of include/gpca.h names the reference interface it replaces (file:line)."""
+    src = open(os.path.join(ROOT, "include", "gpca.h")).read()
+    for cite in ("prepare.rs:1838-2030", "main.rs:602,648-660", "main.rs:359-366", "prepare.rs:1100-1422", "prepare.rs:1641-1745",
+                 "main.rs:322,584", "prepare.rs:1770-1779"):
+        assert cite in src, cite
 
 
 def test_fails_loudly_without_gpu(gpca):

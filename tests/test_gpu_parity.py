@@ -286,7 +286,9 @@ def test_allreduce_hook_two_shards_one_gpu(gpca, oracle):
     M, N, P, k = 4000, 384, 8, 6
     th = gpca.synth_thresholds(M, P, seed=31, fst=0.3)
     G = oracle.synth_genotypes(M, N, 31, th)
-    full = gpca.GpcaEngine(); full.upload_genotypes_i8(G); full.snp_stats(); full.rsvd(k, 10, 2, seed=5)
+    from genomic_pca_amd import _lib
+    mk = lambda: gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_INT8)     # the headline path, named explicitly
+    full = mk(); full.upload_genotypes_i8(G); full.snp_stats(); full.rsvd(k, 10, 2, seed=5)
     ref_scores, ref_ev, ref_ld = full.scores(f64=True), full.eigenvalues(), full.loadings(); full.close()
     world = 2
     spans = [gpca.shard_rows(M, world, r) for r in range(world)]
@@ -294,7 +296,7 @@ def test_allreduce_hook_two_shards_one_gpu(gpca, oracle):
 
     def run(rank):
         a, b_ = spans[rank]
-        e = gpca.GpcaEngine(); e.upload_genotypes_i8(G[a:b_]); e.snp_stats()
+        e = mk(); e.upload_genotypes_i8(G[a:b_]); e.snp_stats()
 
         def hook(buf):
             bufs[rank] = buf.copy(); barrier.wait()
@@ -305,10 +307,12 @@ def test_allreduce_hook_two_shards_one_gpu(gpca, oracle):
     ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])   # replicated results identical
-    assert np.max(np.abs(res[0][1] - ref_ev) / ref_ev) < 1e-6
-    assert oracle.max_abs_dpc(res[0][0], ref_scores) < 1e-5
+    # exact integer partial sums and per-unit centring partials: sharding only changes the f64 order in which the two
+    # shards' sketches are added
+    assert np.max(np.abs(res[0][1] - ref_ev) / ref_ev) < 1e-10
+    assert oracle.max_abs_dpc(res[0][0], ref_scores) < 1e-9
     ld = np.concatenate([res[0][2], res[1][2]], axis=0)
-    assert oracle.max_abs_dpc(ld.astype(np.float64), ref_ld.astype(np.float64)) < 1e-5
+    assert oracle.max_abs_dpc(ld.astype(np.float64), ref_ld.astype(np.float64)) < 1e-6
 
 
 def test_rccl_world1(gpca, oracle, engine):
@@ -326,7 +330,10 @@ def test_rccl_world1(gpca, oracle, engine):
 
 def test_timings_exposed(gpca, oracle, engine):
     th, G = _make(gpca, oracle, engine, 3000, 512, 4, seed=2)
-    engine.snp_stats(fetch=False); engine.reset_timings()
+    engine.snp_stats(fetch=False)
+    engine.rsvd(10, 10, 2, seed=1)
+    assert engine.timings() == {}                      # off by default: a long-running host accumulates nothing
+    engine.enable_timings(True); engine.reset_timings()
     engine.rsvd(10, 10, 2, seed=1)
     t = engine.timings()
     assert t["gemm_GQ"]["launches"] == 3 and t["gemm_GtT"]["launches"] == 3
@@ -386,21 +393,32 @@ def test_bed2bit_decode_reference_fixture(gpca, oracle, engine):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json configs[1] at full size (1M SNPs x 10k samples): size-independent properties
 # ------------------------------------------------------------------------------------------------
-def test_full_size_properties(gpca, oracle):
+_FULL = {}
+
+
+@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("f32", "int8")])
+def test_full_size_properties(gpca, oracle, prec, store):
+    """BASELINE.json configs[1] at full size on EVERY GEMM path, named explicitly: ("i8", "int8") is the headline path of
+    bench.py (k_gq_d / k_gtt_d, LDS-DMA), ("i8", "2bit") the packed kernels (k_gq_2bit / k_gtt_p), ("f32", "int8") the
+    f32 matrix-core kernels.  The oracle cannot run at this size, so: spot rows against the oracle, orthogonality,
+    centring, idempotence, PCA::transform consistency, and agreement of the structured PCs between the paths."""
+    from genomic_pca_amd import _lib
     M, N, k, seed = 1_000_000, 10_000, 20, 1
     th = gpca.synth_thresholds(M, 3, seed=seed)
-    with gpca.GpcaEngine() as e:
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA,
+                         storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8) as e:
         e.synth_genotypes(M, N, seed, th)
         st = e.snp_stats(gpca.QcConfig.none())
         counts, _ = e.snp_qc_detail()
         # (1) generator + stats: spot rows against the oracle (same global row index -> same bytes)
         rows = np.array([0, 1, 65535, 65536, 123457, 777777, M - 1])
+        pca_rows = e.pca_snp_rows()
         for i in rows:
             g_row = oracle.synth_genotypes(1, N, seed, th[i:i + 1], snp_offset=int(i))
             o = oracle.snp_stats(g_row, N, 0.0, 0.0, 1.0)
             assert np.array_equal(counts[i], o["counts"][0]) and st["mu"][i] == o["mu"][0]
             assert abs(float(st["sigma"][i]) - float(o["sigma"][0])) <= np.spacing(o["sigma"][0])
-            blk = e.standardize_block([int(np.searchsorted(e.pca_snp_rows(), i))], np.arange(0, N, 997))
+            blk = e.standardize_block([int(np.searchsorted(pca_rows, i))], np.arange(0, N, 997))
             ref, err = oracle.standardize_block(g_row, o["mu"], o["sigma"], [0], np.arange(0, N, 997))
             assert err is None and np.array_equal(blk, ref)
         assert counts[:, 0].min() == N and int(st["keep"].sum()) == M         # no missing, everything kept
@@ -426,6 +444,55 @@ def test_full_size_properties(gpca, oracle):
         # (5) PCA::transform consistency: A^T U = V s up to convergence of the trailing (noise) PCs
         tr = e.transform()
         assert oracle.max_abs_dpc(tr[:, :2], sc[:, :2]) < 1e-4
+        # (6) loadings of spot rows against a direct f64 evaluation  u_i = a_i . V_k / s  from the oracle's bytes
+        V = sc[:, :2] / sv[:2]
+        for i in rows:
+            g_row = oracle.synth_genotypes(1, N, seed, th[i:i + 1], snp_offset=int(i)).astype(np.float64)[0]
+            a_i = (g_row - float(st["mu"][i])) / float(st["sigma"][i])
+            assert np.max(np.abs(a_i @ V / sv[:2] - ld[i, :2].astype(np.float64))) < 1e-5
+    # (7) the paths agree with each other at full size on the structured PCs (the i8 paths are the same integers)
+    _FULL[(prec, store)] = (ev, sc[:, :2].copy(), ld[:, :2].astype(np.float64))
+    if ("i8", "int8") in _FULL and (prec, store) != ("i8", "int8"):
+        ev0, sc0, ld0 = _FULL[("i8", "int8")]
+        tol = 1e-8 if prec == "i8" else 1e-5
+        assert np.max(np.abs(ev[:2] - ev0[:2]) / ev0[:2]) < tol
+        assert oracle.max_abs_dpc(sc[:, :2], sc0) < tol and oracle.max_abs_dpc(ld[:, :2].astype(np.float64), ld0) < 10 * tol
+
+
+@pytest.mark.parametrize("M,N", [(200_000, 100_000)])
+def test_c4_shape_class_i8_and_2bit(gpca, oracle, M, N):
+    """BASELINE.json configs[3]'s per-GPU shape class (100k samples) with enough rows for full LDS-DMA rounds: 20 GB of
+    int8 genotypes.  No oracle at this size: property checks, bitwise repeat, and int8-resident == 2-bit-resident (the
+    same exact integers), plus spot rows of the loadings against a direct f64 evaluation from the oracle's bytes."""
+    from genomic_pca_amd import _lib
+    k, seed = 20, 5
+    th = gpca.synth_thresholds(M, 3, seed=seed)
+    res = {}
+    for store in ("int8", "2bit"):
+        with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8) as e:
+            e.synth_genotypes(M, N, seed, th)
+            st = e.snp_stats(gpca.QcConfig.none())
+            e.rsvd(k, 10, 2, seed=seed)
+            sc = e.scores(f64=True); ev = e.eigenvalues(); sv = e.singular_values(); ld = e.loadings()
+            e.rsvd(k, 10, 2, seed=seed)
+            assert np.array_equal(e.eigenvalues(), ev) and np.array_equal(e.scores(f64=True), sc) and np.array_equal(e.loadings(), ld)
+            gram = sc.T @ sc
+            assert np.allclose(np.diag(gram), sv[:k] ** 2, rtol=1e-6)
+            assert np.max(np.abs(gram - np.diag(np.diag(gram)))) < 1e-6 * sv[0] ** 2
+            lg = ld.astype(np.float64).T @ ld.astype(np.float64)
+            assert np.max(np.abs(lg - np.eye(k))) < 1e-4
+            assert np.max(np.abs(sc.sum(axis=0))) < 1e-6 * np.abs(sc).sum(axis=0).max()
+            assert ev[1] > 20 * ev[2]
+            V = sc[:, :2] / sv[:2]
+            for i in (0, 77_777, M - 1):
+                g_row = oracle.synth_genotypes(1, N, seed, th[i:i + 1], snp_offset=int(i)).astype(np.float64)[0]
+                a_i = (g_row - float(st["mu"][i])) / float(st["sigma"][i])
+                assert np.max(np.abs(a_i @ V / sv[:2] - ld[i, :2].astype(np.float64))) < 1e-5
+            tr = e.transform()
+            assert oracle.max_abs_dpc(tr[:, :2], sc[:, :2]) < 1e-4
+            res[store] = (ev, sc, ld)
+    assert np.max(np.abs(res["int8"][0] - res["2bit"][0]) / res["int8"][0]) < 1e-8
+    assert oracle.max_abs_dpc(res["int8"][1][:, :2], res["2bit"][1][:, :2]) < 1e-8
 
 
 # ------------------------------------------------------------------------------------------------
@@ -461,14 +528,14 @@ def test_i8_matches_f32_and_is_partition_independent(gpca, oracle, engine, engin
     assert np.max(np.abs(out["i8"][0] - out["f32"][0]) / out["f32"][0]) < 1e-5
     assert oracle.max_abs_dpc(out["i8"][1], out["f32"][1]) < 1e-5
     assert oracle.max_abs_dpc(out["i8"][2], out["f32"][2]) < 1e-5
-    # the integer GEMM partial sums are exact, so a different grid partition changes only the f32 partials of the
-    # centring term c = b^T T: results agree to ~1e-9 (the f32 path moves at ~1e-7)
+    # the integer GEMM partial sums are exact and the centring term c = b^T T is summed per 32-row unit in a fixed order, so a
+    # different grid partition returns the same bits
     from genomic_pca_amd import _lib
     monkeypatch.setenv("GPCA_GQ_WAVES", "64"); monkeypatch.setenv("GPCA_GTT_WAVES", "96")
     with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e2:
         e2.upload_genotypes_i8(G); e2.snp_stats(); e2.rsvd(6, 10, 2, seed=3)
-        assert np.max(np.abs(e2.eigenvalues() - out["i8"][0]) / out["i8"][0]) < 1e-8
-        assert oracle.max_abs_dpc(e2.scores(f64=True), out["i8"][1]) < 1e-8
+        assert np.array_equal(e2.eigenvalues(), out["i8"][0])
+        assert np.array_equal(e2.scores(f64=True), out["i8"][1])
 
 
 @pytest.mark.parametrize("store,planes", [("int8", 0), ("2bit", 0), ("2bit", 3)])
@@ -658,7 +725,10 @@ def test_rsvd_bitwise_repeatable(gpca, prec, store, M, N, k):
 # the alternative kernels behind the diagnostic switches stay correct ("Diagnostic switches")
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env", [{"GPCA_GQ_DMA": "0"}, {"GPCA_GTT_DMA": "0"}, {"GPCA_GQ_DMA": "0", "GPCA_GTT_DMA": "0"},
-                                 {"GPCA_LDS_PLANES": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GTT_WAVES": "64"}])
+                                 {"GPCA_LDS_PLANES": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GTT_WAVES": "64"},
+                                 {"GPCA_GQ_SLOTS": "7", "GPCA_GQ_WAVES": "8"}, {"GPCA_GTT_XCD": "0"}, {"GPCA_GQ_DMA_NT": "0"},
+                                 {"GPCA_GQ_DMA": "0", "GPCA_GQ_R": "2"}, {"GPCA_LDS_PLANES": "0", "GPCA_STREAM_NT": "1"},
+                                 {"GPCA_GTT_DMA": "0", "GPCA_GTTX_XCD": "1"}])
 def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     """Register-staged (k_gq_x / k_gtt_x) and per-wave-plane (k_gq_i8 / k_gtt_i8) kernels, and a tiny grid that forces
     full LDS-DMA rounds on a small matrix, against the default configuration: the integer products are exact, so only

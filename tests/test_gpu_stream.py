@@ -1,0 +1,383 @@
+"""GPU tests of the rows either side of the resident hot path (through the C ABI):
+
+* panel sources and out-of-core streaming (BASELINE.json configs[4]; the reference's strip pull loop, main.rs:322,584,
+  prepare.rs:1839-2022): a streamed run must return the SAME BITS as the resident engine on a matrix that fits;
+* rank-agreed status of row-sharded runs (a failing shard must not leave its peers inside a collective);
+* boundary hardening: chunked .bed upload, shared handle, bounded timings, per-device LDS opt-in, ld_blocks.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LUT_A1 = np.array([2, -127, 1, 0], np.int8)          # count_a1: 00->2, 01->missing, 10->1, 11->0 (prepare.rs:622-629)
+
+
+def _modes(store):
+    from genomic_pca_amd import _lib
+    return dict(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8)
+
+
+def _encode_bed(G):
+    """int8 dosages (count of A1; -127 missing) -> PLINK .bed rows."""
+    code = np.full(G.shape, 1, np.uint8)              # 01 = missing
+    code[G == 2] = 0; code[G == 1] = 2; code[G == 0] = 3
+    M, N = G.shape
+    pad = np.zeros((M, (-N) % 4), np.uint8)
+    c = np.concatenate([code, pad], axis=1).reshape(M, -1, 4)
+    return (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# generators
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("store", ["int8", "2bit"])
+@pytest.mark.parametrize("M,N,P", [(1000, 333, 3), (257, 1025, 5), (64, 2100, 2), (3, 7, 2)])
+def test_synth16_bit_exact(gpca, oracle, store, M, N, P):
+    th16 = gpca.synth_thresholds16(M, P, seed=42, snp_offset=5)
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.load_from_source(gpca.PanelSource.synth16(th16, 42, snp_offset=5), M, N)
+        assert np.array_equal(e.download_genotypes_i8(), oracle.synth16_genotypes(M, N, 42, th16, snp_offset=5))
+
+
+def test_synth16_hardy_weinberg_proportions(gpca, oracle):
+    """g = (u < t1) + (u < t2): P(g = 2) = p^2, P(g >= 1) = 1 - (1-p)^2 -> mean dosage 2p per population."""
+    M, N, P = 64, 30000, 3
+    th16 = gpca.synth_thresholds16(M, P, seed=3)
+    G = oracle.synth16_genotypes(M, N, 9, th16)
+    t2 = (th16 & 0xffff) / 65536.0; t1 = (th16 >> 16) / 65536.0
+    for c in range(P):
+        sub = G[:, c::P]
+        assert np.max(np.abs((sub == 2).mean(axis=1) - t2[:, c])) < 0.02
+        assert np.max(np.abs((sub >= 1).mean(axis=1) - t1[:, c])) < 0.02
+
+
+# ------------------------------------------------------------------------------------------------
+# resident load through every source kind == plain upload
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("store", ["int8", "2bit"])
+def test_load_from_host_sources(gpca, oracle, store):
+    M, N = 3000, 517
+    G = oracle.synth_genotypes(M, N, 3, gpca.synth_thresholds(M, 3, seed=3, fst=0.1))
+    G[np.random.default_rng(0).random(G.shape) < 0.01] = -127
+    calls = []
+
+    def rows_i8(row0, rows):
+        calls.append((row0, rows))
+        return G[row0:row0 + rows]
+    bed = _encode_bed(G)
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.load_from_source(gpca.PanelSource.host_i8(rows_i8), M, N)
+        assert np.array_equal(e.download_genotypes_i8(), G)
+        assert calls and calls[0][0] == 0 and sum(r for _, r in calls) == M
+        e.load_from_source(gpca.PanelSource.host_bed(lambda r0, r: bed[r0:r0 + r]), M, N)
+        assert np.array_equal(e.download_genotypes_i8(), G)
+        with pytest.raises(ValueError):                                    # a callback that returns the wrong shape fails loudly
+            e.load_from_source(gpca.PanelSource.host_i8(lambda r0, r: G[:1]), M, N)
+        with pytest.raises(RuntimeError, match="boom"):                    # ... and an exception inside it reaches the caller
+            def bad(r0, r):
+                raise RuntimeError("boom")
+            e.load_from_source(gpca.PanelSource.host_i8(bad), M, N)
+
+
+def test_bed_upload_is_chunked(gpca, oracle):
+    """A .bed payload larger than the 256 MiB staging buffer goes up in several chunks (no second full-size device copy):
+    600 000 SNPs x 2 000 samples = 300 MB of .bed bytes; decode checked on rows either side of the chunk boundary."""
+    M, N = 600_000, 2000
+    bpr = N // 4
+    rng = np.random.default_rng(1)
+    blk = rng.integers(0, 256, size=(4096, bpr), dtype=np.uint8)
+    bed = np.tile(blk, (M // 4096 + 1, 1))[:M]
+    bed[::4096, 0] = (np.arange(0, M, 4096) // 4096 % 251).astype(np.uint8)   # make the tiles distinguishable
+    boundary = (256 << 20) // bpr
+    probe = np.array([0, 1, boundary - 1, boundary, boundary + 1, M - 1])
+    for store in ("int8", "2bit"):
+        with gpca.GpcaEngine(**_modes(store)) as e:
+            e.upload_bed2bit(bed, N)
+            st = e.snp_stats(gpca.QcConfig.none())
+            counts, _ = e.snp_qc_detail()
+            for i in probe:
+                dec = np.empty(bpr * 4, np.int8)
+                for s in range(4):
+                    dec[s::4] = LUT_A1[(bed[i] >> (2 * s)) & 3]
+                o = oracle.snp_stats(dec[None, :N], N, 0.0, 0.0, 1.0)
+                assert np.array_equal(counts[i], o["counts"][0]) and st["mu"][i] == o["mu"][0]
+
+
+# ------------------------------------------------------------------------------------------------
+# streamed panels == resident, bit for bit
+# ------------------------------------------------------------------------------------------------
+def _run(e, k, seed, qc=None):
+    st = e.snp_stats(qc)
+    counts, reason = e.snp_qc_detail()
+    e.rsvd(k, 10, 2, seed=seed)
+    return dict(mu=st["mu"], sigma=st["sigma"], keep=st["keep"], counts=counts, reason=reason, ev=e.eigenvalues(),
+                sv=e.singular_values(), sc=e.scores(f64=True), sc32=e.scores(), ld=e.loadings(), tr=e.transform())
+
+
+def _same(a, b):
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("store", ["int8", "2bit"])
+@pytest.mark.parametrize("kind", ["synth", "synth16", "host_i8", "host_bed"])
+def test_streamed_equals_resident_bitwise(gpca, oracle, store, kind):
+    """5 panels (the last one short and not a multiple of 128 rows), ring of 2: QC statistics, eigenvalues, scores, loadings
+    and PCA::transform of the streamed run are the resident run's bits; and the resident run holds the oracle's parity bar."""
+    M, N, P, k, seed = 20_000, 1000, 16, 10, 1
+    th = gpca.synth_thresholds(M, P, seed=seed, fst=0.2)
+    th16 = gpca.synth_thresholds16(M, P, seed=seed, fst=0.2)
+    G = oracle.synth16_genotypes(M, N, seed, th16) if kind == "synth16" else oracle.synth_genotypes(M, N, seed, th)
+    bed = _encode_bed(G)
+    src = {"synth": lambda: gpca.PanelSource.synth(th, seed), "synth16": lambda: gpca.PanelSource.synth16(th16, seed),
+           "host_i8": lambda: gpca.PanelSource.host_i8(lambda r0, r: G[r0:r0 + r]),
+           "host_bed": lambda: gpca.PanelSource.host_bed(lambda r0, r: bed[r0:r0 + r])}[kind]
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.load_from_source(src(), M, N)
+        assert np.array_equal(e.download_genotypes_i8(), G)
+        res = _run(e, k, seed, gpca.QcConfig())
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.stream_open(src(), M, N, panel_rows=4096, ring_slots=2)
+        assert e.dims() == (M, N)
+        stm = _run(e, k, seed, gpca.QcConfig())
+        with pytest.raises(gpca.GpcaError) as err:                 # the pull API needs resident rows
+            e.standardize_block([0], [0])
+        assert err.value.status == -7
+        with pytest.raises(gpca.GpcaError):
+            e.download_genotypes_i8()
+    _same(res, stm)
+    ref = oracle.snp_stats(G, N, 0.98, 0.01, 1e-6)
+    r, b = oracle.scale_shift(ref["mu"], ref["sigma"], ref["keep"])
+    R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=seed)
+    assert np.array_equal(stm["keep"], ref["keep"]) and np.array_equal(stm["counts"], ref["counts"])
+    assert np.max(np.abs(stm["ev"] - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
+    assert oracle.max_abs_dpc(stm["sc"], R["scores"]) < 1e-4
+    assert oracle.max_abs_dpc(stm["ld"].astype(np.float64), R["loadings"][ref["keep"].astype(bool)]) < 1e-4
+
+
+@pytest.mark.parametrize("store,planes", [("int8", 0), ("2bit", 0), ("2bit", 3)])
+def test_streamed_wide_sketch_k40(gpca, oracle, store, planes):
+    """BASELINE.json configs[4]'s sketch width: k = 40 -> l = 50 -> two 32-column halves per panel; ring of 3."""
+    from genomic_pca_amd import _lib
+    M, N, k, seed = 9000, 700, 40, 3
+    th = gpca.synth_thresholds(M, 48, seed=seed, fst=0.3)
+    kw = dict(_modes(store), digit_planes=planes)
+    with gpca.GpcaEngine(**kw) as e:
+        e.synth_genotypes(M, N, seed, th)
+        res = _run(e, k, seed)
+    with gpca.GpcaEngine(**kw) as e:
+        e.stream_open(gpca.PanelSource.synth(th, seed), M, N, panel_rows=2048, ring_slots=3)
+        stm = _run(e, k, seed)
+    _same(res, stm)
+
+
+@pytest.mark.parametrize("store", ["int8", "2bit"])
+def test_streamed_full_dma_rounds(gpca, store):
+    """Panels large enough that every K1 workgroup runs full LDS-DMA rounds (300 000 x 2 048 in 5 panels of 65 536 rows)."""
+    M, N, k, seed = 300_000, 2048, 20, 7
+    th16 = gpca.synth_thresholds16(M, 3, seed=seed)
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.load_from_source(gpca.PanelSource.synth16(th16, seed), M, N)
+        res = _run(e, k, seed)
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.stream_open(gpca.PanelSource.synth16(th16, seed), M, N, panel_rows=65536, ring_slots=3)
+        stm = _run(e, k, seed)
+        again = _run(e, k, seed)                               # a second pass over the same stream: same bits
+    _same(res, stm); _same(stm, again)
+
+
+def test_stream_open_argument_errors(gpca):
+    from genomic_pca_amd import _lib
+    th = gpca.synth_thresholds(256, 3, seed=1)
+    with gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA) as e:
+        with pytest.raises(gpca.GpcaError):                     # integer partial sums are what make panel order irrelevant
+            e.stream_open(gpca.PanelSource.synth(th, 1), 256, 64)
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        with pytest.raises(gpca.GpcaError):
+            e.stream_open(gpca.PanelSource.synth(th, 1), 256, 64, ring_slots=1)
+        with pytest.raises(ValueError):
+            e.stream_open(gpca.PanelSource.synth(th, 1), 300, 64)          # table shorter than M
+        e.stream_open(gpca.PanelSource.synth(th, 1), 256, 64)              # panel_rows = 0 -> one ~1 GiB panel
+        e.snp_stats(); e.rsvd(2, 4, 1, 1)
+        e.upload_genotypes_i8(np.ones((4, 4), np.int8))                    # a resident upload closes the stream
+        assert e.dims() == (4, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# row-sharded runs fail together
+# ------------------------------------------------------------------------------------------------
+def _two_shard_run(gpca, G, poison, k=4):
+    """Two engines on one GPU, each a row shard, exchanging through a host hook (threads)."""
+    M, N = G.shape
+    world = 2
+    spans = [gpca.shard_rows(M, world, r) for r in range(world)]
+    barrier = threading.Barrier(world, timeout=60); bufs = [None] * world; out = [None] * world
+
+    def run(rank):
+        a, b_ = spans[rank]
+        e = gpca.GpcaEngine(**_modes("int8"))
+        try:
+            shard = G[a:b_].copy()
+            if poison is not None and poison[0] == rank:
+                shard[poison[1], poison[2]] = poison[3]
+            e.upload_genotypes_i8(shard); e.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0))
+
+            def hook(buf):
+                bufs[rank] = buf.copy(); barrier.wait()
+                buf[:] = sum(bufs[r] for r in range(world)); barrier.wait()
+            e.set_allreduce_hook(hook, world, rank, a)
+            try:
+                e.rsvd(k, 10, 2, seed=5)
+                out[rank] = ("ok", e.eigenvalues())
+            except gpca.GpcaError as err:
+                out[rank] = ("err", err.status, err.message)
+        finally:
+            e.close()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a rank is still inside the call: the shards did not leave together"
+    return out
+
+
+def test_sharded_ranks_fail_together(gpca, oracle):
+    M, N = 4000, 384
+    G = oracle.synth_genotypes(M, N, 31, gpca.synth_thresholds(M, 8, seed=31, fst=0.3))
+    ok = _two_shard_run(gpca, G, None)
+    assert ok[0][0] == "ok" and ok[1][0] == "ok" and np.array_equal(ok[0][1], ok[1][1])
+    # shard 1 holds a missing genotype in a kept SNP: BOTH ranks return -5, nobody hangs
+    out = _two_shard_run(gpca, G, (1, 17, 5, -127))
+    assert out[0][0] == "err" and out[1][0] == "err" and out[0][1] == -5 and out[1][1] == -5
+    assert "1 of 2 rank(s)" in out[0][2] and "missing genotype" in out[0][2]           # the clean rank says who failed
+    assert "Unexpected missing genotype" in out[1][2]                                   # the failing rank keeps its own message
+    # an invalid dosage on shard 0: -9 everywhere
+    out = _two_shard_run(gpca, G, (0, 3, 9, 7))
+    assert [o[1] for o in out] == [-9, -9]
+
+
+def _proc_worker(rank, world, port, M, N, k, seed, out_dir, poison_rank):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import genomic_pca_amd as g
+    from genomic_pca_amd import _lib
+    from genomic_pca_amd.distributed import shard_rows, torch_allreduce_hook
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b_ = shard_rows(M, world, rank)
+    th = g.synth_thresholds(b_ - a, 8, seed=seed, fst=0.3, snp_offset=a)
+    with g.GpcaEngine(device=0, precision=_lib.PREC_I8_EXACT) as e:
+        e.synth_genotypes(b_ - a, N, seed, th, snp_offset=a)
+        if rank == poison_rank:
+            G = e.download_genotypes_i8(); G[11, 3] = -127; e.upload_genotypes_i8(G)
+        e.snp_stats(g.QcConfig(0.5, 0.0, 1.0))
+        e.set_allreduce_hook(torch_allreduce_hook(), world, rank, a)
+        try:
+            e.rsvd(k, 10, 2, seed=seed)
+            np.savez(os.path.join(out_dir, f"rank{rank}.npz"), status=0, ev=e.eigenvalues(), sc=e.scores(f64=True), ld=e.loadings())
+        except g.GpcaError as err:
+            np.savez(os.path.join(out_dir, f"rank{rank}.npz"), status=err.status)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("poison_rank", [-1, 1])
+def test_two_process_shards_through_libgpca(tmp_path, gpca, oracle, poison_rank):
+    """Two PROCESSES, each driving libgpca.so on its row shard (both on GPU 0), exchanging through gloo via
+    gpca_set_allreduce_hook: equals the unsharded engine; with one poisoned shard both processes return -5."""
+    import torch.multiprocessing as mp
+    M, N, k, seed, world = 6000, 512, 6, 23, 2
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_proc_worker, args=(world, port, M, N, k, seed, str(tmp_path), poison_rank), nprocs=world, join=True)
+    z = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(world)]
+    if poison_rank >= 0:
+        assert int(z[0]["status"]) == -5 and int(z[1]["status"]) == -5
+        return
+    assert int(z[0]["status"]) == 0 and int(z[1]["status"]) == 0
+    assert np.array_equal(z[0]["ev"], z[1]["ev"]) and np.array_equal(z[0]["sc"], z[1]["sc"])
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        e.synth_genotypes(M, N, seed, gpca.synth_thresholds(M, 8, seed=seed, fst=0.3))
+        e.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0)); e.rsvd(k, 10, 2, seed=seed)
+        assert np.max(np.abs(z[0]["ev"] - e.eigenvalues()) / e.eigenvalues()) < 1e-10
+        assert oracle.max_abs_dpc(z[0]["sc"], e.scores(f64=True)) < 1e-9
+        ld = np.concatenate([z[0]["ld"], z[1]["ld"]], axis=0).astype(np.float64)
+        assert oracle.max_abs_dpc(ld, e.loadings().astype(np.float64)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# boundary hardening
+# ------------------------------------------------------------------------------------------------
+def test_handle_shared_between_threads(gpca, oracle):
+    """The reference's accessor is Clone + Send + Sync and is called from rayon workers (prepare.rs:1770-1779, 1838):
+    eight threads pull blocks through ONE handle concurrently; every block is bit-exact."""
+    M, N = 4000, 700
+    G = oracle.synth_genotypes(M, N, 9, gpca.synth_thresholds(M, 3, seed=9, fst=0.1))
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        e.upload_genotypes_i8(G)
+        st = e.snp_stats(gpca.QcConfig(0.0, 0.05, 1.0))
+        rows = e.pca_snp_rows()
+        acc = gpca.MicroarrayGenotypeAccessor(e)
+        errs = []
+
+        def worker(t):
+            rng = np.random.default_rng(t)
+            try:
+                for _ in range(25):
+                    sid = rng.permutation(len(rows))[:rng.integers(1, 300)]
+                    cid = rng.permutation(N)[:rng.integers(1, 200)]
+                    out = acc.get_standardized_snp_sample_block(sid, cid)
+                    ref, err = oracle.standardize_block(G, st["mu"], st["sigma"], rows[sid], cid)
+                    assert err is None and np.array_equal(out, ref)
+            except BaseException as ex:  # noqa: BLE001
+                errs.append(ex)
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert not errs, errs[0]
+
+
+def test_timings_are_bounded(gpca, oracle):
+    """More pending records than the cap: they are folded into per-name totals, launch counts stay exact."""
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        e.synth_genotypes(2048, 256, 1, gpca.synth_thresholds(2048, 3, seed=1))
+        e.snp_stats(); e.enable_timings(True); e.reset_timings()
+        calls = 7000                                           # 5 records per call (omega, 2 x K2, 2 x K1) -> 35 000 > 32 768
+        for _ in range(calls):
+            e.rsvd(2, 2, 1, seed=1)
+        t = e.timings()
+        assert t["gemm_GQ"]["launches"] == 2 * calls and t["gemm_GtT"]["launches"] == 2 * calls and t["omega"]["launches"] == calls
+
+
+def test_compute_pca_honours_ld_blocks(gpca, oracle):
+    """compute_pca(&accessor, &[LdBlockSpecification]) (main.rs:359-365): SNPs outside every block leave the PCA."""
+    M, N, k = 3000, 256, 5
+    G = oracle.synth_genotypes(M, N, 21, gpca.synth_thresholds(M, 8, seed=21, fst=0.3))
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        e.upload_genotypes_i8(G)
+        e.snp_stats(gpca.QcConfig())
+        acc = gpca.MicroarrayGenotypeAccessor(e)
+        n_pca = acc.num_pca_snps()
+        rows = acc.original_indices_of_pca_snps()
+        ids_a = list(range(0, n_pca // 3)); ids_b = list(range(n_pca // 2, n_pca - 7))
+        blocks = [gpca.LdBlockSpecification("b:2", ids_b), gpca.LdBlockSpecification("a:1", ids_a)]
+        cfg = gpca.EigenSNPCoreAlgorithmConfig(target_num_global_pcs=k, collect_diagnostics=True)
+        out, diag = gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, blocks)
+        used = np.array(sorted(ids_a + ids_b))
+        assert out.num_pca_snps_used == len(used) and out.final_snp_principal_component_loadings.shape == (len(used), k)
+        assert diag["num_ld_blocks"] == 2 and np.array_equal(diag["pca_snp_ids_used"], used)
+        assert acc.num_pca_snps() == n_pca and np.array_equal(acc.original_indices_of_pca_snps(), rows)   # accessor untouched
+        ref = oracle.snp_stats(G, N, 0.98, 0.01, 1e-6)
+        keep = np.zeros(M, np.uint8); keep[rows[used]] = 1
+        r, b = oracle.scale_shift(ref["mu"], ref["sigma"], keep)
+        R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=2025)
+        assert oracle.max_abs_dpc(out.final_sample_principal_component_scores.astype(np.float64), R["scores"]) < 1e-4
+        assert oracle.max_abs_dpc(out.final_snp_principal_component_loadings.astype(np.float64), R["loadings"][rows[used]]) < 1e-4
+        assert np.max(np.abs(out.final_principal_component_eigenvalues - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
+        with pytest.raises(ValueError):
+            gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, [gpca.LdBlockSpecification("x", [n_pca])])
+        with pytest.raises(ValueError):
+            gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, [])

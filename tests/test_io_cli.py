@@ -155,3 +155,97 @@ def test_cli_vcf_workflow(tmp_path, gpca, oracle):
     ref = oracle.standardized_dense(Gk, N, r, b).T @ R["loadings"]
     sc = np.array([[float(x) for x in rw[1:]] for rw in rows])
     assert oracle.max_abs_dpc(sc, ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] on its own data: the reference's data/chr22_subset50 PLINK set through --eigensnp
+# ------------------------------------------------------------------------------------------------
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _chr22_fileset(tmp_path):
+    """120 000 consecutive SNPs of the reference's data/chr22_subset50.bed with its own .fam ids; the .bim is synthesised
+    (chromosome 22, increasing positions) because data/chr22_subset50.bim.zip is missing from the reference checkout."""
+    z = np.load(os.path.join(GOLD, "chr22_subset50_120k.npz"))
+    rows = z["bed_rows"]; n = int(z["n_samples"]); M = rows.shape[0]
+    pre = str(tmp_path / "chr22_subset50")
+    with open(pre + ".bed", "wb") as f:
+        f.write(b"\x6c\x1b\x01"); f.write(rows.tobytes())
+    with open(pre + ".fam", "w") as f:
+        for fid, iid in zip(z["fids"], z["iids"]):
+            f.write(f"{fid} {iid} 0 0 0 -9\n")
+    pos = 16_050_000 + 25 * np.arange(M)
+    with open(pre + ".bim", "w") as f:
+        for i in range(M):
+            f.write(f"22\t22:{pos[i]}\t0\t{pos[i]}\tA\tG\n")
+    lut = np.array([2, -127, 1, 0], np.int8)
+    G = np.empty((M, rows.shape[1] * 4), np.int8)
+    for s in range(4):
+        G[:, s::4] = lut[(rows >> (2 * s)) & 3]
+    return pre, z, G[:, :n], pos
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("storage", ["int8", "2bit"])
+def test_cli_config3_chr22_subset50(tmp_path, gpca, oracle, storage):
+    """`genomic_pca --eigensnp --bed-file data/chr22_subset50.bed --ld-block-file <one genome-wide block> --eigensnp-k-global 20`
+    (README.md:106-115 usage; main.rs:250-442) on real genotypes, N = 64 samples: QC decisions, eigenvalues, scores and
+    loadings against the oracle (same seed) and the committed fixture, for both residencies."""
+    from genomic_pca_amd.cli import main
+    pre, z, G, pos = _chr22_fileset(tmp_path)
+    n = G.shape[1]
+    ld = tmp_path / "ld.txt"
+    ld.write_text("22 1 500000000\n")
+    out = str(tmp_path / "res" / storage)
+    assert main(["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--eigensnp-k-global", "20", "--out", out,
+                 "--gpca-storage", storage]) == 0
+    hdr, rows = _read_tsv(out + ".eigensnp.pca.tsv")
+    assert hdr == ["SampleID"] + [f"PC{i}" for i in range(1, 21)] and [r[0] for r in rows] == [str(x) for x in z["iids"]]
+    _, erows = _read_tsv(out + ".eigenvalues.tsv")
+    _, lrows = _read_tsv(out + ".eigensnp.loadings.tsv")
+    keep = z["keep"].astype(bool)                                   # QC with clap's effective defaults (main.rs:545-560)
+    assert [r[0] for r in lrows] == [f"22:{p}" for p in pos[keep]]   # the PCA SNP set = the oracle's QC decisions
+    st = oracle.snp_stats(G, n, 0.98, 0.01, 1e-6)
+    assert np.array_equal(st["keep"], z["keep"])
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, n, r, b, 20, 10, 2, seed=2025)                # --eigensnp-seed default (main.rs:580)
+    ev = np.array([float(rw[1]) for rw in erows])
+    assert np.max(np.abs(ev - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
+    assert np.allclose(ev, z["eigenvalues"], rtol=1e-4)             # ... and the committed numbers
+    sc = np.array([[float(x) for x in rw[1:]] for rw in rows])
+    al = oracle.sign_align(sc, R["scores"])
+    assert np.max(np.abs(al - R["scores"])) < 2e-6 + 1e-4 * np.max(np.abs(R["scores"]))    # 6-decimal TSV rounding
+    ldv = np.array([[float(x) for x in rw[3:]] for rw in lrows])
+    assert np.max(np.abs(oracle.sign_align(ldv, R["loadings"][keep]) - R["loadings"][keep])) < 2e-6 + 1e-4
+    # the converged answer (exact PCA, tests/pca.py:81-141 pattern): N = 64 gives a flat noise spectrum, so only the leading
+    # PCs of the randomized PCA have converged at q = 2
+    E = oracle.exact_pca(G, n, r, b, 20)
+    assert abs(ev[0] - E["eigenvalues"][0]) / E["eigenvalues"][0] < 0.02
+
+
+@pytest.mark.gpu
+def test_engine_config3_full_precision(gpca, oracle):
+    """The same data through the C ABI without the TSV rounding: unit-norm sign-aligned PCs within 1e-4 of the oracle on all
+    three GEMM paths (N = 64 is padded to 256 / 1024 samples by the kernels' tiles)."""
+    from genomic_pca_amd import _lib
+    z = np.load(os.path.join(GOLD, "chr22_subset50_120k.npz"))
+    rows = z["bed_rows"]; n = int(z["n_samples"])
+    lut = np.array([2, -127, 1, 0], np.int8)
+    G = np.empty((rows.shape[0], rows.shape[1] * 4), np.int8)
+    for s in range(4):
+        G[:, s::4] = lut[(rows >> (2 * s)) & 3]
+    G = G[:, :n]
+    st = oracle.snp_stats(G, n, 0.98, 0.01, 1e-6)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, n, r, b, 20, 10, 2, seed=2025)
+    kept = st["keep"].astype(bool)
+    for prec, store in ((_lib.PREC_I8_EXACT, _lib.STORE_INT8), (_lib.PREC_I8_EXACT, _lib.STORE_2BIT), (_lib.PREC_F32_MFMA, _lib.STORE_INT8)):
+        with gpca.GpcaEngine(precision=prec, storage=store) as e:
+            e.upload_bed2bit(rows, n)
+            s2 = e.snp_stats(gpca.QcConfig())
+            _, reason = e.snp_qc_detail()
+            assert np.array_equal(s2["keep"], z["keep"]) and np.array_equal(reason, z["reason"]) and np.array_equal(s2["mu"], z["mu"])
+            e.rsvd(20, 10, 2, seed=2025)
+            assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
+            assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < 1e-4
+            assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"][kept]) < 1e-4

@@ -115,6 +115,100 @@ def test_rsvd_converges_to_exact_pca(oracle, gpca):
     assert np.max(np.abs(R32["eigenvalues"] - R["eigenvalues"]) / R["eigenvalues"]) < 1e-5
 
 
+def _structured_case(oracle, gpca, M=5000, N=400, P=6, seed=13):
+    th = gpca.synth_thresholds(M, P, seed=seed, fst=0.3)
+    G = oracle.synth_genotypes(M, N, seed, th)
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    return G, N, r, b, P - 1          # P populations -> P - 1 structured PCs with clean gaps
+
+
+def test_checker_shares_no_small_dense_code_with_the_port(oracle, gpca):
+    """oracle.rsvd (LAPACK Householder QR + gesdd) against oracle.rsvd_port (the product's recipe: CholeskyQR2 + cyclic
+    Jacobi, restated in C): same sketch, same products, independent factorisations -> agreement at rounding level.  A defect
+    in the transcribed Jacobi / Cholesky would show up here instead of cancelling in the GPU parity tests."""
+    G, N, r, b, ks = _structured_case(oracle, gpca)
+    for k, ov, q in ((8, 10, 2), (5, 0, 0), (1, 3, 1), (20, 10, 2)):
+        A = oracle.rsvd(G, N, r, b, k, ov, q, seed=3)
+        Pt = oracle.rsvd_port(G, N, r, b, k, ov, q, seed=3)
+        assert np.max(np.abs(A["eigenvalues"] - Pt["eigenvalues"]) / Pt["eigenvalues"]) < 1e-11
+        assert np.max(np.abs(A["singular_values"] - Pt["singular_values"]) / Pt["singular_values"][0]) < 1e-11
+        kk = min(k, ks)               # the structured PCs are well conditioned; noise PCs are compared through the subspace below
+        assert oracle.max_abs_dpc(A["scores"][:, :kk], Pt["scores"][:, :kk]) < 1e-9
+        assert oracle.max_abs_dpc(A["loadings"][:, :kk], Pt["loadings"][:, :kk]) < 1e-9
+        PA = A["scores"] @ np.linalg.pinv(A["scores"]); PP = Pt["scores"] @ np.linalg.pinv(Pt["scores"])
+        assert np.max(np.abs(PA - PP)) < 1e-8                                # same k-dimensional score subspace
+
+
+def test_checker_against_scipy_svd_of_the_dense_matrix(oracle, gpca):
+    """exact SVD (scipy.linalg.svd -> LAPACK gesdd) of the dense standardised matrix X = A^T.
+    With q = 2 the structured PCs of the randomized PCA have converged to it; the noise PCs agree as a subspace bound."""
+    import scipy.linalg
+    G, N, r, b, ks = _structured_case(oracle, gpca)
+    A = oracle.standardized_dense(G, N, r, b)                                 # M x N
+    U, s, Vt = scipy.linalg.svd(A.T, full_matrices=False)                     # X = U diag(s) Vt, U: samples
+    R = oracle.rsvd(G, N, r, b, 10, 10, 2, seed=7)
+    # convergence bounds of q = 2 on this spectrum (measured: eigenvalues 1e-7 .. 5e-6, scores 4e-4, loadings 3e-5): this pins the
+    # ALGORITHM's answer to the exact decomposition; kernel parity (1e-4 against the same-sketch checker) is a different bar
+    assert np.max(np.abs(R["eigenvalues"][:ks] - s[:ks] ** 2 / (N - 1)) / (s[:ks] ** 2 / (N - 1))) < 2e-5
+    assert oracle.max_abs_dpc(R["scores"][:, :ks], U[:, :ks] * s[:ks]) < 2e-3
+    assert oracle.max_abs_dpc(R["loadings"][:, :ks], Vt[:ks].T) < 2e-4
+    # all 10 eigenvalues are bounded by the exact ones (Rayleigh-Ritz) and within 20 % even in the noise bulk
+    ex = s[:10] ** 2 / (N - 1)
+    assert np.all(R["eigenvalues"] <= ex * (1 + 1e-9)) and np.max(np.abs(R["eigenvalues"] - ex) / ex) < 0.2
+    # exact_pca (eigh of the Gram, the reference's tests/pca.py pattern) is the same decomposition
+    E = oracle.exact_pca(G, N, r, b, 10)
+    assert np.allclose(E["eigenvalues"], ex, rtol=1e-9)
+
+
+def test_checker_against_sklearn_randomized_svd(oracle, gpca):
+    """SURVEY.md 8c(3), the independent third opinion: sklearn.utils.extmath.randomized_svd (its own Gaussian sketch, its own
+    LU/QR-normalised power iterations) on the dense standardised matrix, n_iter = 2, same oversampling."""
+    from sklearn.utils.extmath import randomized_svd
+    G, N, r, b, ks = _structured_case(oracle, gpca)
+    X = oracle.standardized_dense(G, N, r, b).T                               # samples x variants
+    U, s, Vt = randomized_svd(X, n_components=10, n_oversamples=10, n_iter=2, power_iteration_normalizer="QR", random_state=0)
+    R = oracle.rsvd(G, N, r, b, 10, 10, 2, seed=7)
+    assert np.max(np.abs(R["eigenvalues"][:ks] - s[:ks] ** 2 / (N - 1)) / R["eigenvalues"][:ks]) < 1e-5
+    assert oracle.max_abs_dpc(R["scores"][:, :ks], U[:, :ks] * s[:ks]) < 2e-3          # (two different sketches, q = 2 each)
+    assert oracle.max_abs_dpc(R["loadings"][:, :ks], Vt[:ks].T) < 1e-3
+    # different sketches -> different noise PCs, but comparable captured variance
+    assert abs(R["eigenvalues"].sum() - (s ** 2).sum() / (N - 1)) / R["eigenvalues"].sum() < 0.02
+
+
+def test_synth16_known_answers(oracle, gpca):
+    """Fast panel generator: field order and threshold halves, by hand from one Philox block."""
+    th = np.array([[(40000 << 16) | 10000, (65535 << 16) | 65535, 0]], np.uint32)          # pop 0: mixed; pop 1: always 2; pop 2: always 0
+    G = oracle.synth16_genotypes(1, 24, 99, th, snp_offset=7)
+    assert np.all(G[0, 1::3] == 2) and np.all(G[0, 2::3] == 0)
+    o = oracle.philox([7, 0, 0, 0x47454E31], [99, 0])                                       # samples 0..7 of SNP 7
+    u0 = int(o[0]) & 0xffff; u3 = (int(o[1]) >> 16) & 0xffff; u6 = int(o[3]) & 0xffff
+    for n, u in ((0, u0), (3, u3), (6, u6)):
+        assert G[0, n] == (u < 40000) + (u < 10000)
+    assert np.array_equal(oracle.synth16_genotypes(3, 50, 5, gpca.synth_thresholds16(3, 2, seed=5, snp_offset=11), snp_offset=11),
+                          oracle.synth16_genotypes(14, 50, 5, gpca.synth_thresholds16(14, 2, seed=5), snp_offset=0)[11:])
+
+
+def test_chr22_fixture_pins_the_checker(oracle):
+    """tests/golden/chr22_subset50_120k.npz: 120 000 SNPs of the reference's own data/chr22_subset50.bed (BASELINE.json
+    configs[2]'s data; 64 samples): the oracle reproduces the QC decisions and randomized-PCA outputs committed with it."""
+    z = np.load(os.path.join(GOLD, "chr22_subset50_120k.npz"))
+    rows = z["bed_rows"]; n = int(z["n_samples"])
+    lut = np.array([2, -127, 1, 0], np.int8)                                  # count_a1 (prepare.rs:622-629)
+    G = np.empty((rows.shape[0], rows.shape[1] * 4), np.int8)
+    for s4 in range(4):
+        G[:, s4::4] = lut[(rows >> (2 * s4)) & 3]
+    G = G[:, :n]
+    st = oracle.snp_stats(G, n, 0.98, 0.01, 1e-6)
+    assert np.array_equal(st["keep"], z["keep"]) and np.array_equal(st["reason"], z["reason"])
+    assert np.array_equal(st["mu"], z["mu"]) and np.array_equal(st["sigma"], z["sigma"])
+    assert 20_000 < int(st["keep"].sum()) < 30_000
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, n, r, b, int(z["k"]), 10, 2, seed=int(z["seed"]))
+    assert np.allclose(R["eigenvalues"], z["eigenvalues"], rtol=1e-9)
+    assert oracle.max_abs_dpc(R["scores"][:, :5], z["scores"][:, :5]) < 1e-7
+
+
 def test_rsvd_shard_invariance(oracle, gpca):
     """A row shard draws the Omega rows and genotypes of its global SNP indices."""
     M, N, P = 512, 64, 3
