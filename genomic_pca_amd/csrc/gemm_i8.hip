@@ -144,9 +144,9 @@ __device__ __forceinline__ void gq8_group(const int8_t* __restrict__ G, int64_t 
             const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
             const float ri = rv[row], bi = bv[row];
             const float gq = (float)(combine_digits(acc[t], e) * qs);
-            const float tv = ri * gq + bi * sj;
-            ct += bi * tv;
-            Tout[row * ldt + c] = scale_out ? ri * tv : tv;
+            const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+            ct = __fmaf_rn(bi, tv, ct);
+            Tout[row * ldt + c] = scale_out ? __fmul_rn(ri, tv) : tv;
         }
         GPCA_STORE_CUNIT(row0 / 32 + t)
     }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ 
     const int64_t stride = Npad * 32;
     double s = 0.0;
     for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
-    Y[(e >> 5) * ldy + j] = cvec[j] + tscale[j] * s;
+    Y[(e >> 5) * ldy + j] = fma(tscale[j], s, cvec[j]);   // one rounding, the same in k_finish_y_i8
 }
 void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
                         const double* tscale, double* Y, int64_t ldy) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_finish_y_i8(const double* __restrict__ 
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= N * 32) return;
     const int j = (int)(e & 31);
-    Y[(e >> 5) * ldy + j] = cvec[j] + tscale[j] * Yint[e];
+    Y[(e >> 5) * ldy + j] = fma(tscale[j], Yint[e], cvec[j]);
 }
 void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first) {
     const int64_t total = N * 32;
@@ -512,9 +512,9 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
             const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
             const float ri = rv[row], bi = bv[row];
             const float gq = (float)(combine_digits<ND == 3 ? 8 : 7>(acc[t], e) * qs);
-            const float tv = ri * gq + bi * sj;
-            ct += bi * tv;
-            const float ov = scale_out ? ri * tv : tv;
+            const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+            ct = __fmaf_rn(bi, tv, ct);
+            const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
             amax = fmaxf(amax, fabsf(ov));
             Tout[row * ldt + c] = ov;
         }
@@ -794,9 +794,9 @@ __device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t 
                 const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const float ri = rv[row], bi = bv[row];
                 const float gq = (float)(combine_digits(acc[t], e) * qs);
-                const float tv = ri * gq + bi * sj;
-                ct += bi * tv;
-                const float ov = scale_out ? ri * tv : tv;
+                const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+                ct = __fmaf_rn(bi, tv, ct);
+                const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
                 amax = fmaxf(amax, fabsf(ov));
                 Tout[row * ldt + c] = ov;
             }
@@ -1033,9 +1033,9 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                 const int64_t row = row0 + 32 * t + rin;
                 const float ri = __shfl(rrow[t], rin), bi = __shfl(brow[t], rin);
                 const float gq = (float)(combine_digits(acc[t], e) * qs);
-                const float tv = ri * gq + bi * sj;
-                ct += bi * tv;
-                const float ov = scale_out ? ri * tv : tv;
+                const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+                ct = __fmaf_rn(bi, tv, ct);
+                const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
                 amax = fmaxf(amax, fabsf(ov));
                 Tout[row * ldt + c] = ov;
             }

@@ -261,6 +261,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     h->storage = cfg ? cfg->storage : GPCA_STORE_INT8;
     if (h->storage != GPCA_STORE_INT8 && h->storage != GPCA_STORE_2BIT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown storage mode"); }
     if (h->precision != GPCA_PREC_F32_MFMA && h->precision != GPCA_PREC_I8_EXACT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown precision mode"); }
+    if (h->storage == GPCA_STORE_2BIT && h->precision != GPCA_PREC_I8_EXACT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: GPCA_STORE_2BIT requires GPCA_PREC_I8_EXACT"); }
     {
         const int dp = cfg ? cfg->digit_planes : 0;
         if (dp != 0 && dp != 3 && dp != 4) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes must be 0, 3 or 4"); }

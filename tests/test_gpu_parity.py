@@ -307,10 +307,10 @@ def test_allreduce_hook_two_shards_one_gpu(gpca, oracle):
     ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])   # replicated results identical
-    # exact integer partial sums and per-unit centring partials: sharding only changes the f64 order in which the two
-    # shards' sketches are added
-    assert np.max(np.abs(res[0][1] - ref_ev) / ref_ev) < 1e-10
-    assert oracle.max_abs_dpc(res[0][0], ref_scores) < 1e-9
+    # each shard quantises its rows of T' against its OWN column maximum (no extra exchange), so the 28-bit fixed-point
+    # rounding differs from the unsharded run at the 1e-9 level; everything else is exact integers
+    assert np.max(np.abs(res[0][1] - ref_ev) / ref_ev) < 5e-8
+    assert oracle.max_abs_dpc(res[0][0], ref_scores) < 1e-7
     ld = np.concatenate([res[0][2], res[1][2]], axis=0)
     assert oracle.max_abs_dpc(ld.astype(np.float64), ref_ld.astype(np.float64)) < 1e-6
 

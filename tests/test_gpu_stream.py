@@ -303,8 +303,9 @@ def test_two_process_shards_through_libgpca(tmp_path, gpca, oracle, poison_rank)
     with gpca.GpcaEngine(**_modes("int8")) as e:
         e.synth_genotypes(M, N, seed, gpca.synth_thresholds(M, 8, seed=seed, fst=0.3))
         e.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0)); e.rsvd(k, 10, 2, seed=seed)
-        assert np.max(np.abs(z[0]["ev"] - e.eigenvalues()) / e.eigenvalues()) < 1e-10
-        assert oracle.max_abs_dpc(z[0]["sc"], e.scores(f64=True)) < 1e-9
+        # (each shard quantises T' against its own column maximum: 1e-9-level differences from the unsharded fixed point)
+        assert np.max(np.abs(z[0]["ev"] - e.eigenvalues()) / e.eigenvalues()) < 5e-8
+        assert oracle.max_abs_dpc(z[0]["sc"], e.scores(f64=True)) < 1e-7
         ld = np.concatenate([z[0]["ld"], z[1]["ld"]], axis=0).astype(np.float64)
         assert oracle.max_abs_dpc(ld, e.loadings().astype(np.float64)) < 1e-6
 
