@@ -97,8 +97,8 @@ def pmc_traffic(kernel):
     scripts/gpu_profile.sh: separate rocprofv3 --pmc runs).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950 wide coalesced reads (calibrated on k_snp_stats: 2 x 5120.1 MB = the 10 240 MB it streams)."""
     import glob
-    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit<4>", "gemm_GtT_2bit": "gpca::k_gtt_p<4>", "gemm_GQ_i8": "gpca::k_gq_d<1, 6>", "gemm_GtT_i8": "gpca::k_gtt_d<1>", "gemm_GQ_f32": "gpca::k_gq_f32<1>",
-           "gemm_GtT_f32": "gpca::k_gtt_f32<1>"}.get(kernel)
+    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit<4>", "gemm_GtT_2bit": "gpca::k_gtt_p<4>", "gemm_GQ_i8": "gpca::k_gq_d<1, 6>", "gemm_GtT_i8": "gpca::k_gtt_d<1>", "gemm_GQ_f32": "gpca::k_gq_f32<1, false>",
+           "gemm_GtT_f32": "gpca::k_gtt_f32<1, false>"}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not key or not files:
         return None, None
@@ -113,6 +113,9 @@ def pmc_traffic(kernel):
     return (2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024.0, os.path.basename(files[-1])
 
 
+DEFAULT_SHAPE = True   # set in main(): the committed PMC traffic figures belong to the default 1M x 10k workload only
+
+
 def roofline_of(timings, precision, steps, storage="int8"):
     gq, gt = timings.get("gemm_GQ"), timings.get("gemm_GtT")
     dom_name, dom = max((("gemm_GQ", gq), ("gemm_GtT", gt)), key=lambda kv: kv[1]["total_ms"] if kv[1] else 0.0)
@@ -123,7 +126,7 @@ def roofline_of(timings, precision, steps, storage="int8"):
               "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
               "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
               "all_kernels_ms_per_step": {n: t["total_ms"] / steps for n, t in timings.items()}}
-    traffic, src = pmc_traffic(common["kernel"])
+    traffic, src = pmc_traffic(common["kernel"]) if DEFAULT_SHAPE else (None, None)
     common["traffic_source"] = (f"profiles/{src}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch, separate rocprofv3 --pmc passes"
                                 if src else None)
     if precision == "i8" and storage == "2bit":
@@ -249,7 +252,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-path", action="store_true", help="skip the extra f32-MFMA measurement")
     ap.add_argument("--storage", default="int8", choices=["int8", "2bit"],
-                    help="HBM residency of the genotypes: int8 = 1 B/genotype (the BASELINE.json configs), 2bit = 0.25 B (exact path only)")
+                    help="HBM residency of the genotypes: int8 = 1 B/genotype (the BASELINE.json configs), 2bit = 0.25 B, decoded in the GEMM prologues")
     ap.add_argument("--digit-planes", type=int, default=0, choices=[0, 3, 4],
                     help="exact path: 4 (default) signed base-128 digit planes, or 3 base-256 planes (24-bit; --storage 2bit only)")
     ap.add_argument("--precision", default="i8", choices=["f32", "i8"],
@@ -257,7 +260,8 @@ def main():
     ap.add_argument("--streamed", action="store_true",
                     help="BASELINE.json configs[4] mode: the matrix is never resident; panels come from the device generator "
                          "(GPCA_PANEL_SYNTH16) through a ring of HBM buffers, one panel ahead of the GEMMs")
-    ap.add_argument("--panel-rows", type=int, default=0, help="--streamed: SNP rows per panel (0 = ~1 GiB panels)")
+    ap.add_argument("--streamed-extra", action="store_true", help="resident run: also time the same shape out-of-core (8 panels)")
+    ap.add_argument("--panel-rows", type=int, default=0, help="--streamed: SNP rows per panel (0 = 131072 rows or what fits)")
     ap.add_argument("--ring", type=int, default=3, help="--streamed: panel buffers in the ring")
     a = ap.parse_args()
 
@@ -281,6 +285,8 @@ def main():
     if a.streamed:
         return streamed_main(a, g, rank, world, local_rank, dist, torch)
     M_local, N, k = a.snps, a.samples, a.components
+    global DEFAULT_SHAPE
+    DEFAULT_SHAPE = (M_local, N, k) == (1_000_000, 10_000, 20)
     l = k + a.oversample
     if a.precision == "i8" and l > 64:
         a.precision = "f32"      # (neither path goes beyond 64 columns; the f32 one gives the clearer error)
@@ -309,7 +315,7 @@ def main():
     t_stats = None
     for prec in order:
         packed = prec in ("i8_2bit", "i8_2bit_3p")
-        store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == "i8") or packed) else g._lib.STORE_INT8
+        store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == a.precision) or packed) else g._lib.STORE_INT8
         planes = 3 if prec == "i8_2bit_3p" else (a.digit_planes if (prec == "i8" and store == g._lib.STORE_2BIT) else 0)
         eng = g.GpcaEngine(device=local_rank, precision=PREC["i8" if packed else prec], storage=store, digit_planes=planes)
         engines[:] = [eng]
@@ -341,7 +347,7 @@ def main():
                                    f"k={k}, l={l}, q={a.power_iters}, seed={a.rfit_seed}, resident in HBM",
                        "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample,
                        "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}", "gemm_path": a.precision,
-                       "residency": a.storage if a.precision == "i8" else "int8"},
+                       "residency": a.storage},
             "roofline": roofline_of(timings, a.precision, a.steps, a.storage),
             "snp_stats_s": t_stats,
             "top_eigenvalues": [float(x) for x in ev[:3]],
@@ -366,8 +372,9 @@ def main():
                 "value": M_total * N / (dt4 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt4 / a.steps * 1e3,
                 "all_kernels_ms_per_step": {n: t["total_ms"] / a.steps for n, t in tim4.items()},
                 "max_rel_d_eigenvalue_vs_default_path": float(np.max(np.abs(ev4 - ev) / ev))}
-        if extras and a.precision == "i8":
-            # the headline matrix shape again, never resident: 8 panels of 131 072 rows regenerated by the device generator on every sweep
+        if a.streamed_extra and a.precision == "i8":
+            # (not in the default run: its panel launches use the same kernels as the headline and would blur the per-kernel
+            #  averages of a rocprofv3 --stats run of this command)  the headline matrix shape again, never resident: 8 panels of 131 072 rows regenerated by the device generator on every sweep
             a2 = argparse.Namespace(**vars(a)); a2.panel_rows = 131072; a2.ring = 3; a2.digit_planes = 0
             dts, tims, evs, _ = streamed_run(g, a2, M_local, N, k, a.storage, local_rank, 0, None, None, steps=min(a.steps, 3), warmup=1)
             out["streamed_panels"] = {"note": "same shape out-of-core (BASELINE.json configs[4] mode at configs[1] size): panels come from the "

@@ -17,7 +17,10 @@
 //   Result: 140 TF (89 % of the 157 TF MFMA-f32 peak) on the padded shape.
 //
 // G is read straight from HBM into registers: each byte feeds exactly one MFMA, so LDS staging would add
-// traffic without reuse.  Rows of G/T are zero-padded to a multiple of 128 and samples to a multiple of 256,
+// traffic without reuse.  Both kernels also run on 2-bit resident genotypes (GPCA_STORE_2BIT, template PACKED): the codes
+// are spread to one byte each in the conversion block (4 shift/mask per 16 samples in K1, a 2-step bit spread per 4 samples
+// in K2) and then take the same fp8 path -- the same f32 FMA chains, so the results equal the int8-resident run bit for bit,
+// at a quarter of the HBM bytes (north_star's 10M SNPs x 100k samples = 250 GB fit one MI355X).  Rows of G/T are zero-padded to a multiple of 128 and samples to a multiple of 256,
 // so the main loops carry no predicates.
 //
 // Blocked layouts (written by the producing kernels, see blocked_* helpers in kernels.h):
@@ -56,14 +59,26 @@ GqPlan gq_plan(int64_t Mpad, int waves_target) {
     return p;
 }
 
-template <int R, int LT>
-struct GqBuf { i32x4 g[R]; i32x4 q0[LT], q1[LT], q2[LT], q3[LT]; };
+// One 128-sample super-chunk of a group's R row tiles.  int8 rows: the four 32-byte pieces of a row's 128-byte line are
+// requested back to back by the same lanes (one L1 miss + three hits); requested one piece per 32-sample chunk -- 8 192
+// MFMA cycles apart -- the lines were evicted from L2 in between and came in again from the fabric (FETCH_SIZE 2.25 x the
+// matrix).  Packed rows (2-bit dosage codes, GPCA_STORE_2BIT): 32 bytes per row per super-chunk, both lane halves load the
+// same 16 bytes (64 samples) and take their own dword.
+template <int R, bool PACKED>
+struct GqG { i32x4 g[PACKED ? 2 : 4][R]; };
+template <int LT>
+struct GqQ { i32x4 q0[LT], q1[LT], q2[LT], q3[LT]; };
 
-template <int R, int LT>
-__device__ __forceinline__ void gq_load(GqBuf<R, LT>& b, __amdgpu_buffer_rsrc_t rg, const uint32_t (&gvo)[R], uint32_t s0,
-                                        __amdgpu_buffer_rsrc_t rq, uint32_t qvo, uint32_t qoff) {
+template <int R, bool PACKED>
+__device__ __forceinline__ void gq_load_g(GqG<R, PACKED>& b, __amdgpu_buffer_rsrc_t rg, const uint32_t (&gvo)[R], uint32_t s0) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) b.g[t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], s0, 0);
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int j = 0; j < (PACKED ? 2 : 4); ++j)
+            b.g[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], PACKED ? (s0 >> 2) + 16u * j : s0 + 32u * j, 0);
+}
+template <int LT>
+__device__ __forceinline__ void gq_load_q(GqQ<LT>& b, __amdgpu_buffer_rsrc_t rq, uint32_t qvo, uint32_t qoff) {
 #pragma unroll
     for (int lt = 0; lt < LT; ++lt) {
         b.q0[lt] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, qoff + lt * 4096, 0);
@@ -73,17 +88,33 @@ __device__ __forceinline__ void gq_load(GqBuf<R, LT>& b, __amdgpu_buffer_rsrc_t 
     }
 }
 
-template <int R, int LT>
-__device__ __forceinline__ void gq_compute(const GqBuf<R, LT>& b, f32x16 (&acc)[R][LT]) {
+// chunk J (0..3) of the super-chunk held in b: 16 k-steps of 32x32x2 MFMAs per tile and column block
+template <int R, int LT, bool PACKED, int J>
+__device__ __forceinline__ void gq_compute(const GqG<R, PACKED>& b, const GqQ<LT>& q, f32x16 (&acc)[R][LT], int h) {
     float av[R][16];
 #pragma unroll
-    for (int t = 0; t < R; ++t)
+    for (int t = 0; t < R; ++t) {
+        if (PACKED) {
+            // the lane's 16 samples of this chunk = one dword of codes: field s at bits 2s.  (w >> 2j) & 0x03030303 leaves the
+            // codes of samples j, 4+j, 8+j, 12+j in bytes 0..3 -- as fp8-e4m3 subnormals exactly g * 2^-9
+            const int lo_ = b.g[J >> 1][t][2 * (J & 1)], hi_ = b.g[J >> 1][t][2 * (J & 1) + 1];
+            const unsigned w = (unsigned)(h ? hi_ : lo_);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[t][v], false);
-            const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[t][v], true);
-            av[t][4 * v + 0] = lo[0]; av[t][4 * v + 1] = lo[1]; av[t][4 * v + 2] = hi[0]; av[t][4 * v + 3] = hi[1];
+            for (int j = 0; j < 4; ++j) {
+                const int x = (int)((w >> (2 * j)) & 0x03030303u);
+                const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(x, false);
+                const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(x, true);
+                av[t][j] = lo[0]; av[t][4 + j] = lo[1]; av[t][8 + j] = hi[0]; av[t][12 + j] = hi[1];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[PACKED ? 0 : J][t][v], false);
+                const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[PACKED ? 0 : J][t][v], true);
+                av[t][4 * v + 0] = lo[0]; av[t][4 * v + 1] = lo[1]; av[t][4 * v + 2] = hi[0]; av[t][4 * v + 3] = hi[1];
+            }
         }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 16; ++u)
@@ -91,22 +122,22 @@ __device__ __forceinline__ void gq_compute(const GqBuf<R, LT>& b, f32x16 (&acc)[
         for (int lt = 0; lt < LT; ++lt) {
             // (element picked with plain constant subscripts: `v[u & 3]` made hipcc 7.2 narrow the 16-byte loads to
             //  one dword and feed element 0 to all four k-steps)
-            const float qv = __builtin_bit_cast(float, u < 4 ? b.q0[lt][u] : u < 8 ? b.q1[lt][u - 4] : u < 12 ? b.q2[lt][u - 8] : b.q3[lt][u - 12]);
+            const float qv = __builtin_bit_cast(float, u < 4 ? q.q0[lt][u] : u < 8 ? q.q1[lt][u - 4] : u < 12 ? q.q2[lt][u - 8] : q.q3[lt][u - 12]);
 #pragma unroll
             for (int t = 0; t < R; ++t) acc[t][lt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][u], qv, acc[t][lt], 0, 0, 0);
         }
 }
 
-template <int R, int LT>
-__device__ __forceinline__ void gq_group(const int8_t* __restrict__ G, int64_t ldg, int64_t nchunks,
+template <int R, int LT, bool PACKED>
+__device__ __forceinline__ void gq_group(const void* __restrict__ Gv, int64_t ldr, int64_t nsuper,
                                          const float* __restrict__ Qb, const float* __restrict__ rv,
                                          const float* __restrict__ bv, const float (&sj)[LT], float* __restrict__ Tout,
                                          float* __restrict__ Tb, float (&csum)[LT], int64_t row0, int c, int h, int lane) {
     constexpr int L = 32 * LT;
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc(G + row0 * ldg);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(static_cast<const char*>(Gv) + row0 * ldr);
     uint32_t gvo[R];
 #pragma unroll
-    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)((32 * t + c) * ldg + 16 * h);
+    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)((32 * t + c) * ldr + (PACKED ? 0 : 16 * h));
     const uint32_t qvo = (uint32_t)(lane * 64);
     constexpr uint32_t QCH = LT * 4096;   // bytes of Qb per 32-sample chunk
 
@@ -118,22 +149,27 @@ __device__ __forceinline__ void gq_group(const int8_t* __restrict__ G, int64_t l
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
 
-    GqBuf<R, LT> A, B;
-    gq_load<R, LT>(A, rg, gvo, 0u, make_rsrc(Qb), qvo, 0u);
-    // chunks are processed in pairs; nchunks is even (samples padded to a multiple of 64 for this loop)
-    for (int64_t ch = 0; ch < nchunks; ch += 2) {
-        const __amdgpu_buffer_rsrc_t rq = make_rsrc(reinterpret_cast<const char*>(Qb) + ch * QCH);
-        const uint32_t s0 = (uint32_t)(ch * 32);
-        const uint32_t nx = (ch + 2 < nchunks) ? 2u : 0u;   // last pair prefetches its own first chunk (unused)
-        gq_load<R, LT>(B, rg, gvo, s0 + 32u, rq, qvo, QCH);
-        __builtin_amdgcn_sched_barrier(0);
-        gq_compute<R, LT>(A, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        gq_load<R, LT>(A, rg, gvo, s0 + 32u * nx, rq, qvo, QCH * nx);
-        __builtin_amdgcn_sched_barrier(0);
-        gq_compute<R, LT>(B, acc);
-        __builtin_amdgcn_sched_barrier(0);
+    GqG<R, PACKED> GA, GB;
+    GqQ<LT> QA, QB;
+    gq_load_g<R, PACKED>(GA, rg, gvo, 0u);
+    gq_load_q<LT>(QA, make_rsrc(Qb), qvo, 0u);
+    // super-chunks (128 samples = 4 chunks) are processed in pairs; nsuper is even (samples padded to a multiple of 256).
+    // Q rides one chunk ahead (QA / QB alternate), G one super-chunk ahead (GA / GB alternate).
+#define GQF_STEP(GCUR, J, QCUR, QNXT, QOFF)                       \
+    gq_load_q<LT>(QNXT, rq, qvo, (QOFF));                          \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    gq_compute<R, LT, PACKED, J>(GCUR, QCUR, acc, h);              \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int64_t sc = 0; sc < nsuper; sc += 2) {
+        const __amdgpu_buffer_rsrc_t rq = make_rsrc(reinterpret_cast<const char*>(Qb) + sc * 4 * QCH);
+        const uint32_t s0 = (uint32_t)(sc * 128);
+        const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;   // the last trip prefetches its own first data (unused)
+        gq_load_g<R, PACKED>(GB, rg, gvo, s0 + 128u);
+        GQF_STEP(GA, 0, QA, QB, 1 * QCH) GQF_STEP(GA, 1, QB, QA, 2 * QCH) GQF_STEP(GA, 2, QA, QB, 3 * QCH) GQF_STEP(GA, 3, QB, QA, 4 * QCH)
+        gq_load_g<R, PACKED>(GA, rg, gvo, s0 + 256u * more);
+        GQF_STEP(GB, 0, QA, QB, 5 * QCH) GQF_STEP(GB, 1, QB, QA, 6 * QCH) GQF_STEP(GB, 2, QA, QB, 7 * QCH) GQF_STEP(GB, 3, QB, QA, 8 * QCH * more)
     }
+#undef GQF_STEP
 
     // epilogue: D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Pad rows have r = b = 0.
 #pragma unroll
@@ -156,9 +192,9 @@ __device__ __forceinline__ void gq_group(const int8_t* __restrict__ G, int64_t l
     }
 }
 
-template <int LT>
-__global__ __launch_bounds__(256, 1) void k_gq_f32(const int8_t* __restrict__ G, int64_t ldg, int64_t units,
-                                                    int64_t nchunks, const float* __restrict__ Qb,
+template <int LT, bool PACKED>
+__global__ __launch_bounds__(256, 1) void k_gq_f32(const void* __restrict__ G, int64_t ldr, int64_t units,
+                                                    int64_t nsuper, const float* __restrict__ Qb,
                                                     const float* __restrict__ rv, const float* __restrict__ bv,
                                                     const float* __restrict__ sv, float* __restrict__ Tout,
                                                     float* __restrict__ Tb, float* __restrict__ cpart) {
@@ -174,12 +210,9 @@ __global__ __launch_bounds__(256, 1) void k_gq_f32(const int8_t* __restrict__ G,
     float csum[LT], sj[LT];
 #pragma unroll
     for (int lt = 0; lt < LT; ++lt) { csum[lt] = 0.f; sj[lt] = sv[32 * lt + c]; }
-    if (LT == 1) {
-        for (; u + 8 <= u_end; u += 8) gq_group<8, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane);
-    }
-    for (; u + 4 <= u_end; u += 4) gq_group<4, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane);
-    if (u + 2 <= u_end) { gq_group<2, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane); u += 2; }
-    if (u + 1 <= u_end) { gq_group<1, LT>(G, ldg, nchunks, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane); u += 1; }
+    for (; u + 4 <= u_end; u += 4) gq_group<4, LT, PACKED>(G, ldr, nsuper, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane);
+    if (u + 2 <= u_end) { gq_group<2, LT, PACKED>(G, ldr, nsuper, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane); u += 2; }
+    if (u + 1 <= u_end) { gq_group<1, LT, PACKED>(G, ldr, nsuper, Qb, rv, bv, sj, Tout, Tb, csum, u * 32, c, h, lane); u += 1; }
 #pragma unroll
     for (int lt = 0; lt < LT; ++lt) {
         const float o = csum[lt] + __shfl_xor(csum[lt], 32);
@@ -187,14 +220,15 @@ __global__ __launch_bounds__(256, 1) void k_gq_f32(const int8_t* __restrict__ G,
     }
 }
 
-void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const float* Qb, int L,
+// G: int8 rows of pitch ldr (packed = 0) or 2-bit dosage codes of pitch ldr bytes (packed = 1); Npad = padded sample count
+void launch_gq_f32(hipStream_t st, const void* G, int packed, int64_t ldr, const GqPlan& plan, int64_t Npad, const float* Qb, int L,
                    const float* r, const float* b, const float* s, float* Tout, float* Tb, float* cpart) {
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
-    const int64_t nchunks = (N + 63) / 64 * 2;   // 32-sample chunks, even count (Npad is a multiple of 256 >= this)
-    if (L == 32)
-        hipLaunchKernelGGL((k_gq_f32<1>), grid, blk, 0, st, G, ldg, plan.units, nchunks, Qb, r, b, s, Tout, Tb, cpart);
-    else
-        hipLaunchKernelGGL((k_gq_f32<2>), grid, blk, 0, st, G, ldg, plan.units, nchunks, Qb, r, b, s, Tout, Tb, cpart);
+    const int64_t nsuper = Npad / 128;   // even: Npad is a multiple of 256
+#define GPCA_GQF(LTV, PK) hipLaunchKernelGGL((k_gq_f32<LTV, PK>), grid, blk, 0, st, G, ldr, plan.units, nsuper, Qb, r, b, s, Tout, Tb, cpart)
+    if (L == 32) { if (packed) GPCA_GQF(1, true); else GPCA_GQF(1, false); }
+    else { if (packed) GPCA_GQF(2, true); else GPCA_GQF(2, false); }
+#undef GPCA_GQF
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -225,11 +259,15 @@ GttPlan gtt_plan(int64_t Mpad, int64_t Npad, int L, int target_waves) {
 template <int LT>
 struct GttBuf { i32x2 g[8]; i32x4 t0[LT], t1[LT]; };
 
-template <int LT>
+// PACKED: the lane's 8 samples are 16 bits of the row; lanes 2j and 2j+1 load the same dword and take their own half
+template <int LT, bool PACKED>
 __device__ __forceinline__ void gtt_load(GttBuf<LT>& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off,
                                          uint32_t ldg, __amdgpu_buffer_rsrc_t rt, uint32_t tvo, uint32_t toff) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) b.g[u] = __builtin_amdgcn_raw_buffer_load_b64(rg, gvo, row_off + (uint32_t)(2 * u) * ldg, 0);
+    for (int u = 0; u < 8; ++u) {
+        if (PACKED) b.g[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)(2 * u) * ldg, 0);
+        else b.g[u] = __builtin_amdgcn_raw_buffer_load_b64(rg, gvo, row_off + (uint32_t)(2 * u) * ldg, 0);
+    }
 #pragma unroll
     for (int lt = 0; lt < LT; ++lt) {
         b.t0[lt] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, toff + lt * 2048, 0);
@@ -237,13 +275,25 @@ __device__ __forceinline__ void gtt_load(GttBuf<LT>& b, __amdgpu_buffer_rsrc_t r
     }
 }
 
-template <int LT>
-__device__ __forceinline__ void gtt_compute(const GttBuf<LT>& b, f32x16 (&acc)[8][LT]) {
+// one byte of 2-bit codes (4 samples) -> 4 bytes, one code each
+__device__ __forceinline__ int spread_codes(unsigned t) {
+    t = (t | (t << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    return (int)t;
+}
+
+template <int LT, bool PACKED>
+__device__ __forceinline__ void gtt_compute(const GttBuf<LT>& b, f32x16 (&acc)[8][LT], unsigned hsh) {
     float bv[8][8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][0], false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][0], true);
-        const f32x2 p2 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][1], false), p3 = __builtin_amdgcn_cvt_pk_f32_fp8(b.g[u][1], true);
+        int g0, g1;
+        if (PACKED) {
+            const unsigned w = ((unsigned)b.g[u][0] >> hsh) & 0xffffu;     // this lane's 8 samples
+            g0 = spread_codes(w & 0xffu); g1 = spread_codes(w >> 8);
+        } else { g0 = b.g[u][0]; g1 = b.g[u][1]; }
+        const f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8(g0, false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8(g0, true);
+        const f32x2 p2 = __builtin_amdgcn_cvt_pk_f32_fp8(g1, false), p3 = __builtin_amdgcn_cvt_pk_f32_fp8(g1, true);
         bv[u][0] = p0[0]; bv[u][1] = p0[1]; bv[u][2] = p1[0]; bv[u][3] = p1[1];
         bv[u][4] = p2[0]; bv[u][5] = p2[1]; bv[u][6] = p3[0]; bv[u][7] = p3[1];
     }
@@ -258,8 +308,8 @@ __device__ __forceinline__ void gtt_compute(const GttBuf<LT>& b, f32x16 (&acc)[8
         }
 }
 
-template <int LT>
-__global__ __launch_bounds__(256, 1) void k_gtt_f32(const int8_t* __restrict__ G, int64_t ldg, int64_t Mpad,
+template <int LT, bool PACKED>
+__global__ __launch_bounds__(256, 1) void k_gtt_f32(const uint8_t* __restrict__ G, int64_t ldg, int64_t Mpad,
                                                      int64_t Npad, const float* __restrict__ Tb,
                                                      float* __restrict__ Ypart, int64_t ngroups, int64_t rows_per_wave) {
     constexpr int L = 32 * LT;
@@ -285,25 +335,27 @@ __global__ __launch_bounds__(256, 1) void k_gtt_f32(const int8_t* __restrict__ G
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][lt][e] = 0.f;
 
-    const uint32_t gvo = (uint32_t)(h * ldg + 8 * c);
+    // (ldg = row pitch in bytes: N padded for int8 rows, a quarter of it for packed rows)
+    const uint32_t gvo = PACKED ? (uint32_t)(h * ldg + 4 * (c >> 1)) : (uint32_t)(h * ldg + 8 * c);
+    const unsigned hsh = 16u * (unsigned)(c & 1);
     const uint32_t tvo = (uint32_t)(lane * 32);
     constexpr uint32_t TGR = LT * 2048;                       // bytes of Tb per 16-row group
-    const int8_t* gp = G + m_begin * ldg + n0;
+    const uint8_t* gp = G + m_begin * ldg + (PACKED ? (n0 >> 2) : n0);
     const char* tp = reinterpret_cast<const char*>(Tb) + (m_begin >> 4) * TGR;
     GttBuf<LT> A, B;
-    gtt_load<LT>(A, make_rsrc(gp), gvo, 0u, (uint32_t)ldg, make_rsrc(tp), tvo, 0u);
+    gtt_load<LT, PACKED>(A, make_rsrc(gp), gvo, 0u, (uint32_t)ldg, make_rsrc(tp), tvo, 0u);
     for (int64_t g = 0; g < groups; g += 2) {
         // descriptors are re-based every pair of groups, so the 32-bit offsets stay < 48 * ldg
         const __amdgpu_buffer_rsrc_t rg = make_rsrc(gp + g * 16 * ldg);
         const __amdgpu_buffer_rsrc_t rt = make_rsrc(tp + g * TGR);
         const uint32_t nx = (g + 2 < groups) ? 2u : 0u;       // last pair prefetches its own first group (unused)
-        gtt_load<LT>(B, rg, gvo, 16u * (uint32_t)ldg, (uint32_t)ldg, rt, tvo, TGR);
+        gtt_load<LT, PACKED>(B, rg, gvo, 16u * (uint32_t)ldg, (uint32_t)ldg, rt, tvo, TGR);
         __builtin_amdgcn_sched_barrier(0);
-        gtt_compute<LT>(A, acc);
+        gtt_compute<LT, PACKED>(A, acc, hsh);
         __builtin_amdgcn_sched_barrier(0);
-        gtt_load<LT>(A, rg, gvo, 16u * nx * (uint32_t)ldg, (uint32_t)ldg, rt, tvo, TGR * nx);
+        gtt_load<LT, PACKED>(A, rg, gvo, 16u * nx * (uint32_t)ldg, (uint32_t)ldg, rt, tvo, TGR * nx);
         __builtin_amdgcn_sched_barrier(0);
-        gtt_compute<LT>(B, acc);
+        gtt_compute<LT, PACKED>(B, acc, hsh);
         __builtin_amdgcn_sched_barrier(0);
     }
     // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h (+32 lt), col = c -> sample n0 + 8c + t.
@@ -325,14 +377,14 @@ __global__ __launch_bounds__(256, 1) void k_gtt_f32(const int8_t* __restrict__ G
     }
 }
 
-void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const float* Tb, int L,
+void launch_gtt_f32(hipStream_t st, const void* G, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const float* Tb, int L,
                     float* Ypart, const GttPlan& plan) {
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     const dim3 grid((unsigned)plan.grid), blk(256);
-    if (L == 32)
-        hipLaunchKernelGGL((k_gtt_f32<1>), grid, blk, 0, st, G, ldg, Mpad, Npad, Tb, Ypart, ngroups, plan.rows_per_wave);
-    else
-        hipLaunchKernelGGL((k_gtt_f32<2>), grid, blk, 0, st, G, ldg, Mpad, Npad, Tb, Ypart, ngroups, plan.rows_per_wave);
+#define GPCA_GTTF(LTV, PK) hipLaunchKernelGGL((k_gtt_f32<LTV, PK>), grid, blk, 0, st, (const uint8_t*)G, ldr, Mpad, Npad, Tb, Ypart, ngroups, plan.rows_per_wave)
+    if (L == 32) { if (packed) GPCA_GTTF(1, true); else GPCA_GTTF(1, false); }
+    else { if (packed) GPCA_GTTF(2, true); else GPCA_GTTF(2, false); }
+#undef GPCA_GTTF
 }
 
 }  // namespace gpca

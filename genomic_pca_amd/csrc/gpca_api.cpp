@@ -261,7 +261,6 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     h->storage = cfg ? cfg->storage : GPCA_STORE_INT8;
     if (h->storage != GPCA_STORE_INT8 && h->storage != GPCA_STORE_2BIT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown storage mode"); }
     if (h->precision != GPCA_PREC_F32_MFMA && h->precision != GPCA_PREC_I8_EXACT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown precision mode"); }
-    if (h->storage == GPCA_STORE_2BIT && h->precision != GPCA_PREC_I8_EXACT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: GPCA_STORE_2BIT requires GPCA_PREC_I8_EXACT"); }
     {
         const int dp = cfg ? cfg->digit_planes : 0;
         if (dp != 0 && dp != 3 && dp != 4) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes must be 0, 3 or 4"); }
@@ -587,7 +586,20 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
     CHK(alloc_genotypes(h, M, N, /*resident=*/false));
     const bool packed = h->storage == GPCA_STORE_2BIT;
     const int64_t row_bytes = packed ? h->ld2 : h->ldg;
-    if (panel_rows == 0) panel_rows = ((int64_t)1 << 30) / row_bytes;
+    if (panel_rows == 0) {
+        // K1 gives every wave 128 SNP rows and sweeps all samples with them: a panel needs gq_waves_target x 128 rows (131 072)
+        // to fill the chip, however wide the rows are (a 1 GiB panel of 500k-sample rows holds 8k rows and leaves three quarters
+        // of the CUs idle).  Take that many rows when the ring fits in half of the free HBM after the M- and N-sized workspace.
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const double workspace = (double)h->Mpad * (64 * 4 + 2 * 32 * kDigits + 48) + (double)h->ldg * (64 * 8 * 3 + 2 * 32 * kDigits + 32 * 8 * 4);
+        const double budget = 0.5 * ((double)free_b - workspace);
+        int64_t rows = (int64_t)h->gq_waves_target * kGQRowsPerWave;
+        const int64_t fit = (int64_t)(budget / ((double)ring_slots * (double)row_bytes));
+        if (rows > fit) rows = fit;
+        panel_rows = rows / kGQRowsPerWave * kGQRowsPerWave;
+        if (panel_rows < kGQRowsPerWave) panel_rows = kGQRowsPerWave;
+    }
     panel_rows = round_up(std::max<int64_t>(panel_rows, 1), kGQRowsPerWave);
     if (panel_rows > h->Mpad) panel_rows = h->Mpad;
     StreamState& sm = h->sm;
@@ -1055,8 +1067,9 @@ static int stage_AtT_local(gpca_handle* h) {
         return GPCA_OK;
     }
     {
-        ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, elems);
-        launch_gtt_f32(h->st, h->dG, h->ldg, h->Mpad, h->ldg, h->dTb, h->L, h->dYpart, h->plan);
+        const bool packed = h->storage == GPCA_STORE_2BIT;
+        ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, packed ? elems / 4 : elems);
+        launch_gtt_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ldg, h->Mpad, h->ldg, h->dTb, h->L, h->dYpart, h->plan);
     }
     HIPCHK(hipGetLastError());
     launch_reduce_y(h->st, h->dYpart, h->plan.W, h->ldg, h->N, h->L, h->d_c, h->dY);
@@ -1115,8 +1128,10 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
         return GPCA_OK;
     }
     {
-        ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, elems);
-        launch_gq_f32(h->st, h->dG, h->ldg, h->gqplan, h->N, h->dQ, h->L, h->d_r, h->d_b, h->d_s32, h->dT, scale_out ? h->dTb : nullptr, h->d_cpart);
+        const bool packed = h->storage == GPCA_STORE_2BIT;
+        ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, packed ? elems / 4 : elems);
+        launch_gq_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ldg, h->gqplan, h->ldg, h->dQ, h->L, h->d_r, h->d_b,
+                      h->d_s32, h->dT, scale_out ? h->dTb : nullptr, h->d_cpart);
     }
     HIPCHK(hipGetLastError());
     if (scale_out) CHK(stage_sum_c(h, h->gqplan.waves));

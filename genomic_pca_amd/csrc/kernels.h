@@ -71,12 +71,13 @@ void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t
 // (power iteration); Tb == NULL: write T row-major into Tout (projection B = A Q).  Qb is the blocked basis.
 struct GqPlan { int64_t units; int64_t waves; };   // 32-row units of the padded matrix; resident waves (multiple of 4)
 GqPlan gq_plan(int64_t Mpad, int waves_target);
-void launch_gq_f32(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const float* Qb,
+// G: int8 rows (packed = 0) or 2-bit dosage codes (packed = 1) of row pitch ldr bytes; Npad = padded sample count (multiple of 256)
+void launch_gq_f32(hipStream_t st, const void* G, int packed, int64_t ldr, const GqPlan& plan, int64_t Npad, const float* Qb,
                    int L, const float* r, const float* b, const float* s, float* Tout, float* Tb, float* cpart);
 // K2: Ypart[w][n][j] = 2^-9 * sum over the wave's SNP rows of G[i][n] * T'[i][j]   (T' blocked in Tb)
 struct GttPlan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; };
 GttPlan gtt_plan(int64_t Mpad, int64_t Npad, int L, int target_waves);
-void launch_gtt_f32(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const float* Tb,
+void launch_gtt_f32(hipStream_t st, const void* G, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const float* Tb,
                     int L, float* Ypart, const GttPlan& plan);
 // Y[n][j] = c[j] + 2^9 * sum_w Ypart[w][n][j]   (f64 sum), n < N
 void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, int64_t N, int L, const double* c,

@@ -65,8 +65,8 @@ typedef enum gpca_precision {
 /* How the genotypes stay resident in HBM. */
 typedef enum gpca_storage {
     GPCA_STORE_INT8 = 0, /* 1 B per genotype */
-    GPCA_STORE_2BIT = 1  /* 0.25 B per genotype (PLINK-like packing of dosage codes), decoded in the GEMM prologues;
-                            requires GPCA_PREC_I8_EXACT.  10M SNPs x 100k samples = 250 GB: fits one MI355X. */
+    GPCA_STORE_2BIT = 1  /* 0.25 B per genotype (PLINK-like packing of dosage codes), decoded in the GEMM prologues of either
+                            precision.  10M SNPs x 100k samples = 250 GB: fits one MI355X. */
 } gpca_storage;
 
 typedef struct gpca_config {
@@ -136,7 +136,7 @@ GPCA_API int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* src,
 /* Out-of-core mode: the matrix is never resident.  Every pass of gpca_snp_stats / gpca_rsvd / gpca_transform walks
  * ceil(M / panel_rows) panels through a ring of `ring_slots` (>= 2) HBM panel buffers; panel p + 1 is generated or
  * copied on a second stream while panel p is multiplied.  panel_rows is rounded up to a multiple of 128; 0 picks
- * ~1 GiB panels.  Requires GPCA_PREC_I8_EXACT (either storage).  Results are bit-identical to the resident engine on the
+ * 131 072 rows (a full grid of the row-parallel GEMM) or as many as fit the ring in half of the free HBM.  Requires GPCA_PREC_I8_EXACT (either storage).  Results are bit-identical to the resident engine on the
  * same matrix.  The pull API (gpca_standardize_block) and gpca_download_genotypes_i8 need a resident matrix. */
 GPCA_API int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N, int64_t panel_rows,
                               int32_t ring_slots);

@@ -3,6 +3,7 @@
 #   1. bench.py (default config, with cpu_baseline)            -> gpurun_out/bench_<tag>.json
 #   2. rocprofv3 --kernel-trace --stats of the same command    -> gpurun_out/prof_<tag>/
 #   3. PMC passes (separate runs, counters only): HBM bytes, MFMA busy
+# (the default bench.py run holds only full-matrix launches of every GEMM kernel, so per-kernel averages are per-launch figures)
 tag=$1
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

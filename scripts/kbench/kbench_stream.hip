@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <initializer_list>
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -200,6 +201,35 @@ int main() {
         float b2 = time_ms([&] { hipLaunchKernelGGL((k_read_cols_wide<8, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
         printf("column slabs (K2 plan): dword loads NB4 %.2f  NB4 nt %.2f  NB2 nt %.2f | b128 pieces NB4 %.2f  NB4 nt %.2f  NB8 nt %.2f TB/s\n",
                gb / a0 * 1e-9, gb / a1 * 1e-9, gb / a2 * 1e-9, gb / b0 * 1e-9, gb / b1 * 1e-9, gb / b2 * 1e-9);
+    }
+    {
+        // Infinity Cache (256 MiB MALL).  (a) a buffer that stays resident, re-read 20 x back to back: the on-die read rate.
+        // (b) what pairing K1 -> K2 per row chunk would buy: the 10 GiB buffer read twice, either as two full
+        // passes (2 launches: the second pass misses everywhere) or chunk by chunk with the second read of a chunk right behind the
+        // first (2 x 10 GiB / chunk launches: the second read of a chunk can hit the MALL).  grid 4096 keeps a chunk launch
+        // from being all ramp-up.
+        for (int64_t mib : {32, 64, 128, 192, 512}) {
+            const int64_t nb = (mib << 20) / 16;
+            float t = time_ms([&] { for (int r = 0; r < 20; ++r) hipLaunchKernelGGL((k_read<4, 0>), dim3(4096), dim3(256), 0, 0, p, nb, out); }, 3);
+            printf("re-read of a %4lld MiB buffer (20 launches back to back): %.2f TB/s, %.1f us per launch\n", (long long)mib,
+                   20.0 * (double)(mib << 20) / t * 1e-9, t * 1e3 / 20);
+        }
+        const double two = 2.0 * (double)(10LL << 30);
+        const int64_t n10 = (10LL << 30) / 16;
+        float full = time_ms([&] { for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k_read<4, 0>), dim3(16384), dim3(256), 0, 0, p, n10, out); }, 3);
+        float fullnt = time_ms([&] { for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k_read<4, 1>), dim3(16384), dim3(256), 0, 0, p, n10, out); }, 3);
+        printf("10 GiB read twice, two full passes: %.3f ms (%.2f TB/s); nt: %.3f ms (%.2f TB/s)\n", full, two / full * 1e-9, fullnt, two / fullnt * 1e-9);
+        for (int64_t mib : {64, 128, 192}) {
+            const int64_t nb = (mib << 20) / 16, chunks = (10LL << 30) / (mib << 20);
+            float t = time_ms([&] {
+                for (int64_t c = 0; c < chunks; ++c) {
+                    hipLaunchKernelGGL((k_read<4, 0>), dim3(4096), dim3(256), 0, 0, p + c * nb, nb, out);
+                    hipLaunchKernelGGL((k_read<4, 0>), dim3(4096), dim3(256), 0, 0, p + c * nb, nb, out);
+                }
+            }, 3);
+            printf("10 GiB read twice in paired %3lld MiB chunks (%lld launches): %.3f ms (%.2f TB/s)\n", (long long)mib, (long long)(2 * chunks), t,
+                   two / t * 1e-9);
+        }
     }
     return 0;
 }

@@ -396,7 +396,7 @@ def test_bed2bit_decode_reference_fixture(gpca, oracle, engine):
 _FULL = {}
 
 
-@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("f32", "int8")])
+@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("f32", "int8"), ("f32", "2bit")])
 def test_full_size_properties(gpca, oracle, prec, store):
     """BASELINE.json configs[1] at full size on EVERY GEMM path, named explicitly: ("i8", "int8") is the headline path of
     bench.py (k_gq_d / k_gtt_d, LDS-DMA), ("i8", "2bit") the packed kernels (k_gq_2bit / k_gtt_p), ("f32", "int8") the
@@ -455,6 +455,8 @@ def test_full_size_properties(gpca, oracle, prec, store):
     if ("i8", "int8") in _FULL and (prec, store) != ("i8", "int8"):
         ev0, sc0, ld0 = _FULL[("i8", "int8")]
         tol = 1e-8 if prec == "i8" else 1e-5
+    if (prec, store) == ("f32", "2bit") and ("f32", "int8") in _FULL:      # same f32 FMA chains on the decoded codes: the same bits
+        assert np.array_equal(ev, _FULL[("f32", "int8")][0]) and np.array_equal(sc[:, :2], _FULL[("f32", "int8")][1])
         assert np.max(np.abs(ev[:2] - ev0[:2]) / ev0[:2]) < tol
         assert oracle.max_abs_dpc(sc[:, :2], sc0) < tol and oracle.max_abs_dpc(ld[:, :2].astype(np.float64), ld0) < 10 * tol
 
@@ -667,10 +669,30 @@ def test_2bit_equals_int8_residency(gpca, oracle, engine_i8, engine_2bit):
     assert oracle.max_abs_dpc(res[0][1], res[1][1]) < 1e-8
 
 
-def test_2bit_requires_exact_integer_path(gpca):
+@pytest.mark.parametrize("M,N,P,k", [(4096, 512, 12, 8), (20000, 1000, 16, 10), (3000, 1500, 10, 6), (999, 257, 8, 4), (130, 70, 4, 3), (6000, 700, 48, 40)])
+def test_f32_path_on_2bit_residency(gpca, oracle, engine, M, N, P, k):
+    """GPCA_PREC_F32_MFMA on GPCA_STORE_2BIT (north_star's literal configuration: MFMA-fp32 GEMMs on a matrix that only fits one
+    GPU packed): the codes are spread in the conversion block and take the same f32 FMA chains, so the answers are the
+    int8-resident f32 path's, BIT FOR BIT, and hold the oracle's 1e-4 bar."""
     from genomic_pca_amd import _lib
-    with pytest.raises(gpca.GpcaError):
-        gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA, storage=_lib.STORE_2BIT)
+    th = gpca.synth_thresholds(M, P, seed=1, fst=0.2)
+    G = oracle.synth_genotypes(M, N, 1, th)
+    G[5::11, :3] = -127                                        # packed code 3 inside rows that QC drops
+    qc = gpca.QcConfig(0.999, 0.0, 1.0)
+    with gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA, storage=_lib.STORE_2BIT) as e2:
+        e2.upload_genotypes_i8(G); st2 = e2.snp_stats(qc); e2.rsvd(k, 10, 2, seed=1)
+        engine.upload_genotypes_i8(G); st8 = engine.snp_stats(qc); engine.rsvd(k, 10, 2, seed=1)
+        assert np.array_equal(st2["keep"], st8["keep"]) and np.array_equal(st2["mu"], st8["mu"])
+        assert np.array_equal(e2.eigenvalues(), engine.eigenvalues())
+        assert np.array_equal(e2.scores(f64=True), engine.scores(f64=True)) and np.array_equal(e2.loadings(), engine.loadings())
+        assert np.array_equal(e2.transform(), engine.transform())
+        ref = oracle.snp_stats(G, N, qc.min_snp_call_rate, qc.min_snp_maf, qc.max_snp_hwe_p_value)
+        r, b = oracle.scale_shift(ref["mu"], ref["sigma"], ref["keep"])
+        R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=1)
+        kk = min(k, 20)                                        # (k = 40 case: the trailing PCs sit in the noise bulk)
+        assert np.max(np.abs(e2.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+        assert oracle.max_abs_dpc(e2.scores(f64=True)[:, :kk], R["scores"][:, :kk]) < TOL_PC
+        assert oracle.max_abs_dpc(e2.loadings().astype(np.float64)[:, :kk], R["loadings"][ref["keep"].astype(bool)][:, :kk]) < TOL_PC
 
 
 # ------------------------------------------------------------------------------------------------
@@ -684,7 +706,8 @@ def test_wide_sample_axis_all_paths(gpca, oracle):
     st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
     r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
     R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=4)
-    for prec, store in ((_lib.PREC_F32_MFMA, _lib.STORE_INT8), (_lib.PREC_I8_EXACT, _lib.STORE_INT8), (_lib.PREC_I8_EXACT, _lib.STORE_2BIT)):
+    for prec, store in ((_lib.PREC_F32_MFMA, _lib.STORE_INT8), (_lib.PREC_F32_MFMA, _lib.STORE_2BIT), (_lib.PREC_I8_EXACT, _lib.STORE_INT8),
+                        (_lib.PREC_I8_EXACT, _lib.STORE_2BIT)):
         with gpca.GpcaEngine(precision=prec, storage=store) as e:
             e.upload_genotypes_i8(G)
             s2 = e.snp_stats(gpca.QcConfig.none())
@@ -700,7 +723,7 @@ def test_wide_sample_axis_all_paths(gpca, oracle):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec,store,M,N,k", [("i8", "int8", 300_000, 2048, 20), ("i8", "int8", 40_000, 10_000, 10),
                                                ("i8", "2bit", 300_000, 2048, 20), ("f32", "int8", 300_000, 2048, 20),
-                                               ("f32", "int8", 100_000, 1024, 40)])
+                                               ("f32", "int8", 100_000, 1024, 40), ("f32", "2bit", 300_000, 2048, 20)])
 def test_rsvd_bitwise_repeatable(gpca, prec, store, M, N, k):
     """Every kernel has a fixed reduction tree and no float atomics, so the same call must return the same bits.  Sizes
     are chosen so that each K1 workgroup runs full LDS-DMA rounds (> 8 row units per workgroup)."""
