@@ -597,6 +597,13 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
         int64_t rows = (int64_t)h->gq_waves_target * kGQRowsPerWave;
         const int64_t fit = (int64_t)(budget / ((double)ring_slots * (double)row_bytes));
         if (rows > fit) rows = fit;
+        if (src->kind == GPCA_PANEL_HOST_I8 || src->kind == GPCA_PANEL_HOST_BED) {
+            // callback sources also need two pinned host staging panels: keep each within 2 GiB (such a source is bound by the
+            // host link, ~55 GB/s, long before the row-parallel K1 runs out of rows)
+            const int64_t host_ld = src->kind == GPCA_PANEL_HOST_BED ? (N + 3) / 4 : N;
+            const int64_t cap = ((int64_t)2 << 30) / host_ld;
+            if (rows > cap) rows = cap;
+        }
         panel_rows = rows / kGQRowsPerWave * kGQRowsPerWave;
         if (panel_rows < kGQRowsPerWave) panel_rows = kGQRowsPerWave;
     }

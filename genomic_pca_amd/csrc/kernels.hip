@@ -61,36 +61,47 @@ void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, i
 }
 
 // Fast generator for streamed panels: thread = 16 consecutive samples of one SNP row = two Philox calls; writes 16 int8
-// bytes or one 32-bit word of 2-bit dosage codes (no int8 scratch + pack pass).  Bit-identical to
-// oracle/gpca_oracle.c:orc_synth16_genotypes.
+// bytes or one 32-bit word of 2-bit dosage codes (no int8 scratch + pack pass).  The 16 samples of a thread belong to ONE
+// population -- pop(n) = (n / 16) % P -- so the two 16-bit thresholds are loaded once per thread and a genotype costs two
+// sub-dword compares and two carry-adds (the first version, with pop(n) = n % P and a threshold load per sample, spent 80 %
+// of its instructions outside Philox: 1.45e12 genotypes/s).  Bit-identical to oracle/gpca_oracle.c:orc_synth16_genotypes.
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_synth16(void* __restrict__ Gv, int64_t rows, int64_t N, int64_t ld, int64_t snp0,
                                                   uint64_t seed, const uint32_t* __restrict__ thresh, int P) {
-    const int64_t per_row = PACKED ? (ld >> 2) : (ld >> 4);
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= rows * per_row) return;
-    const int64_t i = t / per_row;
-    const int64_t n0 = (t - i * per_row) << 4;
-    const uint64_t gi = (uint64_t)(i + snp0);
-    const uint32_t* th = thresh + i * P;
-    int pop = (int)(n0 % P);
+    // grid = (rows, ceil(words per row / 256)): no 64-bit division per thread
+    const uint32_t per_row = (uint32_t)(PACKED ? (ld >> 2) : (ld >> 4));
+    const int64_t i = blockIdx.x;
+    const uint32_t wi = blockIdx.y * 256u + threadIdx.x;    // 16-sample word of the row
+    if (wi >= per_row) return;
+    const int64_t n0 = (int64_t)wi << 4;
     uint32_t w[4] = {0u, 0u, 0u, 0u};
     uint32_t codes = 0u;
+    if (n0 < N) {
+        const uint64_t gi = (uint64_t)(i + snp0);
+        const uint32_t tw = thresh[i * P + (int)(wi % (uint32_t)P)];
+        const uint32_t t1 = tw >> 16, t2 = tw & 0xffffu;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        if (n0 + 8 * hf < N) {
-            const philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)((n0 >> 3) + hf), GPCA_STREAM_GEN16,
+        for (int hf = 0; hf < 2; ++hf) {
+            const philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), 2u * wi + hf, GPCA_STREAM_GEN16,
                                                (uint32_t)seed, (uint32_t)(seed >> 32));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int s = 8 * hf + j;
-                const uint32_t tw = th[pop];
-                pop = pop + 1 == P ? 0 : pop + 1;
-                const uint32_t u = (o.v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                uint32_t g = (uint32_t)(u < (tw >> 16)) + (uint32_t)(u < (tw & 0xffffu));
-                if (n0 + s >= N) g = 0u;
+                const uint32_t u = (j & 1) ? (o.v[j >> 1] >> 16) : (o.v[j >> 1] & 0xffffu);
+                const uint32_t g = (uint32_t)(u < t1) + (uint32_t)(u < t2);
                 if (PACKED) codes |= g << (2 * s);
                 else w[s >> 2] |= g << (8 * (s & 3));
+            }
+        }
+        if (n0 + 16 > N) {                                   // the row's last, partial word: samples >= N are 0
+            const int valid = (int)(N - n0);                 // 1..15
+            if (PACKED) codes &= (1u << (2 * valid)) - 1u;
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int v = valid - 4 * q;
+                    w[q] = v >= 4 ? w[q] : (v <= 0 ? 0u : (w[q] & ((1u << (8 * v)) - 1u)));
+                }
             }
         }
     }
@@ -99,8 +110,8 @@ __global__ __launch_bounds__(256) void k_synth16(void* __restrict__ Gv, int64_t 
 }
 void launch_synth16(hipStream_t st, void* G, int packed, int64_t rows, int64_t N, int64_t ld, int64_t snp0, uint64_t seed,
                     const uint32_t* d_thresh16, int P) {
-    const int64_t total = rows * (packed ? (ld >> 2) : (ld >> 4));
-    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    const int64_t per_row = packed ? (ld >> 2) : (ld >> 4);
+    const dim3 grid((unsigned)rows, (unsigned)((per_row + 255) / 256)), blk(256);
     if (packed) hipLaunchKernelGGL(k_synth16<true>, grid, blk, 0, st, G, rows, N, ld, snp0, seed, d_thresh16, P);
     else hipLaunchKernelGGL(k_synth16<false>, grid, blk, 0, st, G, rows, N, ld, snp0, seed, d_thresh16, P);
 }

@@ -39,7 +39,7 @@ def synth_thresholds16(M: int, P: int = 3, seed: int = 1, fst: float = 0.05, snp
     """uint32 [M, P] for the fast panel generator (GPCA_PANEL_SYNTH16): one 16-bit uniform u per genotype,
     g = (u < t1) + (u < t2) with t2 = floor(p^2 * 65536) in the low half (P(g = 2)) and
     t1 = floor((1 - (1 - p)^2) * 65536) in the high half (P(g >= 1)): Hardy-Weinberg proportions of the same
-    per-population allele frequencies synth_thresholds() uses."""
+    per-population allele frequencies synth_thresholds() uses.  Sample n belongs to population (n // 16) % P."""
     out = np.empty((M, P), np.uint32)
     done = 0
     while done < M:

@@ -116,7 +116,8 @@ typedef enum gpca_panel_kind {
     GPCA_PANEL_HOST_BED = 1, /* `fill` writes PLINK .bed rows (2 bits/sample, count_a1 decode), row pitch ld = ceil(N/4) */
     GPCA_PANEL_SYNTH = 2,    /* device generator of gpca_synth_genotypes: thresh = uint32 [M][n_pop] = floor(p * 2^32) */
     GPCA_PANEL_SYNTH16 = 3   /* fast device generator, one 16-bit uniform per genotype: thresh = uint32 [M][n_pop],
-                                high half = floor(P(g >= 1) * 65536), low half = floor(P(g = 2) * 65536) */
+                                high half = floor(P(g >= 1) * 65536), low half = floor(P(g = 2) * 65536); sample n belongs to
+                                population (n / 16) % n_pop */
 } gpca_panel_kind;
 /* Write rows [row0, row0 + rows) of the matrix into dst (pinned host memory owned by the library).  Return 0, or
  * non-zero to abort the pass (reported as GPCA_ERR_BAD_ARG with the row range in the message). */

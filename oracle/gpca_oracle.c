@@ -88,8 +88,9 @@ void orc_synth_genotypes(int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t sn
 
 /* Fast panel generator (GPCA_PANEL_SYNTH16; device twin: genomic_pca_amd/csrc/kernels.hip:k_synth16).  One 16-bit
  * uniform per genotype: counter = (snp_lo, snp_hi, n/8, stream 0x47454E31), key = seed; sample n = 8q + j takes
- * u = 16-bit field (j & 1) of output word j >> 1;  g = (u < t1) + (u < t2) with the thresholds of population n % P packed
- * in thresh[i*P + n%P]: high half t1 = floor(P(g >= 1) * 65536), low half t2 = floor(P(g = 2) * 65536). */
+ * u = 16-bit field (j & 1) of output word j >> 1;  g = (u < t1) + (u < t2) with the thresholds of the sample's population
+ * (n / 16) % P -- blocks of 16 consecutive samples share a population -- packed in thresh[i*P + pop]: high half
+ * t1 = floor(P(g >= 1) * 65536), low half t2 = floor(P(g = 2) * 65536). */
 void orc_synth16_genotypes(int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset,
                            uint64_t seed, const uint32_t* thresh, int P) {
 #pragma omp parallel for schedule(static)
@@ -101,7 +102,7 @@ void orc_synth16_genotypes(int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t 
                           (uint32_t)seed, (uint32_t)(seed >> 32), o);
             for (int j = 0; j < 8 && 8 * q + j < N; ++j) {
                 int64_t n = 8 * q + j;
-                uint32_t tw = thresh[i * P + (n % P)];
+                uint32_t tw = thresh[i * P + ((n >> 4) % P)];
                 uint32_t u = (o[j >> 1] >> (16 * (j & 1))) & 0xffffu;
                 G[i * ld + n] = (int8_t)((u < (tw >> 16)) + (u < (tw & 0xffffu)));
             }

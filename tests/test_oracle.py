@@ -179,9 +179,9 @@ def test_checker_against_sklearn_randomized_svd(oracle, gpca):
 def test_synth16_known_answers(oracle, gpca):
     """Fast panel generator: field order and threshold halves, by hand from one Philox block."""
     th = np.array([[(40000 << 16) | 10000, (65535 << 16) | 65535, 0]], np.uint32)          # pop 0: mixed; pop 1: always 2; pop 2: always 0
-    G = oracle.synth16_genotypes(1, 24, 99, th, snp_offset=7)
-    assert np.all(G[0, 1::3] == 2) and np.all(G[0, 2::3] == 0)
-    o = oracle.philox([7, 0, 0, 0x47454E31], [99, 0])                                       # samples 0..7 of SNP 7
+    G = oracle.synth16_genotypes(1, 70, 99, th, snp_offset=7)
+    assert np.all(G[0, 16:32] == 2) and np.all(G[0, 32:48] == 0) and np.all(G[0, 64:70] == 2)   # pop(n) = (n / 16) % 3
+    o = oracle.philox([7, 0, 0, 0x47454E31], [99, 0])                                       # samples 0..7 of SNP 7 (population 0)
     u0 = int(o[0]) & 0xffff; u3 = (int(o[1]) >> 16) & 0xffff; u6 = int(o[3]) & 0xffff
     for n, u in ((0, u0), (3, u3), (6, u6)):
         assert G[0, n] == (u < 40000) + (u < 10000)
