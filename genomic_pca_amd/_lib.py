@@ -85,6 +85,7 @@ PROTOTYPES = {
     "gpca_set_standardization": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_get_standardization": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_hwe_chi_squared_p_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
+    "gpca_host_eigh_desc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpca_standardize_block": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gpca_num_pca_snps": (C.c_int64, [_H]),
     "gpca_num_qc_samples": (C.c_int64, [_H]),

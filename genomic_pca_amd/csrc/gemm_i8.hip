@@ -1651,10 +1651,10 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
     for (int j = 0; j < 16; ++j) {
         const int64_t row = layout ? (blk >> 2) * 128 + 64 * hh + 16 * (blk & 3) + j : blk * 32 + 16 * hh + j;
         const double x = row < rows ? (double)X[row * ldx + cc] : 0.0;
-        long long v = __double2ll_rn(x * sc);
+        int v = __double2int_rn(x * sc);          // |x * sc| <= 0.49 * 2^28 (2^24 in three-plane mode): 32-bit digit arithmetic
 #pragma unroll
         for (int d = 0; d < kDigits; ++d) {
-            long long dg;
+            int dg;
             if (nd == 3) { if (d < 2) { dg = ((v + 128) & 255) - 128; v = (v - dg) >> 8; } else { dg = v; v = 0; } }    // base 256, plane 3 = 0
             else if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
             w[d][j >> 2] |= ((unsigned)(dg & 0xff)) << (8 * (j & 3));

@@ -134,6 +134,7 @@ struct gpca_handle {
     double* d_amax_run = nullptr;    // [2][32] running column abs-max over the panels of a streamed K1 sweep
     double* d_yint = nullptr; size_t cap_yint = 0;   // [halves][N][32] integer partial sums of a streamed K2 sweep
     double* d_status = nullptr;      // [16] status word the ranks agree on
+    double* h_status = nullptr;      // pinned [32]: contribution | agreed histogram
     // persistent scratch of the pull API (no allocation per call)
     int64_t *d_blk_rows = nullptr, *d_blk_cols = nullptr; float* d_blk_out = nullptr; unsigned long long* d_blk_err = nullptr;
     size_t cap_blk_rows = 0, cap_blk_cols = 0, cap_blk_out = 0;
@@ -349,7 +350,7 @@ extern "C" int gpca_destroy(gpca_handle* h) {
       for (auto e : h->ev_pool) (void)hipEventDestroy(e);
       if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
       free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
-      dfree(h->d_blk_rows); dfree(h->d_blk_cols); dfree(h->d_blk_out); dfree(h->d_blk_err); dfree(h->d_status);
+      dfree(h->d_blk_rows); dfree(h->d_blk_cols); dfree(h->d_blk_out); dfree(h->d_blk_err); dfree(h->d_status); if (h->h_status) { (void)hipHostFree(h->h_status); h->h_status = nullptr; }
       (void)hipStreamDestroy(h->st);
     }
     delete h;
@@ -905,6 +906,7 @@ extern "C" int gpca_comm_init(gpca_handle* h, int32_t world, int32_t rank, const
         return fail(h, GPCA_ERR_RCCL, m);
     }
     if (!h->d_status) HIPCHK(hipMalloc((void**)&h->d_status, 16 * sizeof(double)));   // allocated here so that the agreement itself cannot run out of memory
+    if (!h->h_status) HIPCHK(hipHostMalloc((void**)&h->h_status, 32 * sizeof(double), hipHostMallocDefault));
     h->world = world; h->rank = rank; h->snp_offset = snp_offset; h->hook = nullptr;
     return GPCA_OK;
 }
@@ -915,6 +917,7 @@ extern "C" int gpca_set_allreduce_hook(gpca_handle* h, gpca_allreduce_fn fn, voi
     LOCK(h);
     HIPCHK(hipSetDevice(h->device));
     if (!h->d_status) HIPCHK(hipMalloc((void**)&h->d_status, 16 * sizeof(double)));
+    if (!h->h_status) HIPCHK(hipHostMalloc((void**)&h->h_status, 32 * sizeof(double), hipHostMallocDefault));
     h->hook = fn; h->hook_user = user; h->world = world; h->rank = rank; h->snp_offset = snp_offset;
     return GPCA_OK;
 }
@@ -958,15 +961,15 @@ static hipError_t stream_wait(gpca_handle* h) {
 static int agree_status(gpca_handle* h, int local_rc, const char* where) {
     if (!multi_rank(h)) return local_rc;
     const std::string own = h->err;
-    double v[16];
-    for (double& x : v) x = 0.0;
-    v[local_rc == GPCA_OK ? 0 : std::min(15, -local_rc)] = 1.0;
-    if (!h->d_status) return fail(h, GPCA_ERR_STATE, "agree_status: no status buffer (gpca_comm_init / gpca_set_allreduce_hook allocate it)");
-    HIPCHK(hipMemcpyAsync(h->d_status, v, sizeof v, hipMemcpyHostToDevice, h->st));
-    HIPCHK(hipStreamSynchronize(h->st));
+    if (!h->d_status || !h->h_status) return fail(h, GPCA_ERR_STATE, "agree_status: no status buffer (gpca_comm_init / gpca_set_allreduce_hook allocate it)");
+    double* v = h->h_status + 16;
+    for (int i = 0; i < 16; ++i) h->h_status[i] = 0.0;
+    h->h_status[local_rc == GPCA_OK ? 0 : std::min(15, -local_rc)] = 1.0;
+    // pinned staging both ways and one wait: H2D, exchange and D2H are stream-ordered
+    HIPCHK(hipMemcpyAsync(h->d_status, h->h_status, 16 * sizeof(double), hipMemcpyHostToDevice, h->st));
     CHK(allreduce_f64(h, h->d_status, 16));
-    HIPCHK(hipMemcpyAsync(v, h->d_status, sizeof v, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(hipStreamSynchronize(h->st));
+    HIPCHK(hipMemcpyAsync(v, h->d_status, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(stream_wait(h));
     int agreed = GPCA_OK;
     for (int i = 15; i >= 1; --i) if (v[i] > 0.5) agreed = -i;    // ends on the smallest index = GPCA_ERR_BAD_ARG first ... any is fine, all ranks pick the same
     if (agreed == GPCA_OK) return GPCA_OK;
@@ -979,29 +982,123 @@ static int agree_status(gpca_handle* h, int local_rc, const char* where) {
 }
 
 // ---- small dense (host, f64) ----------------------------------------------------------------------------------
-static void jacobi_eigh(std::vector<double>& A, std::vector<double>& V, std::vector<double>& w, int n) {
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int i = 0; i < n; ++i) { dg += A[i*n+i] * A[i*n+i]; for (int j = i + 1; j < n; ++j) off += A[i*n+j] * A[i*n+j]; }
-        if (off <= 1e-30 * dg || off == 0.0) break;
-        for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
-            const double apq = A[p * n + q];
-            if (apq == 0.0) continue;
-            const double theta = (A[q*n+q] - A[p*n+p]) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-            const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-            for (int k = 0; k < n; ++k) { const double a = A[k*n+p], b = A[k*n+q]; A[k*n+p] = c*a - s*b; A[k*n+q] = s*a + c*b; }
-            for (int k = 0; k < n; ++k) { const double a = A[p*n+k], b = A[q*n+k]; A[p*n+k] = c*a - s*b; A[q*n+k] = s*a + c*b; }
-            for (int k = 0; k < n; ++k) { const double a = V[k*n+p], b = V[k*n+q]; V[k*n+p] = c*a - s*b; V[k*n+q] = s*a + c*b; }
+// Symmetric eigenproblem of the l x l Gram of the projection (l <= 64): Householder tridiagonalisation + implicit QL
+// (the EISPACK tred2 / tql2 pair).  It replaced a cyclic Jacobi solver: at l = 30 Jacobi's ~8 sweeps of 435 rotations kept
+// the stream idle for ~190 us per call while the host worked; this pair needs ~20 us.  (The parity checker of tests/ uses LAPACK,
+// oracle/oracle.py:rsvd -- no code in common.)  A: symmetric, row-major, destroyed; V: eigenvectors in columns; w: eigenvalues,
+// sorted descending.
+static void tred2(int n, double* V, double* d, double* e) {
+    for (int j = 0; j < n; ++j) d[j] = V[(n - 1) * n + j];
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = V[(i - 1) * n + j]; V[i * n + j] = 0.0; V[j * n + i] = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g; h -= f * g; d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; V[j * n + i] = f; g = e[j] + V[j * n + j] * f;
+                for (int k = j + 1; k <= i - 1; ++k) { g += V[k * n + j] * d[k]; e[k] += V[k * n + j] * f; }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; g = e[j];
+                for (int k = j; k <= i - 1; ++k) V[k * n + j] -= (f * e[k] + g * d[k]);
+                d[j] = V[(i - 1) * n + j]; V[i * n + j] = 0.0;
+            }
         }
+        d[i] = h;
     }
-    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
-    for (int i = 0; i < n - 1; ++i) {
+    for (int i = 0; i < n - 1; ++i) {        // accumulate the transformations
+        V[(n - 1) * n + i] = V[i * n + i]; V[i * n + i] = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = V[k * n + (i + 1)] / h;
+            for (int j = 0; j <= i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += V[k * n + (i + 1)] * V[k * n + j];
+                for (int k = 0; k <= i; ++k) V[k * n + j] -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) V[k * n + (i + 1)] = 0.0;
+    }
+    for (int j = 0; j < n; ++j) { d[j] = V[(n - 1) * n + j]; V[(n - 1) * n + j] = 0.0; }
+    V[(n - 1) * n + (n - 1)] = 1.0; e[0] = 0.0;
+}
+static void tql2(int n, double* V, double* d, double* e) {
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n - 1 && std::fabs(e[m]) > eps * tst1) ++m;     // e[n-1] = 0 ends the search
+        if (m > l) {
+            int iter = 0;
+            do {
+                ++iter;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r); d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i]; h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r; s = e[i] / r; c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        h = V[k * n + i + 1];
+                        V[k * n + i + 1] = s * V[k * n + i] + c * h;
+                        V[k * n + i] = c * V[k * n + i] - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p; d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1 && iter < 200);
+        }
+        d[l] += f; e[l] = 0.0;
+    }
+}
+static void host_eigh_desc(std::vector<double>& A, std::vector<double>& V, std::vector<double>& w, int n) {
+    std::vector<double> e((size_t)n);
+    V = A;
+    if (n == 1) { w[0] = A[0]; V[0] = 1.0; return; }
+    tred2(n, V.data(), w.data(), e.data());
+    tql2(n, V.data(), w.data(), e.data());
+    for (int i = 0; i < n - 1; ++i) {        // selection sort, descending
         int m = i;
         for (int j = i + 1; j < n; ++j) if (w[j] > w[m]) m = j;
-        if (m != i) { std::swap(w[i], w[m]); for (int k = 0; k < n; ++k) std::swap(V[k*n+i], V[k*n+m]); }
+        if (m != i) { std::swap(w[i], w[m]); for (int k = 0; k < n; ++k) std::swap(V[k * n + i], V[k * n + m]); }
     }
+}
+// test hook (host only, no GPU): eigen-decomposition of a symmetric n x n row-major matrix, eigenvalues descending
+extern "C" int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, double* v) {
+    if (!a_sym || !w || !v || n < 1 || n > 64) return GPCA_ERR_BAD_ARG;
+    std::vector<double> A(a_sym, a_sym + (size_t)n * n), V((size_t)n * n), W((size_t)n);
+    host_eigh_desc(A, V, W, n);
+    std::copy(W.begin(), W.end(), w); std::copy(V.begin(), V.end(), v);
+    return GPCA_OK;
 }
 
 // ---- rsvd stages -----------------------------------------------------------------------------------------------
@@ -1314,7 +1411,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
 #undef LOCAL
 #undef EXCHANGE
     for (int a2 = 0; a2 < l; ++a2) for (int c = 0; c < l; ++c) C[(size_t)a2 * l + c] = 0.5 * (Wfull[(size_t)a2 * L + c] + Wfull[(size_t)c * L + a2]);
-    jacobi_eigh(C, V, w, l);
+    host_eigh_desc(C, V, w, l);
     h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
     for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
     for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);

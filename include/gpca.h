@@ -154,6 +154,10 @@ GPCA_API int gpca_get_snp_qc_detail(gpca_handle* h, uint32_t* counts, uint8_t* r
 GPCA_API int gpca_set_standardization(gpca_handle* h, const float* mu, const float* sigma, const uint8_t* keep);
 /* Current parameters, length M each (any may be NULL): what gpca_snp_stats computed or gpca_set_standardization set. */
 GPCA_API int gpca_get_standardization(gpca_handle* h, float* mu, float* sigma, uint8_t* keep);
+/* Host helper (no GPU): the symmetric eigen-solver gpca_rsvd uses for its l x l host step (Householder tridiagonalisation +
+ * implicit QL), exposed so that CPU-only tests can pin it against LAPACK.  a_sym: n x n row-major (n <= 64); w: eigenvalues
+ * descending; v: eigenvectors in columns, row-major. */
+GPCA_API int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, double* v);
 /* Host helper, same branches as prepare.rs:1641-1745. */
 GPCA_API double gpca_hwe_chi_squared_p_value(uint64_t n_hom1, uint64_t n_het, uint64_t n_hom2);
 
