@@ -249,3 +249,43 @@ def test_engine_config3_full_precision(gpca, oracle):
             assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
             assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < 1e-4
             assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"][kept]) < 1e-4
+
+
+def test_vcf_fast_path_equals_per_sample_rules(tmp_path):
+    """The vectorised GT-first path against the per-sample rule (_gt_to_dosage, vcf.rs:52-63) on random records, including
+    broken genotypes that must drop the variant; and a throughput floor so that a chr22-scale file stays usable."""
+    import time
+    rng = np.random.default_rng(0)
+    ns, nv = 300, 400
+    names = [f"S{i}" for i in range(ns)]
+    gts = np.array(["0|0", "0|1", "1|0", "1|1", "0/1", "1/1"])
+    bad = ["./.", "0|2", "1", "0|1|1", ".|1", "01"]
+    lines, expect = [], []
+    for v in range(nv):
+        g = gts[rng.integers(0, len(gts), ns)].tolist()
+        fmt = ["GT", "GT:DP", "GT:DP:GQ"][v % 3]
+        if v % 7 == 3:
+            g[int(rng.integers(0, ns))] = bad[v % len(bad)]
+        fields = [x + ("" if fmt == "GT" else ":7" + (":30" if fmt.endswith("GQ") else "")) for x in g]
+        lines.append(f"1\t{v + 1}\t.\tA\tC\t.\t.\t.\t{fmt}\t" + "\t".join(fields))
+        d = [gio._gt_to_dosage(x) for x in g]
+        if None not in d:
+            af = sum(d) / (2 * ns)
+            if min(af, 1 - af) >= 0.01:
+                expect.append((f"1:{v + 1}:A:C", d))
+    p = tmp_path / "r.vcf"
+    p.write_text("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n" + "\n".join(lines) + "\n")
+    samples, ids, G = gio.read_vcf(str(p), 0.01)
+    assert samples == names and ids == [e[0] for e in expect]
+    assert np.array_equal(G, np.array([e[1] for e in expect], np.int8))
+    # throughput: 2 000 variants x 2 504 samples (the 1000 Genomes sample count), GT-only columns
+    ns2, nv2 = 2504, 2000
+    row = "\t".join(gts[rng.integers(0, 4, ns2)].tolist())
+    with open(tmp_path / "big.vcf", "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"s{i}" for i in range(ns2)) + "\n")
+        for v in range(nv2):
+            f.write(f"22\t{v + 1}\t.\tA\tG\t.\t.\t.\tGT\t{row}\n")
+    t0 = time.perf_counter()
+    _, ids2, G2 = gio.read_vcf(str(tmp_path / "big.vcf"), 0.0)
+    dt = time.perf_counter() - t0
+    assert G2.shape == (nv2, ns2) and dt < 5.0, dt          # 5M genotypes; the per-genotype loop needed ~10 s for this
