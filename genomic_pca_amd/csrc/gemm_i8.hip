@@ -906,22 +906,10 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
     return r;
 }
 
-// State a wave carries from one DMA round into the next when the rounds are chained: where it stands in its ring and the two
-// operands it has already read ahead.  Chaining: the last S refills of a round (which otherwise wrap around to stage 0 of the
-// same tiles and are thrown away) fetch the first units of the NEXT round's tiles, and the last plane prefetch is the next
-// round's stage 0 anyway -- so the next round starts with its prologue already in flight behind this round's epilogue instead
-// of a cold ring.  The hand-counted waits stay valid: extra vector-memory operations (the epilogue's stores, the r/b row
-// loads) only make a counted wait stricter.  Bit-identical to the unchained form (test_alternative_kernels_same_answer).
-// MEASURED (scripts/gpu_ab_chain.sh, C2, same box, 10 steps each): 1.745 / 1.735 ms per launch chained vs 1.756 / 1.725
-// unchained -- no gain: the round boundaries are not what holds K1 at 5.9 TB/s, its sustained DMA rate is.  Off by default
-// (GPCA_GQ_CHAIN=1 enables it).
-struct GqdCarry { uint32_t rslot; i32x4 gcur, gnxt; int primed; };
-
 template <int NT, int S>
 __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
                                           const int8_t* __restrict__ Qd, GqdSmemT<S>* sm, int wv, int lane, int c, int h,
-                                          int64_t unit0, int nvalid, int64_t unit0_next, int nvalid_next, GqdCarry& cy, double qs,
-                                          const float* __restrict__ rv,
+                                          int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float* __restrict__ cunit, float& amax) {
     constexpr int R = 4;
@@ -936,13 +924,8 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     const uint32_t gvo_o = (uint32_t)(lane >> 3) * ld32 + 16u * (uint32_t)((lane & 7) ^ (lane >> 4) ^ 4);
     const uint32_t qvo = (uint32_t)(lane * 16);
     uint32_t toff[R];                                   // wave-uniform byte offset of tile t (tiles past the range: tile 0)
-    uint32_t toffn[R];                                  // the same for the next chained round's tiles, relative to THIS round's row 0
 #pragma unroll
-    for (int t = 0; t < R; ++t) {
-        toff[t] = (uint32_t)(t < nvalid ? 32 * t : 0) * ld32;
-        toffn[t] = nvalid_next >= 0 ? (uint32_t)((unit0_next - unit0) * 32 + (t < nvalid_next ? 32 * t : 0)) * ld32 : toff[t];
-    }
-    int wrapped = 0;                                    // refills have passed the last stage of this round
+    for (int t = 0; t < R; ++t) toff[t] = (uint32_t)(t < nvalid ? 32 * t : 0) * ld32;
     // r and b of the round's rows, one row per lane (row 32 t + c), requested before anything else: the epilogue picks them up
     // with a cross-lane read instead of 32 dependent global loads per tile at the end of the round
     float rrow[R], brow[R];
@@ -970,7 +953,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     // fill unit (stage st, tile t) into ring slot `slot`
 #define GQD_ISSUE_G(ST, T, SLOT)                                                                          \
     {                                                                                                     \
-        const uint32_t so_ = (wrapped ? toffn[(T)] : toff[(T)]) + (uint32_t)(ST) * 128u;                  \
+        const uint32_t so_ = toff[(T)] + (uint32_t)(ST) * 128u;                                           \
         const uint32_t la_ = lds_g + (uint32_t)(SLOT) * 4096u;                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma<NT>(la_ + 1024u * i, (i & 1) ? gvo_o : gvo_e, rg, so_ + 8u * i * ld32); \
     }
@@ -982,18 +965,15 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     const int64_t s1 = nstage > 1 ? 1 : 0;
     // ring of S slots: the unit consumed is re-filled with the unit S ahead; S - 4 units precede Q(0) in the prologue so
     // that the steady-state counts hold from the first stage on (S = 6: G0 G1 Q0 G2..G5;  S = 7: G0 G1 G2 Q0 G3..G6)
-    const int primed = cy.primed;       // (wave-uniform) the previous round of the chain already issued this round's prologue
-    if (!primed) {
-        GQD_ISSUE_G(0, 0, 0) GQD_ISSUE_G(0, 1, 1)
-        if constexpr (S == 7) GQD_ISSUE_G(0, 2, 2)
-        GQD_ISSUE_Q(0, 0)
-        if constexpr (S == 6) { GQD_ISSUE_G(0, 2, 2) GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) }
-        else { GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) GQD_ISSUE_G(s1, 2, 6) }
-    }
+    GQD_ISSUE_G(0, 0, 0) GQD_ISSUE_G(0, 1, 1)
+    if constexpr (S == 7) GQD_ISSUE_G(0, 2, 2)
+    GQD_ISSUE_Q(0, 0)
+    if constexpr (S == 6) { GQD_ISSUE_G(0, 2, 2) GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) }
+    else { GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) GQD_ISSUE_G(s1, 2, 6) }
     int64_t ist = s1;        // next unit to issue: (stage ist, tile it), always into the slot just consumed
     int it = S - 4;
-    uint32_t rslot = primed ? cy.rslot : 0u;      // slot of the unit being consumed
-    i32x4 gcur = cy.gcur, gnxt = cy.gnxt;
+    uint32_t rslot = 0;      // slot of the unit being consumed
+    i32x4 gcur, gnxt;
 
     for (int64_t st = 0; st < nstage; ++st) {
         asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");      // Q(st) landed in every wave's plane
@@ -1003,7 +983,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int d = 0; d < kDigits; ++d) q[s4][d] = sm->q[st & 1][s4][d][lane];
-        if (st == 0 && !primed) {                        // unit 0 (slot 0) landed with Q(0); a chained round has read them ahead already
+        if (st == 0) {                                   // unit 0 (slot 0) landed with Q(0)
             gcur = *reinterpret_cast<const i32x4*>(gl + loff[0]);
             gnxt = *reinterpret_cast<const i32x4*>(gl + loff[1]);
         }
@@ -1033,18 +1013,14 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                     // every read of this unit has returned (its last operand fed the MFMAs above): re-fill its slot
                     asm volatile("" :: "v"(gcur));
                     GQD_ISSUE_G(ist, it, rslot)
-                    if (++it == R) { it = 0; if (ist + 1 < nstage) ist = ist + 1; else { ist = 0; wrapped = 1; } }
+                    if (++it == R) { it = 0; ist = ist + 1 < nstage ? ist + 1 : 0; }
                 }
                 gcur = gnxt; gnxt = gfar;
             }
             rslot = nslot;
         }
     }
-    if (nvalid_next >= 0) { cy.primed = 1; cy.rslot = rslot; cy.gcur = gcur; cy.gnxt = gnxt; }   // the ring keeps turning into the next round
-    else {
-        cy.primed = 0;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // ring and plane slots quiescent before a register-staged round / the end
-    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // ring and plane slots quiescent before the next round
 #undef GQD_ISSUE_G
 #undef GQD_ISSUE_Q
 #pragma unroll
@@ -1073,7 +1049,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
-                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt, int chain) {
+                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmemT<S>* sm = reinterpret_cast<GqdSmemT<S>*>(gqd_smem);
     i32x4 (*tds)[4][kDigits][64] = sm->q;
@@ -1086,25 +1062,16 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
     const float sj = sv[c];
     const double qs = qscale[c];
     int64_t u = u0;
-    GqdCarry cy; cy.primed = 0; cy.rslot = 0; cy.gcur = i32x4{0, 0, 0, 0}; cy.gnxt = i32x4{0, 0, 0, 0};
-    // this wave's tiles of the DMA round that starts at unit uu (a short last round of 9..15 units is split evenly -- (3,3,2,2)
-    // rather than (4,4,2,0) -- so that no wave sweeps the samples for nothing while another carries a full load)
-    auto dma_share = [&](int64_t uu, int64_t& mine, int& nv) {
-        const int64_t rem_ = u1 - uu;
-        const int64_t take_ = rem_ < 16 ? rem_ : 16;
-        const int64_t base = take_ >> 2, extra = take_ & 3;
-        mine = uu + wv * base + (wv < extra ? wv : extra);
-        nv = (int)(base + (wv < extra ? 1 : 0));
-        return take_;
-    };
     while (u < u1) {
         const int64_t rem = u1 - u;
         if (rem > 8) {           // up to 4 tiles per wave, genotypes by LDS-DMA
-            int64_t mine, mine_next = 0; int nv, nv_next = -1;
-            const int64_t take = dma_share(u, mine, nv);
-            // chain into the next round when that is a DMA round too (and the row offsets between the two fit 32 bits comfortably)
-            if (chain && u1 - (u + take) > 8 && 1024 * ldg < ((int64_t)1 << 31)) (void)dma_share(u + take, mine_next, nv_next);
-            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, mine_next, nv_next, cy, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
+            // a short last round (9..15 units) is split evenly -- (3,3,2,2) rather than (4,4,2,0) -- so that no wave sweeps
+            // the samples for nothing while another carries a full load
+            const int64_t take = rem < 16 ? rem : 16;
+            const int64_t base = take >> 2, extra = take & 3;
+            const int64_t mine = u + wv * base + (wv < extra ? wv : extra);
+            const int nv = (int)(base + (wv < extra ? 1 : 0));
+            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
             u += take;
         } else if (rem > 4) {    // tails: the register-staged rounds
             const int64_t mine = u + 2 * wv;
@@ -1132,7 +1099,7 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
 #define GPCA_GQD(NTV, SV)                                                                                                       \
     {                                                                                                                          \
         hipLaunchKernelGGL((k_gq_d<NTV, SV>), grid, blk, sizeof(GqdSmemT<SV>), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, \
-                           Tout, cpart, apart, scale_out, ldt, ko.gq_chain);                                                   \
+                           Tout, cpart, apart, scale_out, ldt);                                                                \
     }
     if (slots == 7) { if (g_dma_nt) GPCA_GQD(1, 7) else GPCA_GQD(0, 7) }
     else { if (g_dma_nt) GPCA_GQD(1, 6) else GPCA_GQD(0, 6) }

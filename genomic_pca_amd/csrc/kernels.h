@@ -18,7 +18,6 @@ struct KernelOpts {
     int dma_nt = 1;      // GPCA_GQ_DMA_NT  : nt on the LDS-DMA genotype streams (k_gq_d, k_gtt_d)
     int gq_r = 4;        // GPCA_GQ_R       : max tiles per wave in k_gq_x
     int gq_slots = 6;    // GPCA_GQ_SLOTS   : ring slots per wave in k_gq_d (6 or 7)
-    int gq_chain = 0;    // GPCA_GQ_CHAIN   : 1 = k_gq_d keeps its DMA ring turning from one round into the next (measured: no gain, off)
     int gtt_xcd = 1;     // GPCA_GTT_XCD    : XCD-aware n-group order in k_gtt_d / k_gtt_p
     int gttx_xcd = 0;    // GPCA_GTTX_XCD   : the same in the register-staged k_gtt_x (measured: no gain there)
 };

@@ -145,6 +145,35 @@ __global__ __launch_bounds__(256, 1) void k_read_cols_wide(const char* __restric
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
 }
+// K1's DMA fill shape generalised: one wave instruction (64 lanes x 16 B = 1 KiB) covers ROWS = 1024 / WB rows x WB contiguous
+// bytes (WB = 128: 8 rows x one line, what k_gq_d issues; 256: 4 rows x two lines; 512: 2 rows x four lines).  A wave owns
+// 32*R rows and sweeps the columns WB bytes at a time; NT: non-temporal.
+template <int R, int WB, int NT>
+__global__ __launch_bounds__(256, 1) void k_read_pieces(const char* __restrict__ p, int64_t M, int64_t ld, int* __restrict__ out) {
+    constexpr int ROWS = 1024 / WB, LPR = WB / 16;     // rows per instruction, lanes per row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t units = M / (32 * R);
+    i32x4 acc = {0, 0, 0, 0};
+    for (int64_t u = (units * wave) / waves; u < (units * (wave + 1)) / waves; ++u) {
+        const char* base = p + u * 32 * R * ld;
+        for (int64_t col = 0; col < ld; col += WB) {
+            i32x4 v[R][32 / ROWS];
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+#pragma unroll
+                for (int j = 0; j < 32 / ROWS; ++j) {
+                    const i32x4* q = reinterpret_cast<const i32x4*>(base + (int64_t)(32 * t + ROWS * j + lane / LPR) * ld + col + 16 * (lane % LPR));
+                    v[t][j] = NT ? __builtin_nontemporal_load(q) : *q;
+                }
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+#pragma unroll
+                for (int j = 0; j < 32 / ROWS; ++j) acc ^= v[t][j];
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
 template <typename F> static float time_ms(F f, int reps) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -201,6 +230,18 @@ int main() {
         float b2 = time_ms([&] { hipLaunchKernelGGL((k_read_cols_wide<8, 1>), dim3(g), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
         printf("column slabs (K2 plan): dword loads NB4 %.2f  NB4 nt %.2f  NB2 nt %.2f | b128 pieces NB4 %.2f  NB4 nt %.2f  NB8 nt %.2f TB/s\n",
                gb / a0 * 1e-9, gb / a1 * 1e-9, gb / a2 * 1e-9, gb / b0 * 1e-9, gb / b1 * 1e-9, gb / b2 * 1e-9);
+    }
+    {
+        const int64_t M = 1000064, ld = 10240;
+        const double gb = (double)M * ld;
+#define PIECES(R, WB, NT) time_ms([&] { hipLaunchKernelGGL((k_read_pieces<R, WB, NT>), dim3(256), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5)
+        printf("K1 fill shape, 256 WGs, R2 (8 KiB in flight per wave-step): 8r x 128B %.2f nt %.2f | 4r x 256B %.2f nt %.2f | 2r x 512B %.2f nt %.2f TB/s\n",
+               gb / PIECES(2, 128, 0) * 1e-9, gb / PIECES(2, 128, 1) * 1e-9, gb / PIECES(2, 256, 0) * 1e-9, gb / PIECES(2, 256, 1) * 1e-9,
+               gb / PIECES(2, 512, 0) * 1e-9, gb / PIECES(2, 512, 1) * 1e-9);
+        printf("K1 fill shape, 256 WGs, R4 (16 KiB in flight per wave-step): 8r x 128B %.2f nt %.2f | 4r x 256B %.2f nt %.2f | 2r x 512B %.2f nt %.2f TB/s\n",
+               gb / PIECES(4, 128, 0) * 1e-9, gb / PIECES(4, 128, 1) * 1e-9, gb / PIECES(4, 256, 0) * 1e-9, gb / PIECES(4, 256, 1) * 1e-9,
+               gb / PIECES(4, 512, 0) * 1e-9, gb / PIECES(4, 512, 1) * 1e-9);
+        fflush(stdout);
     }
     {
         // Infinity Cache (256 MiB MALL).  (a) a buffer that stays resident, re-read 20 x back to back: the on-die read rate.

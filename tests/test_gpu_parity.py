@@ -751,8 +751,8 @@ def test_rsvd_bitwise_repeatable(gpca, prec, store, M, N, k):
                                  {"GPCA_LDS_PLANES": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GTT_WAVES": "64"},
                                  {"GPCA_GQ_SLOTS": "7", "GPCA_GQ_WAVES": "8"}, {"GPCA_GTT_XCD": "0"}, {"GPCA_GQ_DMA_NT": "0"},
                                  {"GPCA_GQ_DMA": "0", "GPCA_GQ_R": "2"}, {"GPCA_LDS_PLANES": "0", "GPCA_STREAM_NT": "1"},
-                                 {"GPCA_GTT_DMA": "0", "GPCA_GTTX_XCD": "1"}, {"GPCA_GQ_CHAIN": "1"},
-                                 {"GPCA_GQ_CHAIN": "1", "GPCA_GQ_WAVES": "8"}, {"GPCA_GQ_CHAIN": "1", "GPCA_GQ_WAVES": "12", "GPCA_GQ_SLOTS": "7"}])
+                                 {"GPCA_GTT_DMA": "0", "GPCA_GTTX_XCD": "1"},
+                                 {"GPCA_GQ_WAVES": "12", "GPCA_GQ_SLOTS": "7"}, {"GPCA_GQ_WAVES": "8", "GPCA_GQ_DMA_NT": "0"}])
 def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     """Register-staged (k_gq_x / k_gtt_x) and per-wave-plane (k_gq_i8 / k_gtt_i8) kernels, and a tiny grid that forces
     full LDS-DMA rounds on a small matrix, against the default configuration: the integer products are exact, so only
