@@ -97,7 +97,8 @@ struct gpca_handle {
     std::string err;
 
     // genotypes
-    int64_t M = 0, N = 0, ldg = 0, Mpad = 0;   // Mpad = round_up(M, 128): zero rows, so the GEMM loops carry no predicates
+    int64_t M = 0, N = 0, ldg = 0, Mpad = 0;   // ldg = samples padded to the kernels' tiles; Mpad = round_up(M, 128): zero rows, so the GEMM loops carry no predicates
+    int64_t ld8 = 0;           // byte pitch of the int8 rows: ldg, plus 256 when ldg / 256 is even (see alloc_genotypes)
     int8_t* dG = nullptr;      // GPCA_STORE_INT8: [Mpad][ldg]
     uint8_t* dG2 = nullptr;    // GPCA_STORE_2BIT: [Mpad][ld2], ld2 = ldg / 4, dosage codes (3 = missing)
     int64_t ld2 = 0;
@@ -376,16 +377,21 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
     h->M = M; h->N = N; h->Mpad = round_up(M, kGQRowsPerWave); h->pack_flags = 0;
     if (h->storage == GPCA_STORE_2BIT) {
-        h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4;
+        h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4; h->ld8 = h->ldg;
         if (!resident) return GPCA_OK;
         HIPCHK(hipMalloc((void**)&h->dG2, (size_t)h->Mpad * (size_t)h->ld2));
         if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG2 + (size_t)M * (size_t)h->ld2, 0, (size_t)(h->Mpad - M) * (size_t)h->ld2, h->st));
         return GPCA_OK;
     }
     h->ldg = round_up(N, kSamplePad); h->ld2 = 0;
+    // Row pitch vs HBM channel interleave: rows an EVEN multiple of 256 B apart (10 240 B for 10 000 samples) stream 2-5 % slower
+    // than rows an odd multiple apart (profiles/r1_kbench_summary.md section 6): 8 rows of one DMA piece then spread over fewer
+    // channels.  The pitch gets one extra 256-byte block in that case; the kernels never read past ldg.
+    h->ld8 = ((h->ldg / 256) & 1) ? h->ldg : h->ldg + 256;
+    if (getenv("GPCA_PITCH_PAD") && atoi(getenv("GPCA_PITCH_PAD")) == 0) h->ld8 = h->ldg;
     if (!resident) return GPCA_OK;
-    HIPCHK(hipMalloc((void**)&h->dG, (size_t)h->Mpad * (size_t)h->ldg));
-    if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG + (size_t)M * (size_t)h->ldg, 0, (size_t)(h->Mpad - M) * (size_t)h->ldg, h->st));
+    HIPCHK(hipMalloc((void**)&h->dG, (size_t)h->Mpad * (size_t)h->ld8));
+    if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG + (size_t)M * (size_t)h->ld8, 0, (size_t)(h->Mpad - M) * (size_t)h->ld8, h->st));
     return GPCA_OK;
 }
 
@@ -425,8 +431,8 @@ extern "C" int gpca_upload_genotypes_i8(gpca_handle* h, const int8_t* src, int64
         HIPCHK(e);
         return rc;
     }
-    if (h->ldg != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ldg, h->st));
-    HIPCHK(hipMemcpy2DAsync(h->dG, (size_t)h->ldg, src, (size_t)ld, (size_t)N, (size_t)M, hipMemcpyHostToDevice, h->st));
+    if (h->ld8 != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ld8, h->st));
+    HIPCHK(hipMemcpy2DAsync(h->dG, (size_t)h->ld8, src, (size_t)ld, (size_t)N, (size_t)M, hipMemcpyHostToDevice, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
     return GPCA_OK;
 }
@@ -449,7 +455,7 @@ extern "C" int gpca_upload_bed2bit(gpca_handle* h, const uint8_t* bed_rows, int6
         e = hipMemcpyAsync(d_bed, bed_rows + (size_t)r0 * (size_t)bpr, (size_t)rows * (size_t)bpr, hipMemcpyHostToDevice, h->st);
         if (e != hipSuccess) break;
         if (h->storage == GPCA_STORE_2BIT) launch_bed_to_codes(h->st, d_bed, bpr, h->dG2 + (size_t)r0 * h->ld2, rows, N, h->ld2);   // stays 2-bit
-        else launch_bed_decode(h->st, d_bed, bpr, h->dG + (size_t)r0 * h->ldg, rows, N, h->ldg);
+        else launch_bed_decode(h->st, d_bed, bpr, h->dG + (size_t)r0 * h->ld8, rows, N, h->ld8);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(h->st);   // the staging buffer is reused; the host source may be pageable
     }
@@ -521,11 +527,11 @@ static int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, vo
             if (packed) {
                 launch_synth(st, f.d_scratch8, rows, h->N, h->ldg, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
                 launch_pack_i8(st, f.d_scratch8, h->ldg, (uint8_t*)dst, rows, h->N, h->ld2, f.d_flags);
-            } else launch_synth(st, (int8_t*)dst, rows, h->N, h->ldg, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
+            } else launch_synth(st, (int8_t*)dst, rows, h->N, h->ld8, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
             HIPCHK(hipGetLastError());
             return GPCA_OK;
         case GPCA_PANEL_SYNTH16:
-            launch_synth16(st, dst, packed ? 1 : 0, rows, h->N, packed ? h->ld2 : h->ldg, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
+            launch_synth16(st, dst, packed ? 1 : 0, rows, h->N, packed ? h->ld2 : h->ld8, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
             HIPCHK(hipGetLastError());
             return GPCA_OK;
         case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED: {
@@ -539,14 +545,14 @@ static int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, vo
             if (s.kind == GPCA_PANEL_HOST_BED) {
                 HIPCHK(hipMemcpyAsync(f.d_raw, f.h_stage[b], (size_t)rows * (size_t)f.stage_ld, hipMemcpyHostToDevice, st));
                 if (packed) launch_bed_to_codes(st, f.d_raw, f.stage_ld, (uint8_t*)dst, rows, h->N, h->ld2);
-                else launch_bed_decode(st, f.d_raw, f.stage_ld, (int8_t*)dst, rows, h->N, h->ldg);
+                else launch_bed_decode(st, f.d_raw, f.stage_ld, (int8_t*)dst, rows, h->N, h->ld8);
                 HIPCHK(hipGetLastError());
             } else if (packed) {
                 HIPCHK(hipMemcpy2DAsync(f.d_scratch8, (size_t)h->ldg, f.h_stage[b], (size_t)f.stage_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
                 launch_pack_i8(st, f.d_scratch8, h->ldg, (uint8_t*)dst, rows, h->N, h->ld2, f.d_flags);
                 HIPCHK(hipGetLastError());
             } else {
-                HIPCHK(hipMemcpy2DAsync(dst, (size_t)h->ldg, f.h_stage[b], (size_t)f.stage_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpy2DAsync(dst, (size_t)h->ld8, f.h_stage[b], (size_t)f.stage_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
             }
             HIPCHK(hipEventRecord(f.ev_stage[b], st)); f.stage_pending[b] = 1;
             return GPCA_OK;
@@ -561,13 +567,13 @@ extern "C" int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* sr
     CHK(check_source(h, src, "gpca_load_from_source"));
     CHK(alloc_genotypes(h, M, N));
     const bool packed = h->storage == GPCA_STORE_2BIT;
-    if (!packed && h->ldg != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ldg, h->st));   // pad columns of host-copied rows
+    if (!packed && h->ld8 != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ld8, h->st));   // pad columns of host-copied rows
     const int64_t cr = pack_chunk_rows(h);
     Filler f;
     int rc = filler_open(h, f, *src, cr, h->st);
     for (int64_t r0 = 0; r0 < M && rc == GPCA_OK; r0 += cr) {
         const int64_t rows = std::min(cr, M - r0);
-        void* dst = packed ? (void*)(h->dG2 + (size_t)r0 * h->ld2) : (void*)(h->dG + (size_t)r0 * h->ldg);
+        void* dst = packed ? (void*)(h->dG2 + (size_t)r0 * h->ld2) : (void*)(h->dG + (size_t)r0 * h->ld8);
         rc = filler_fill(h, f, r0, rows, dst, h->st);
     }
     if (rc == GPCA_OK && f.d_flags) rc = finish_pack_flags(h, f.d_flags, h->st);
@@ -586,7 +592,7 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
     if (ring_slots < 2 || ring_slots > 16 || panel_rows < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_stream_open: ring_slots must be in [2, 16], panel_rows >= 0");
     CHK(alloc_genotypes(h, M, N, /*resident=*/false));
     const bool packed = h->storage == GPCA_STORE_2BIT;
-    const int64_t row_bytes = packed ? h->ld2 : h->ldg;
+    const int64_t row_bytes = packed ? h->ld2 : h->ld8;
     if (panel_rows == 0) {
         // K1 gives every wave 128 SNP rows and sweeps all samples with them: a panel needs gq_waves_target x 128 rows (131 072)
         // to fill the chip, however wide the rows are (a 1 GiB panel of 500k-sample rows holds 8k rows and leaves three quarters
@@ -638,7 +644,7 @@ static int for_each_panel(gpca_handle* h, F&& fn) {
     if (!h->sm.on) { const PanelView pv{h->dG, h->dG2, 0, h->M, h->Mpad, 0}; return fn(pv); }
     StreamState& sm = h->sm;
     const bool packed = h->storage == GPCA_STORE_2BIT;
-    const int64_t row_bytes = packed ? h->ld2 : h->ldg;
+    const int64_t row_bytes = packed ? h->ld2 : h->ld8;
     for (int p = 0; p < sm.n_panels; ++p) {
         const int64_t row0 = (int64_t)p * sm.panel_rows;
         const int64_t rows = std::min(sm.panel_rows, h->M - row0);
@@ -674,7 +680,7 @@ extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t l
         }
         return GPCA_OK;
     }
-    HIPCHK(hipMemcpy2D(out, (size_t)ld, h->dG, (size_t)h->ldg, (size_t)h->N, (size_t)h->M, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(out, (size_t)ld, h->dG, (size_t)h->ld8, (size_t)h->N, (size_t)h->M, hipMemcpyDeviceToHost));
     return GPCA_OK;
 }
 
@@ -730,7 +736,7 @@ extern "C" int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* m
                 launch_snp_stats_2bit(h->st, pv.g2, pv.rows, h->N, h->ld2, q, h->d_mu + o, h->d_sigma + o, h->d_r + o, h->d_b + o, h->d_keep + o,
                                       h->d_reason + o, h->d_counts + 4 * o, h->d_flags);
             else
-                launch_snp_stats(h->st, pv.g8, pv.rows, h->N, h->ldg, q, h->d_mu + o, h->d_sigma + o, h->d_r + o, h->d_b + o, h->d_keep + o,
+                launch_snp_stats(h->st, pv.g8, pv.rows, h->N, h->ld8, q, h->d_mu + o, h->d_sigma + o, h->d_r + o, h->d_b + o, h->d_keep + o,
                                  h->d_reason + o, h->d_counts + 4 * o, h->d_flags);
             HIPCHK(hipGetLastError());
             return GPCA_OK;
@@ -862,7 +868,7 @@ extern "C" int gpca_standardize_block(gpca_handle* h, const int64_t* snp_ids, in
     HIPCHK(hipMemcpyAsync(h->d_blk_cols, sample_ids, (size_t)nj * 8, hipMemcpyHostToDevice, h->st));
     HIPCHK(hipMemcpyAsync(h->d_blk_err, &err_idx, 8, hipMemcpyHostToDevice, h->st));
     if (h->storage == GPCA_STORE_2BIT) launch_standardize_block_2bit(h->st, h->dG2, h->ld2, h->d_mu, h->d_sigma, h->d_blk_rows, ns, h->d_blk_cols, nj, h->d_blk_out, h->d_blk_err);
-    else launch_standardize_block(h->st, h->dG, h->ldg, h->d_mu, h->d_sigma, h->d_blk_rows, ns, h->d_blk_cols, nj, h->d_blk_out, h->d_blk_err);
+    else launch_standardize_block(h->st, h->dG, h->ld8, h->d_mu, h->d_sigma, h->d_blk_rows, ns, h->d_blk_cols, nj, h->d_blk_out, h->d_blk_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&err_idx, h->d_blk_err, 8, hipMemcpyDeviceToHost, h->st));
     HIPCHK(hipMemcpyAsync(out, h->d_blk_out, (size_t)ns * (size_t)nj * 4, hipMemcpyDeviceToHost, h->st));
@@ -1115,14 +1121,14 @@ static int k2_panel(gpca_handle* h, const PanelView& pv, const int8_t* Td_half, 
     const int8_t* Td = Td_half + (size_t)(pv.row0 >> 5) * kPlaneBytesPerBlock;
     const bool packed = h->storage == GPCA_STORE_2BIT;
     if (h->lds_planes && h->gtt_dma && !packed) {
-        const int e = launch_gtt_d(h->st, pv.g8, h->ldg, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+        const int e = launch_gtt_d(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d launch failed (hip error " + std::to_string(e) + ")");
     } else if (((h->lds_planes && h->gtt_dma) || h->nd == 3) && packed) {   // (three planes: only this kernel)
         const int e = launch_gtt_p(h->st, pv.g2, h->ld2, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->nd, h->ko);
         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_p launch failed (hip error " + std::to_string(e) + ")");
-    } else if (h->lds_planes) launch_gtt_x(h->st, packed ? (const void*)pv.g2 : (const void*)pv.g8, packed, packed ? h->ld2 : h->ldg, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+    } else if (h->lds_planes) launch_gtt_x(h->st, packed ? (const void*)pv.g2 : (const void*)pv.g8, packed, packed ? h->ld2 : h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
     else if (packed) launch_gtt_2bit(h->st, pv.g2, h->ld2, pv.rows_pad, h->ldg, Td, h->dYpart64, plan);
-    else launch_gtt_i8(h->st, pv.g8, h->ldg, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+    else launch_gtt_i8(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
     HIPCHK(hipGetLastError());
     return GPCA_OK;
 }
@@ -1173,7 +1179,7 @@ static int stage_AtT_local(gpca_handle* h) {
     {
         const bool packed = h->storage == GPCA_STORE_2BIT;
         ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, packed ? elems / 4 : elems);
-        launch_gtt_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ldg, h->Mpad, h->ldg, h->dTb, h->L, h->dYpart, h->plan);
+        launch_gtt_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ld8, h->Mpad, h->ldg, h->dTb, h->L, h->dYpart, h->plan);
     }
     HIPCHK(hipGetLastError());
     launch_reduce_y(h->st, h->dYpart, h->plan.W, h->ldg, h->N, h->L, h->d_c, h->dY);
@@ -1207,11 +1213,11 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                     ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l / halves, by, nullptr, !streamed);
                     if (packed) launch_gq_2bit(h->st, pv.g2, h->ld2, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, h->nd, L);
                     else if (h->lds_planes && h->gq_dma) {
-                        const int e = launch_gq_d(h->st, pv.g8, h->ldg, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
+                        const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
                         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
                     }
-                    else if (h->lds_planes) launch_gq_x(h->st, pv.g8, h->ldg, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
-                    else launch_gq_i8(h->st, pv.g8, h->ldg, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, scale_out, L, h->ko);
+                    else if (h->lds_planes) launch_gq_x(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
+                    else launch_gq_i8(h->st, pv.g8, h->ld8, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, scale_out, L, h->ko);
                     HIPCHK(hipGetLastError());
                     if (streamed && scale_out && (packed || h->lds_planes)) {   // (streamed: the per-launch timer above is disabled) fold this panel's column abs-max before the next launch reuses ap
                         launch_absmax_fold(h->st, ap, plan.waves, h->d_amax_run + 32 * hf);
@@ -1234,7 +1240,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     {
         const bool packed = h->storage == GPCA_STORE_2BIT;
         ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, packed ? elems / 4 : elems);
-        launch_gq_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ldg, h->gqplan, h->ldg, h->dQ, h->L, h->d_r, h->d_b,
+        launch_gq_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ld8, h->gqplan, h->ldg, h->dQ, h->L, h->d_r, h->d_b,
                       h->d_s32, h->dT, scale_out ? h->dTb : nullptr, h->d_cpart);
     }
     HIPCHK(hipGetLastError());

@@ -21,8 +21,8 @@ for setting in (a, b):
     name, val = setting.split("=")
     os.environ[name] = val
     e = g.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_INT8)
+    e.synth_genotypes(M, N, 1, th)          # (GPCA_PITCH_PAD is read when the matrix is allocated)
     os.environ.pop(name)
-    e.synth_genotypes(M, N, 1, th)
     e.snp_stats(g.QcConfig.none(), fetch=False)
     e.rsvd(k, 10, 2, 1)
     e.enable_timings(True)

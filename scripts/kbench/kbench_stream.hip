@@ -181,7 +181,7 @@ template <typename F> static float time_ms(F f, int reps) {
     float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
 }
 int main() {
-    const int64_t bytes = 11LL << 30; const int64_t n16 = bytes / 16;
+    const int64_t bytes = 12LL << 30; const int64_t n16 = bytes / 16;
     i32x4* p; int* out; CK(hipMalloc(&p, bytes)); CK(hipMalloc(&out, 4)); CK(hipMemset(p, 1, bytes)); CK(hipMemset(out, 0, 4));
     const int grids[] = {1024, 16384};
     for (int g : grids) {
@@ -241,6 +241,19 @@ int main() {
         printf("K1 fill shape, 256 WGs, R4 (16 KiB in flight per wave-step): 8r x 128B %.2f nt %.2f | 4r x 256B %.2f nt %.2f | 2r x 512B %.2f nt %.2f TB/s\n",
                gb / PIECES(4, 128, 0) * 1e-9, gb / PIECES(4, 128, 1) * 1e-9, gb / PIECES(4, 256, 0) * 1e-9, gb / PIECES(4, 256, 1) * 1e-9,
                gb / PIECES(4, 512, 0) * 1e-9, gb / PIECES(4, 512, 1) * 1e-9);
+        fflush(stdout);
+    }
+    {
+        // Row pitch vs HBM channel interleave: the same 8-row x 128-B fill shape over rows 10 240 B apart (40 x 256 B: what a
+        // 10 000-sample int8 matrix padded to 256 gets) and over odd multiples of 256 B.
+        const int64_t M = 1000064;
+        for (int64_t ld : {10240, 10496, 10368, 12288, 12544}) {
+            const double gb = (double)M * ld;
+            float a = time_ms([&] { hipLaunchKernelGGL((k_read_pieces<4, 128, 1>), dim3(256), dim3(256), 0, 0, (const char*)p, M, ld, out); }, 5);
+            const int64_t rpw = 40064;
+            float b = time_ms([&] { hipLaunchKernelGGL((k_read_cols_wide<4, 1>), dim3((unsigned)(ld / 512 * 25)), dim3(256), 0, 0, (const char*)p, M, ld, rpw, out); }, 5);
+            printf("pitch %6lld B (%lld x 256): K1 fill shape nt %.2f TB/s | K2 column slabs nt %.2f TB/s\n", (long long)ld, (long long)(ld / 256), gb / a * 1e-9, gb / b * 1e-9);
+        }
         fflush(stdout);
     }
     {
