@@ -150,7 +150,8 @@ def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn
     th16 = g.synth_thresholds16(M, 3, seed=a.rfit_seed, snp_offset=snp_offset)
     eng = g.GpcaEngine(device=device, precision=g._lib.PREC_I8_EXACT, storage=g._lib.STORE_2BIT if storage == "2bit" else g._lib.STORE_INT8,
                        digit_planes=a.digit_planes if storage == "2bit" else 0)
-    eng.stream_open(g.PanelSource.synth16(th16, a.rfit_seed, snp_offset=snp_offset), M, N, panel_rows=a.panel_rows, ring_slots=a.ring)
+    eng.stream_open(g.PanelSource.synth16(th16, a.rfit_seed, snp_offset=snp_offset), M, N, panel_rows=a.panel_rows, ring_slots=a.ring,
+                    fused=not a.unfused)
     del th16
     t0 = time.perf_counter()
     eng.snp_stats(g.QcConfig.none(), fetch=False)
@@ -186,15 +187,17 @@ def streamed_summary(tim, steps, M, N, l, storage):
     """Per-step times of the streamed sweeps.  gemm_* records span a whole sweep over the panels on the compute stream (waits
     for panels included); panel_fill records are the generator's own kernel times on the fill stream."""
     fill = tim.get("panel_fill", {"total_ms": 0.0, "launches": 0, "bytes": 0.0})
-    gq, gt = tim["gemm_GQ"], tim["gemm_GtT"]
-    sweeps = (gq["launches"] + gt["launches"]) / steps
+    zero = {"total_ms": 0.0, "launches": 0}
+    gq, gt, gf = tim.get("gemm_GQ", zero), tim.get("gemm_GtT", zero), tim.get("gemm_fused", zero)
+    sweeps = (gq["launches"] + gt["launches"] + gf["launches"]) / steps      # = passes over the source per call
     per_b = 0.25 if storage == "2bit" else 1.0
-    gemm_ms = (gq["total_ms"] + gt["total_ms"]) / steps
+    gemm_ms = (gq["total_ms"] + gt["total_ms"] + gf["total_ms"]) / steps
     return {"sweeps_per_step": sweeps, "panel_fills_per_step": fill["launches"] / steps,
             "generator_ms_per_step": fill["total_ms"] / steps,
             "generator_rate_genotypes_per_s": (fill["bytes"] / (fill["total_ms"] * 1e-3)) if fill["total_ms"] else None,
-            "gemm_sweeps_ms_per_step": gemm_ms, "gemm_GQ_ms_per_sweep": gq["total_ms"] / gq["launches"],
-            "gemm_GtT_ms_per_sweep": gt["total_ms"] / gt["launches"],
+            "gemm_sweeps_ms_per_step": gemm_ms, "gemm_GQ_ms_per_sweep": gq["total_ms"] / max(gq["launches"], 1),
+            "gemm_GtT_ms_per_sweep": gt["total_ms"] / max(gt["launches"], 1),
+            "fused_power_iteration_ms_per_sweep": (gf["total_ms"] / gf["launches"]) if gf["launches"] else None,
             "hbm_GBs_per_sweep_algorithmic": M * N * per_b * (1 if l <= 32 else 2) / (gemm_ms / sweeps * 1e-3) / 1e9,
             "note": "fills run one panel ahead on a second stream; a sweep's span includes any wait for the generator"}
 
@@ -214,7 +217,7 @@ def streamed_main(a, g, rank, world, local_rank, dist, torch):
         per_step = dt / a.steps
         ssum = streamed_summary(tim, a.steps, M_local, N, l, a.storage)
         # dominant "kernel" of a streamed run = one sweep of the slower GEMM over all panels of this rank
-        dom = max(("gemm_GQ", "gemm_GtT"), key=lambda n_: tim[n_]["total_ms"] / tim[n_]["launches"])
+        dom = max((n_ for n_ in ("gemm_GQ", "gemm_GtT", "gemm_fused") if n_ in tim), key=lambda n_: tim[n_]["total_ms"] / tim[n_]["launches"])
         sweep_ms = tim[dom]["total_ms"] / tim[dom]["launches"]
         by = tim[dom]["bytes"] / tim[dom]["launches"]
         out = {"metric": "SNPs x samples / sec through rSVD at k=%d (streamed panels); max|dPC| vs ref" % k,
@@ -225,7 +228,7 @@ def streamed_main(a, g, rank, world, local_rank, dist, torch):
                                       f"panels generated on the device by Philox (GPCA_PANEL_SYNTH16) into a ring of {a.ring} HBM buffers",
                           "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample, "power_iters": a.power_iters,
                           "parallelism": f"snp-row-shards x{world}", "gemm_path": "i8", "residency": f"streamed/{a.storage}",
-                          "panel_rows": a.panel_rows, "ring": a.ring},
+                          "panel_rows": a.panel_rows, "ring": a.ring, "passes_over_the_source_per_call": ssum["sweeps_per_step"]},
                "roofline": {"bound": "hbm" if a.storage == "int8" else "mfma", "kernel": dom + " sweep over all panels",
                             "avg_launch_ms": sweep_ms, "achieved": by / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": by / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -263,6 +266,7 @@ def main():
     ap.add_argument("--streamed-extra", action="store_true", help="resident run: also time the same shape out-of-core (8 panels)")
     ap.add_argument("--panel-rows", type=int, default=0, help="--streamed: SNP rows per panel (0 = 131072 rows or what fits)")
     ap.add_argument("--ring", type=int, default=3, help="--streamed: panel buffers in the ring")
+    ap.add_argument("--unfused", action="store_true", help="--streamed: 6 passes per call (bit-identical to the resident engine) instead of 4")
     a = ap.parse_args()
 
     import genomic_pca_amd as g

@@ -360,6 +360,31 @@ void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const dou
     const int64_t total = N * 32;
     hipLaunchKernelGGL(k_finish_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Yint, N, c, tscale, Y, ldy);
 }
+// Fused streamed power iteration: every panel quantises its rows of T' against its OWN column maximum, so its integer sums carry
+// their own scale: Yacc[n][j] (+)= tscale_p[j] * sum_w Ypart[w][n][j]  (exact integer sum, one fma per panel, fixed panel order).
+__global__ __launch_bounds__(256) void k_accum_y_scaled(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
+                                                        const double* __restrict__ tscale, double* __restrict__ Yacc, int first) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * 32) return;
+    const int64_t stride = Npad * 32;
+    double s = 0.0;
+    for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
+    Yacc[e] = fma(tscale[e & 31], s, first ? 0.0 : Yacc[e]);
+}
+__global__ __launch_bounds__(256) void k_finish_y_sum(const double* __restrict__ Yacc, int64_t N, const double* __restrict__ cvec,
+                                                      double* __restrict__ Y, int64_t ldy) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * 32) return;
+    Y[(e >> 5) * ldy + (e & 31)] = cvec[e & 31] + Yacc[e];
+}
+void launch_accum_y_scaled(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first) {
+    const int64_t total = N * 32;
+    hipLaunchKernelGGL(k_accum_y_scaled, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
+}
+void launch_finish_y_sum(hipStream_t st, const double* Yacc, int64_t N, const double* c, double* Y, int64_t ldy) {
+    const int64_t total = N * 32;
+    hipLaunchKernelGGL(k_finish_y_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Yacc, N, c, Y, ldy);
+}
 // run[c] = max(run[c], max_p apart[p][c]): the column abs-max of T' over the panels seen so far (max is exact in any order)
 __global__ __launch_bounds__(1024) void k_absmax_fold(const double* __restrict__ apart, int64_t P, double* __restrict__ run) {
     __shared__ double red[1024];

@@ -84,6 +84,7 @@ struct StreamState {
     std::vector<char> free_pending;
     hipStream_t st_fill = nullptr;
     int64_t seq = 0;                 // panels filled so far: slot = seq % ring
+    int fused = 1;                   // power iterations read every panel once (K1 -> quantise -> K2 per panel): 4 passes per call, not 6
 };
 
 struct gpca_handle {
@@ -619,7 +620,7 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
     StreamState& sm = h->sm;
     sm.panel_rows = panel_rows;
     sm.n_panels = (int)((M + panel_rows - 1) / panel_rows);
-    sm.ring = ring_slots; sm.seq = 0;
+    sm.ring = ring_slots; sm.seq = 0; sm.fused = 1;
     HIPCHK(hipStreamCreateWithFlags(&sm.st_fill, hipStreamNonBlocking));
     sm.on = true;   // from here on stream_close() releases whatever was set up
     int rc = GPCA_OK;
@@ -636,6 +637,14 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
     if (rc == GPCA_OK && hipStreamSynchronize(sm.st_fill) != hipSuccess) rc = fail(h, GPCA_ERR_HIP, "gpca_stream_open: stream failed");
     if (rc != GPCA_OK) { std::string keep = h->err; stream_close(h); h->M = h->N = 0; h->err = keep; }
     return rc;
+}
+
+extern "C" int gpca_stream_set_fused(gpca_handle* h, int32_t fused) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    if (!h->sm.on) return fail(h, GPCA_ERR_STATE, "gpca_stream_set_fused: no panel stream open");
+    h->sm.fused = fused != 0;
+    return GPCA_OK;
 }
 
 // fn(view) once for the resident matrix, or once per panel (generated / copied one panel ahead on the fill stream)
@@ -1248,6 +1257,60 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
     return GPCA_OK;
 }
 
+// One power iteration Y = A^T (A Q) of a STREAMED matrix with every panel read once: K1 on the panel (its rows of T' = r o (A Q), its
+// units' shares of c, its column maxima), the panel's rows of T' quantised against the panel's own maxima, K2 on the same panel,
+// and the panel's integer sums added into Yacc with the panel's scale.  4 passes over the source per call instead of 6 -- the
+// "fused read" SURVEY.md 8(d) counts, which HBM-resident data cannot use (no on-chip room for the N x l accumulators) but a
+// panel that sits in HBM between its two kernels can.  Per-panel scales put the 28-bit fixed point on a per-panel grid, so the
+// result differs from the resident engine at the 1e-9 level, like a row-sharded run does; gpca_stream_set_fused(h, 0) selects
+// the 6-pass form that is bit-identical to the resident engine.
+static int stage_power_fused(gpca_handle* h) {
+    const double elems = (double)h->M * (double)h->N;
+    const int L = h->L, halves = L / 32;
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    const size_t qhalf = (size_t)h->ldg * 32 * kDigits, chalf = (size_t)h->Mpad, ahalf = (size_t)h->gqplan.waves * 32;
+    const size_t td_half = (size_t)h->Mpad * 32 * kDigits, yint_half = (size_t)h->N * 32;
+    {
+        const double by = packed ? elems / 4 : elems;
+        ScopedTimer sweep(h, "gemm_fused", 4.0 * elems * h->l, by * halves);
+        CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
+            const GqPlan plan1 = gq_plan(pv.rows_pad, h->gq_waves_target);
+            const Gtt8Plan plan2 = gtt8_plan(pv.rows_pad, h->ldg, h->gtt_waves_target);
+            const float* rr = h->d_r + pv.row0; const float* bb = h->d_b + pv.row0;
+            for (int hf = 0; hf < halves; ++hf) {
+                const int8_t* Qd = h->dQd + hf * qhalf;
+                float* Th = h->dT + (size_t)pv.row0 * L + 32 * hf;
+                float* cp = h->d_cpart + hf * chalf + (size_t)pv.row0;
+                double* ap = h->d_apart + hf * ahalf;
+                if (packed) launch_gq_2bit(h->st, pv.g2, h->ld2, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, h->nd, L);
+                else if (h->gq_dma) {
+                    const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
+                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
+                } else launch_gq_x(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
+                HIPCHK(hipGetLastError());
+                // this panel's rows of T' -> digit planes against this panel's column maxima
+                launch_quantize_f32_premax(h->st, Th, pv.rows_pad, pv.rows_pad, ap, plan1.waves, h->d_tscale + 32 * hf, h->d_tinv + 32 * hf,
+                                           h->dTd + hf * td_half + (size_t)(pv.row0 >> 5) * kPlaneBytesPerBlock, 0, h->nd, L);
+                HIPCHK(hipGetLastError());
+            }
+            for (int hf = 0; hf < halves; ++hf) {
+                CHK(k2_panel(h, pv, h->dTd + hf * td_half, plan2));
+                launch_accum_y_scaled(h->st, h->dYpart64, plan2.W, h->ldg, h->N, h->d_tscale + 32 * hf, h->d_yint + hf * yint_half, pv.index == 0);
+                HIPCHK(hipGetLastError());
+            }
+            return GPCA_OK;
+        }));
+    }
+    for (int hf = 0; hf < halves; ++hf) {
+        launch_sum_partials_f32(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, 32, h->d_c + 32 * hf, h->d_scratch64);
+        HIPCHK(hipGetLastError());
+        launch_finish_y_sum(h->st, h->d_yint + hf * yint_half, h->N, h->d_c + 32 * hf, h->dY + 32 * hf, L);
+        HIPCHK(hipGetLastError());
+    }
+    h->apart_valid = false;
+    return GPCA_OK;
+}
+
 // CholeskyQR2 of dY -> dQ (f32, padded), s = 1^T Q
 static int stage_orth(gpca_handle* h) {
     const int L = h->L, l = h->l;
@@ -1376,9 +1439,10 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     EXCHANGE(h->dY, h->N * (int64_t)L);
     LOCAL(stage_orth(h));
     // 2. power iterations
+    const bool fused = h->sm.on && h->sm.fused && (h->storage == GPCA_STORE_2BIT || h->lds_planes);   // (k_gq_i8 has no abs-max epilogue)
     for (int it = 0; it < power_iters; ++it) {
-        LOCAL(stage_AQ(h, 1));
-        LOCAL(stage_AtT_local(h));
+        if (fused) LOCAL(stage_power_fused(h));
+        else { LOCAL(stage_AQ(h, 1)); LOCAL(stage_AtT_local(h)); }
         EXCHANGE(h->dY, h->N * (int64_t)L);
         LOCAL(stage_orth(h));
     }

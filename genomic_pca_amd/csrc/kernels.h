@@ -143,6 +143,8 @@ void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad
 void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first);
 void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy = 32);
 void launch_absmax_fold(hipStream_t st, const double* apart, int64_t P, double* run);
+void launch_accum_y_scaled(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first);
+void launch_finish_y_sum(hipStream_t st, const double* Yacc, int64_t N, const double* c, double* Y, int64_t ldy = 32);
 int64_t absmax_num_parts(int64_t rows);
 // X [rows][32] row-major -> digit planes Xd [rows_pad/32][kDigits][64][16 B]; scale[j] = colmax_j / S, inv = 1/scale
 // layout 0: 32 consecutive rows per block; layout 1: the MFMA-step order of the packed (2-bit) G Q kernel

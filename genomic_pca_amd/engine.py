@@ -178,14 +178,16 @@ class GpcaEngine:
             raise src.error
         self._chk(rc)
 
-    def stream_open(self, src: "PanelSource", M: int, N: int, panel_rows: int = 0, ring_slots: int = 3):
+    def stream_open(self, src: "PanelSource", M: int, N: int, panel_rows: int = 0, ring_slots: int = 3, fused: bool = True):
         """Out-of-core mode: later snp_stats / rsvd / transform calls walk the matrix panel by panel through a ring of
-        HBM buffers (the source object must outlive them; it is kept referenced here)."""
+        HBM buffers (the source object must outlive them; it is kept referenced here).  fused = True: a power iteration
+        reads every panel once (4 passes per rsvd at q = 2); False: 6 passes, bit-identical to the resident engine."""
         cs = src.c_struct()
         if src.thresh is not None and src.thresh.shape[0] != M:
             raise ValueError("thresh must be uint32 [M, P]")
         self._source_ref = (src, cs)
         self._chk(self._lib.gpca_stream_open(self._h, C.byref(cs), M, N, panel_rows, ring_slots))
+        self._chk(self._lib.gpca_stream_set_fused(self._h, int(fused)))
 
     def download_genotypes_i8(self) -> np.ndarray:
         M, N = self.dims()

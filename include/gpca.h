@@ -141,6 +141,12 @@ GPCA_API int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* src,
  * same matrix.  The pull API (gpca_standardize_block) and gpca_download_genotypes_i8 need a resident matrix. */
 GPCA_API int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N, int64_t panel_rows,
                               int32_t ring_slots);
+/* fused = 1 (the default after gpca_stream_open): a power iteration reads every panel ONCE -- G Q, quantisation and G^T T per panel
+ * while it sits in HBM -- so gpca_rsvd makes 2 + power_iters passes over the source instead of 2 + 2 * power_iters (4 instead of 6
+ * at q = 2: what counts when the source is a disk or the host link).  Every panel then quantises its rows against its own column
+ * maxima: results differ from the resident engine at the 1e-9 level of the 28-bit fixed point (as a row-sharded run does).
+ * fused = 0: the 6-pass form, bit-identical to the resident engine. */
+GPCA_API int gpca_stream_set_fused(gpca_handle* h, int32_t fused);
 GPCA_API int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N);
 
 /* ---- a1/a3: SNP QC + standardisation parameters (prepare.rs:1100-1422, 1641-1745) -------- */
