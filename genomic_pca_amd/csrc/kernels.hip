@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_snp_stats(const int8_t* __restrict__ G,
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const uint4* p = reinterpret_cast<const uint4*>(G + row * ld);
-    const int64_t nvec = ld >> 4;  // ld is a multiple of 256
+    const int64_t nvec = (N + 15) >> 4;  // the row's samples; bytes between N and the pitch are zero pads (the pitch may exceed the padded sample count)
     int nmiss = 0, sum = 0, sq = 0;
     unsigned weird = 0;
     for (int64_t v0 = lane; v0 < nvec; v0 += 64) {
