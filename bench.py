@@ -225,7 +225,7 @@ def streamed_main(a, g, rank, world, local_rank, dist, torch):
                "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "i8 (exact-integer GEMMs, f64 recombination)", "data": "synthetic (device generator, regenerated on every sweep)",
                "config": {"workload": f"out-of-core: synthetic {M_total} SNPs x {N} samples (never resident), k={k}, l={l}, q={a.power_iters}, "
-                                      f"panels generated on the device by Philox (GPCA_PANEL_SYNTH16) into a ring of {a.ring} HBM buffers",
+                                      f"panels generated on the device by a SplitMix64 counter generator (GPCA_PANEL_SYNTH16) into a ring of {a.ring} HBM buffers",
                           "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample, "power_iters": a.power_iters,
                           "parallelism": f"snp-row-shards x{world}", "gemm_path": "i8", "residency": f"streamed/{a.storage}",
                           "panel_rows": a.panel_rows, "ring": a.ring, "passes_over_the_source_per_call": ssum["sweeps_per_step"]},
@@ -382,7 +382,7 @@ def main():
             a2 = argparse.Namespace(**vars(a)); a2.panel_rows = 131072; a2.ring = 3; a2.digit_planes = 0
             dts, tims, evs, _ = streamed_run(g, a2, M_local, N, k, a.storage, local_rank, 0, None, None, steps=min(a.steps, 3), warmup=1)
             out["streamed_panels"] = {"note": "same shape out-of-core (BASELINE.json configs[4] mode at configs[1] size): panels come from the "
-                                              "Philox device generator (a different synthetic draw than the resident matrix)",
+                                              "device generator (GPCA_PANEL_SYNTH16; a different synthetic draw than the resident matrix)",
                                       "value": M_local * N / (dts / min(a.steps, 3)), "unit": "SNPs*samples/s",
                                       "ms_per_step": dts / min(a.steps, 3) * 1e3, **streamed_summary(tims, min(a.steps, 3), M_local, N, l, a.storage)}
         if world == 1 and not a.no_cpu_baseline:

@@ -42,8 +42,8 @@ __host__ __device__ inline int64_t blocked_q_index(int64_t n, int col, int LT) {
 
 void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset,
                   uint64_t seed, const uint32_t* d_thresh, int P);
-// Fast panel generator (GPCA_PANEL_SYNTH16): one 16-bit uniform per genotype, g = (u < t1) + (u < t2) with the 16-bit
-// thresholds t2 = P(g = 2) (low half) and t1 = P(g >= 1) (high half) of thresh16[row][(n / 16) % P]; 8 genotypes per Philox call.
+// Fast panel generator (GPCA_PANEL_SYNTH16): one 16-bit uniform per genotype (SplitMix64, counter mode), g = (u < t1) + (u < t2) with the 16-bit
+// thresholds t2 = P(g = 2) (low half) and t1 = P(g >= 1) (high half) of thresh16[row][(n / 16) % P]; 4 genotypes per SplitMix64 output.
 // packed = 0: int8 rows of pitch ld; 1: 2-bit dosage codes, rows of pitch ld bytes.  snp0 = global index of row 0.
 void launch_synth16(hipStream_t st, void* G, int packed, int64_t rows, int64_t N, int64_t ld, int64_t snp0, uint64_t seed,
                     const uint32_t* d_thresh16, int P);

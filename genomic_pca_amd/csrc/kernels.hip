@@ -60,7 +60,7 @@ void launch_synth(hipStream_t st, int8_t* G, int64_t M, int64_t N, int64_t ld, i
                        d_thresh, P);
 }
 
-// Fast generator for streamed panels: thread = 16 consecutive samples of one SNP row = two Philox calls; writes 16 int8
+// Fast generator for streamed panels: thread = 16 consecutive samples of one SNP row = four SplitMix64 outputs; writes 16 int8
 // bytes or one 32-bit word of 2-bit dosage codes (no int8 scratch + pack pass).  The 16 samples of a thread belong to ONE
 // population -- pop(n) = (n / 16) % P -- so the two 16-bit thresholds are loaded once per thread and a genotype costs two
 // sub-dword compares and two carry-adds (the first version, with pop(n) = n % P and a threshold load per sample, spent 80 %
@@ -80,14 +80,19 @@ __global__ __launch_bounds__(256) void k_synth16(void* __restrict__ Gv, int64_t 
         const uint64_t gi = (uint64_t)(i + snp0);
         const uint32_t tw = thresh[i * P + (int)(wi % (uint32_t)P)];
         const uint32_t t1 = tw >> 16, t2 = tw & 0xffffu;
+        // four 16-bit uniforms per SplitMix64 output; the thread's four outputs are consecutive in the stream (one multiply,
+        // then 64-bit adds).  Philox4x32-10 here cost 170 of the kernel's 300 instructions (20 wide multiplies per 8 genotypes).
+        uint64_t st = seed + (((gi << 26) + 4ull * wi) + 1ull) * GPCA_SPLITMIX_GAMMA;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), 2u * wi + hf, GPCA_STREAM_GEN16,
-                                               (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t z = splitmix64_mix(st);
+            st += GPCA_SPLITMIX_GAMMA;
+            const uint32_t zl = (uint32_t)z, zh = (uint32_t)(z >> 32);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int s = 8 * hf + j;
-                const uint32_t u = (j & 1) ? (o.v[j >> 1] >> 16) : (o.v[j >> 1] & 0xffffu);
+            for (int j = 0; j < 4; ++j) {
+                const int s = 4 * q + j;
+                const uint32_t half = j < 2 ? zl : zh;
+                const uint32_t u = (j & 1) ? (half >> 16) : (half & 0xffffu);
                 const uint32_t g = (uint32_t)(u < t1) + (uint32_t)(u < t2);
                 if (PACKED) codes |= g << (2 * s);
                 else w[s >> 2] |= g << (8 * (s & 3));

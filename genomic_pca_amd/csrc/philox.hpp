@@ -2,7 +2,8 @@
 // Streams used by the engine (4th counter word):
 //   0x47454E4F  synthetic genotypes  counter = (snp_lo, snp_hi, sample/2)
 //   0x4F4D4547  sketch matrix Omega  counter = (snp_lo, snp_hi, column/4)
-//   0x47454E31  fast panel generator counter = (snp_lo, snp_hi, sample/8): eight 16-bit uniforms per call
+// The fast panel generator (GPCA_PANEL_SYNTH16) uses SplitMix64 in counter mode instead (below): output (snp << 26) + sample / 4
+// of the stream seeded with `seed` = four 16-bit uniforms.
 #pragma once
 #include <stdint.h>
 
@@ -32,4 +33,12 @@ GPCA_HD philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
 
 #define GPCA_STREAM_GENO 0x47454E4Fu
 #define GPCA_STREAM_OMEGA 0x4F4D4547u
-#define GPCA_STREAM_GEN16 0x47454E31u   // fast panel generator: counter = (snp_lo, snp_hi, sample/8)
+// SplitMix64 (Steele, Lea, Flood 2014; the generator that seeds xoshiro) in counter mode: output number i (0-based) of the stream
+// seeded with `seed` is mix(seed + (i + 1) * gamma) -- any i can be computed directly, consecutive i cost one 64-bit add.
+// Known answers (seed 1234567): 6457827717110365317, 3203168211198807973, 9817491932198370423, ...
+#define GPCA_SPLITMIX_GAMMA 0x9E3779B97F4A7C15ull
+GPCA_HD uint64_t splitmix64_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}

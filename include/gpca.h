@@ -115,7 +115,7 @@ typedef enum gpca_panel_kind {
     GPCA_PANEL_HOST_I8 = 0,  /* `fill` writes int8 SNP-major rows (0/1/2, -127 missing), row pitch ld = N */
     GPCA_PANEL_HOST_BED = 1, /* `fill` writes PLINK .bed rows (2 bits/sample, count_a1 decode), row pitch ld = ceil(N/4) */
     GPCA_PANEL_SYNTH = 2,    /* device generator of gpca_synth_genotypes: thresh = uint32 [M][n_pop] = floor(p * 2^32) */
-    GPCA_PANEL_SYNTH16 = 3   /* fast device generator, one 16-bit uniform per genotype: thresh = uint32 [M][n_pop],
+    GPCA_PANEL_SYNTH16 = 3   /* fast device generator, one 16-bit uniform per genotype (SplitMix64 in counter mode): thresh = uint32 [M][n_pop],
                                 high half = floor(P(g >= 1) * 65536), low half = floor(P(g = 2) * 65536); sample n belongs to
                                 population (n / 16) % n_pop */
 } gpca_panel_kind;

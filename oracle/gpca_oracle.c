@@ -86,24 +86,32 @@ void orc_synth_genotypes(int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t sn
     }
 }
 
-/* Fast panel generator (GPCA_PANEL_SYNTH16; device twin: genomic_pca_amd/csrc/kernels.hip:k_synth16).  One 16-bit
- * uniform per genotype: counter = (snp_lo, snp_hi, n/8, stream 0x47454E31), key = seed; sample n = 8q + j takes
- * u = 16-bit field (j & 1) of output word j >> 1;  g = (u < t1) + (u < t2) with the thresholds of the sample's population
- * (n / 16) % P -- blocks of 16 consecutive samples share a population -- packed in thresh[i*P + pop]: high half
+/* SplitMix64 (Steele, Lea, Flood 2014): output i (0-based) of the stream seeded with `seed` is mix(seed + (i + 1) * gamma).
+ * Written independently of genomic_pca_amd/csrc/philox.hpp; pinned by the published outputs for seed 1234567. */
+static inline uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+uint64_t orc_splitmix64_at(uint64_t seed, uint64_t i) { return splitmix64_at(seed, i); }
+
+/* Fast panel generator (GPCA_PANEL_SYNTH16; device twin: genomic_pca_amd/csrc/kernels.hip:k_synth16).  One 16-bit uniform
+ * per genotype: sample n of SNP (global row) gi takes bits 16 (n % 4) .. +15 of SplitMix64 output number (gi << 26) + n / 4
+ * of the stream seeded with `seed`;  g = (u < t1) + (u < t2) with the thresholds of the sample's population (n / 16) % P --
+ * blocks of 16 consecutive samples share a population -- packed in thresh[i*P + pop]: high half
  * t1 = floor(P(g >= 1) * 65536), low half t2 = floor(P(g = 2) * 65536). */
 void orc_synth16_genotypes(int8_t* G, int64_t M, int64_t N, int64_t ld, int64_t snp_offset,
                            uint64_t seed, const uint32_t* thresh, int P) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < M; ++i) {
         uint64_t gi = (uint64_t)(i + snp_offset);
-        for (int64_t q = 0; q < (N + 7) / 8; ++q) {
-            uint32_t o[4];
-            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)q, 0x47454E31u,
-                          (uint32_t)seed, (uint32_t)(seed >> 32), o);
-            for (int j = 0; j < 8 && 8 * q + j < N; ++j) {
-                int64_t n = 8 * q + j;
+        for (int64_t q = 0; q < (N + 3) / 4; ++q) {
+            uint64_t z = splitmix64_at(seed, (gi << 26) + (uint64_t)q);
+            for (int j = 0; j < 4 && 4 * q + j < N; ++j) {
+                int64_t n = 4 * q + j;
                 uint32_t tw = thresh[i * P + ((n >> 4) % P)];
-                uint32_t u = (o[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                uint32_t u = (uint32_t)(z >> (16 * j)) & 0xffffu;
                 G[i * ld + n] = (int8_t)((u < (tw >> 16)) + (u < (tw & 0xffffu)));
             }
         }

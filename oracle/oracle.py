@@ -79,6 +79,13 @@ def synth_genotypes(M: int, N: int, seed: int, thresh: np.ndarray, snp_offset: i
     return G
 
 
+def splitmix64_at(seed: int, i: int) -> int:
+    """Output number i (0-based) of SplitMix64 seeded with `seed`."""
+    f = lib().orc_splitmix64_at
+    f.restype = C.c_uint64
+    return int(f(C.c_uint64(seed), C.c_uint64(i)))
+
+
 def synth16_genotypes(M: int, N: int, seed: int, thresh16: np.ndarray, snp_offset: int = 0, ld: int | None = None) -> np.ndarray:
     """Fast panel generator (GPCA_PANEL_SYNTH16), restated in gpca_oracle.c:orc_synth16_genotypes."""
     ld = ld or N

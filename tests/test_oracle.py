@@ -177,13 +177,16 @@ def test_checker_against_sklearn_randomized_svd(oracle, gpca):
 
 
 def test_synth16_known_answers(oracle, gpca):
-    """Fast panel generator: field order and threshold halves, by hand from one Philox block."""
+    """Fast panel generator: SplitMix64 against its published outputs, then field order and threshold halves by hand."""
+    assert [oracle.splitmix64_at(1234567, i) for i in range(5)] == \
+        [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431, 16408922859458223821]
+    assert oracle.splitmix64_at(0, 0) == 0xE220A8397B1DCDAF
     th = np.array([[(40000 << 16) | 10000, (65535 << 16) | 65535, 0]], np.uint32)          # pop 0: mixed; pop 1: always 2; pop 2: always 0
     G = oracle.synth16_genotypes(1, 70, 99, th, snp_offset=7)
     assert np.all(G[0, 16:32] == 2) and np.all(G[0, 32:48] == 0) and np.all(G[0, 64:70] == 2)   # pop(n) = (n / 16) % 3
-    o = oracle.philox([7, 0, 0, 0x47454E31], [99, 0])                                       # samples 0..7 of SNP 7 (population 0)
-    u0 = int(o[0]) & 0xffff; u3 = (int(o[1]) >> 16) & 0xffff; u6 = int(o[3]) & 0xffff
-    for n, u in ((0, u0), (3, u3), (6, u6)):
+    for n in (0, 3, 6, 13, 48, 63):                                                          # samples of population 0
+        z = oracle.splitmix64_at(99, (7 << 26) + n // 4)
+        u = (z >> (16 * (n % 4))) & 0xffff
         assert G[0, n] == (u < 40000) + (u < 10000)
     assert np.array_equal(oracle.synth16_genotypes(3, 50, 5, gpca.synth_thresholds16(3, 2, seed=5, snp_offset=11), snp_offset=11),
                           oracle.synth16_genotypes(14, 50, 5, gpca.synth_thresholds16(14, 2, seed=5), snp_offset=0)[11:])
