@@ -1,0 +1,261 @@
+#pragma once
+// Internals shared by the translation units of libgpca.so's host driver (gpca_api.cpp: lifecycle, QC statistics, pull API, exchange,
+// timings; gpca_residency.cpp: uploads, panel sources, out-of-core ring; gpca_rsvd.cpp: the randomized-PCA stages).  Nothing here is
+// exported: the library is built with -fvisibility=hidden and only the extern "C" entry points of include/gpca.h carry GPCA_API.
+//
+// C ABI + host driver of the randomized-PCA engine (declared in include/gpca.h).
+//
+// The driver keeps genotypes, basis, sketches and results in HBM behind the opaque handle and only
+// moves l x l (<= 64 x 64) f64 blocks to the host for Cholesky / Jacobi.  Per randomized-PCA call:
+//   sketch Y = A^T Omega, orth;  q x { T = A Q, Y = A^T T, orth };  B = A Q;  eig(B^T B)
+// = 4 passes over the int8 matrix, 12*l flop per genotype.
+#include "../../include/gpca.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace gpca;
+
+// ---- minimal RCCL surface, resolved with dlopen so that libgpca.so loads on hosts without a GPU ----
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId_t;
+typedef int (*pfn_ncclGetUniqueId)(ncclUniqueId_t*);
+typedef int (*pfn_ncclCommInitRank)(ncclComm_t*, int, ncclUniqueId_t, int);
+typedef int (*pfn_ncclAllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*pfn_ncclCommDestroy)(ncclComm_t);
+typedef const char* (*pfn_ncclGetErrorString)(int);
+struct RcclApi {
+    void* lib = nullptr;
+    pfn_ncclGetUniqueId GetUniqueId = nullptr;
+    pfn_ncclCommInitRank CommInitRank = nullptr;
+    pfn_ncclAllReduce AllReduce = nullptr;
+    pfn_ncclCommDestroy CommDestroy = nullptr;
+    pfn_ncclGetErrorString GetErrorString = nullptr;
+    bool load() {
+        if (lib) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        GetUniqueId = (pfn_ncclGetUniqueId)dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (pfn_ncclCommInitRank)dlsym(lib, "ncclCommInitRank");
+        AllReduce = (pfn_ncclAllReduce)dlsym(lib, "ncclAllReduce");
+        CommDestroy = (pfn_ncclCommDestroy)dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (pfn_ncclGetErrorString)dlsym(lib, "ncclGetErrorString");
+        return GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+    }
+};
+extern RcclApi g_rccl;
+enum { kNcclFloat64 = 8, kNcclSum = 0 };  // ncclDataType_t / ncclRedOp_t values (rccl.h)
+
+struct TimingRec { std::string name; hipEvent_t a, b; double flops, bytes; };
+
+// One view of genotype rows in HBM: the whole resident matrix, or the panel currently in a ring slot (streamed mode).
+struct PanelView { const int8_t* g8; const uint8_t* g2; int64_t row0, rows, rows_pad; int index; };
+
+// Turns a gpca_panel_source into rows in device memory: device generators run on `st`; host callbacks fill one of two
+// pinned staging buffers, which is then copied (and, for .bed bytes / 2-bit storage, recoded) on `st`.
+struct Filler {
+    gpca_panel_source src{};
+    int64_t chunk_rows = 0;          // most rows one fill() call may ask for
+    int64_t stage_ld = 0;            // bytes per row of the host staging buffers
+    uint32_t* d_thresh = nullptr;    // SYNTH*: [M][n_pop]
+    int8_t* d_scratch8 = nullptr;    // int8 rows on their way to 2-bit storage: [chunk_rows][ldg]
+    uint8_t* d_raw = nullptr;        // .bed bytes on the device: [chunk_rows][bpr]
+    unsigned* d_flags = nullptr;     // invalid-genotype flag of the pack kernel
+    void* h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    char stage_pending[2] = {0, 0};
+    int stage_idx = 0;
+    bool open = false;
+};
+
+struct StreamState {
+    bool on = false;
+    Filler fl;
+    int64_t panel_rows = 0;
+    int n_panels = 0, ring = 0;
+    std::vector<void*> slot;
+    std::vector<hipEvent_t> ev_filled, ev_free;
+    std::vector<char> free_pending;
+    hipStream_t st_fill = nullptr;
+    int64_t seq = 0;                 // panels filled so far: slot = seq % ring
+    int fused = 1;                   // power iterations read every panel once (K1 -> quantise -> K2 per panel): 4 passes per call, not 6
+};
+
+struct gpca_handle {
+    std::recursive_mutex mu;     // every entry point locks it: a handle may be shared between host threads (gpca.h, "Threading")
+    KernelOpts ko;
+    StreamState sm;
+    int device = 0;
+    int precision = GPCA_PREC_F32_MFMA;
+    int storage = GPCA_STORE_INT8;
+    hipStream_t st = nullptr;
+    std::string err;
+
+    // genotypes
+    int64_t M = 0, N = 0, ldg = 0, Mpad = 0;   // ldg = samples padded to the kernels' tiles; Mpad = round_up(M, 128): zero rows, so the GEMM loops carry no predicates
+    int64_t ld8 = 0;           // byte pitch of the int8 rows: ldg, plus 256 when ldg / 256 is even (see alloc_genotypes)
+    int8_t* dG = nullptr;      // GPCA_STORE_INT8: [Mpad][ldg]
+    uint8_t* dG2 = nullptr;    // GPCA_STORE_2BIT: [Mpad][ld2], ld2 = ldg / 4, dosage codes (3 = missing)
+    int64_t ld2 = 0;
+    uint32_t pack_flags = 0;   // invalid genotypes seen while packing int8 input
+
+    // stats
+    bool have_stats = false;
+    float *d_mu = nullptr, *d_sigma = nullptr, *d_r = nullptr, *d_b = nullptr;
+    uint8_t *d_keep = nullptr, *d_reason = nullptr;
+    uint32_t *d_counts = nullptr, *d_flags = nullptr;
+    int64_t n_pca = 0;
+    std::vector<int64_t> pca_rows;
+    int64_t* d_pca_rows = nullptr;
+    uint32_t flags = 0;
+
+    // rsvd workspace / results
+    int k = 0, l = 0, L = 0;
+    bool have_rsvd = false;
+    float *dQ = nullptr, *dT = nullptr, *dTb = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
+    double* h_pin = nullptr;     // pinned host staging for the l x l blocks of the final eigenproblem (W | Z | flag)
+    int spin_sync = 1;           // busy-poll the stream at the two syncs of gpca_rsvd (GPCA_SPIN_SYNC=0: hipStreamSynchronize)
+    int* d_cholflag = nullptr;   // first failed CholeskyQR pivot + 1 (0 = ok), written by k_chol_inv
+    double *d_scratch64 = nullptr, *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
+    double* d_scores64 = nullptr; float* d_scores32 = nullptr; float* d_load32 = nullptr; int* d_sign = nullptr;
+    size_t cap_Q = 0, cap_T = 0, cap_Tb = 0, cap_Ypart = 0, cap_cpart = 0, cap_Y = 0, cap_part64 = 0, cap_scores = 0, cap_load = 0;
+    std::vector<double> eig, sv;
+    GttPlan plan{};
+    GqPlan gqplan{};
+    Gtt8Plan plan8{};
+    // exact-integer path
+    int8_t *dQd = nullptr, *dTd = nullptr;
+    double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false; int64_t apart_parts = 0;   // column abs-max partials of T' from the K1 epilogue
+    const double* apart_src[2] = {nullptr, nullptr};   // where the partials of each 32-column half sit
+    double* d_amax_run = nullptr;    // [2][32] running column abs-max over the panels of a streamed K1 sweep
+    double* d_yint = nullptr; size_t cap_yint = 0;   // [halves][N][32] integer partial sums of a streamed K2 sweep
+    double* d_status = nullptr;      // [16] status word the ranks agree on
+    double* h_status = nullptr;      // pinned [32]: contribution | agreed histogram
+    // persistent scratch of the pull API (no allocation per call)
+    int64_t *d_blk_rows = nullptr, *d_blk_cols = nullptr; float* d_blk_out = nullptr; unsigned long long* d_blk_err = nullptr;
+    size_t cap_blk_rows = 0, cap_blk_cols = 0, cap_blk_out = 0;
+    double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
+    size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
+    int nd = 4;           // digit planes of the exact path (gpca_config.digit_planes): 4 x base 128, or 3 x base 256 (packed storage)
+    int gtt_dma = 1;      // K2 (int8-resident) by LDS-DMA (GPCA_GTT_DMA=0: register-staged k_gtt_x)
+    int gq_dma = 1;       // K1 (int8-resident) genotype loads by LDS-DMA, full-line pieces (GPCA_GQ_DMA=0: register-staged k_gq_x)
+    int lds_planes = 1;   // share the digit planes of the exact GEMMs through LDS (GPCA_LDS_PLANES=0 disables)
+    int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
+
+    // comm
+    int world = 1, rank = 0;
+    int64_t snp_offset = 0;
+    ncclComm_t comm = nullptr;
+    gpca_allreduce_fn hook = nullptr;
+    void* hook_user = nullptr;
+    std::vector<double> hook_buf;
+
+    // timings (off by default; bounded: pending records are folded into `agg` once kMaxTimingRecs are outstanding)
+    bool timing_on = false;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<gpca_kernel_timing> agg;
+};
+constexpr size_t kMaxTimingRecs = 32768;
+#define LOCK(h) std::lock_guard<std::recursive_mutex> lock_guard_(h->mu)
+
+extern thread_local std::string g_last_global_err;
+int fail(gpca_handle* h, int code, const std::string& msg);
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            char buf_[512];                                                                            \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return fail(h, e_ == hipErrorOutOfMemory ? GPCA_ERR_OOM : GPCA_ERR_HIP, buf_);             \
+        }                                                                                              \
+    } while (0)
+#define CHK(x) do { int rc_ = (x); if (rc_ != GPCA_OK) return rc_; } while (0)
+
+template <typename T>
+inline int ensure(gpca_handle* h, T*& p, size_t& cap, size_t need_elems) {
+    if (cap >= need_elems && p) return GPCA_OK;
+    if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+    HIPCHK(hipMalloc((void**)&p, need_elems * sizeof(T)));
+    cap = need_elems;
+    return GPCA_OK;
+}
+template <typename T>
+inline void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- timing ---------------------------------------------------------------------------------------
+void fold_timings(gpca_handle* h);   // resolve pending records into per-name totals and recycle their events
+struct ScopedTimer {
+    gpca_handle* h; bool on; size_t idx = 0; hipStream_t st;
+    ScopedTimer(gpca_handle* h_, const char* name, double flops, double bytes, hipStream_t st_ = nullptr, bool enable = true)
+        : h(h_), on(h_->timing_on && enable), st(st_ ? st_ : h_->st) {
+        if (!on) return;
+        if (h->recs.size() >= kMaxTimingRecs) fold_timings(h);
+        TimingRec r; r.name = name; r.flops = flops; r.bytes = bytes; r.a = r.b = nullptr;
+        for (hipEvent_t* e : {&r.a, &r.b}) {
+            if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
+        }
+        (void)hipEventRecord(r.a, st);
+        h->recs.push_back(r); idx = h->recs.size() - 1;
+    }
+    ~ScopedTimer() { if (on) (void)hipEventRecord(h->recs[idx].b, st); }
+};
+
+
+// ---- shared between the translation units ---------------------------------------------------------------------
+inline bool have_genotypes(const gpca_handle* h) { return h->dG || h->dG2 || h->sm.on; }
+inline bool multi_rank(const gpca_handle* h) { return h->world > 1 || h->hook != nullptr; }
+constexpr size_t kPlaneBytesPerBlock = (size_t)gpca::kDigits * 1024;   // digit planes of one 32-row (or 32-sample) block
+// gpca_residency.cpp
+void free_stats(gpca_handle* h);
+void free_ws(gpca_handle* h);
+void stream_close(gpca_handle* h);
+int finish_pack_flags(gpca_handle* h, unsigned* d_flags, hipStream_t st);
+int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst, hipStream_t st);
+// gpca_api.cpp
+int allreduce_f64(gpca_handle* h, double* dbuf, int64_t count);   // in-place sum across the ranks that share the sharded matrix
+hipError_t stream_wait(gpca_handle* h);
+int agree_status(gpca_handle* h, int local_rc, const char* where);
+
+// fn(view) once for the resident matrix, or once per panel (generated / copied one panel ahead on the fill stream)
+template <class F>
+inline int for_each_panel(gpca_handle* h, F&& fn) {
+    if (!h->sm.on) { const PanelView pv{h->dG, h->dG2, 0, h->M, h->Mpad, 0}; return fn(pv); }
+    StreamState& sm = h->sm;
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    const int64_t row_bytes = packed ? h->ld2 : h->ld8;
+    for (int p = 0; p < sm.n_panels; ++p) {
+        const int64_t row0 = (int64_t)p * sm.panel_rows;
+        const int64_t rows = std::min(sm.panel_rows, h->M - row0);
+        const int64_t rows_pad = round_up(rows, kGQRowsPerWave);
+        const int s = (int)(sm.seq % sm.ring); sm.seq++;
+        if (sm.free_pending[s]) HIPCHK(hipStreamWaitEvent(sm.st_fill, sm.ev_free[s], 0));   // the slot's last reader has finished
+        {
+            ScopedTimer t(h, "panel_fill", 0.0, (double)rows * (double)h->N, sm.st_fill);
+            if (rows_pad > rows) HIPCHK(hipMemsetAsync((char*)sm.slot[s] + (size_t)rows * row_bytes, 0, (size_t)(rows_pad - rows) * row_bytes, sm.st_fill));
+            CHK(filler_fill(h, sm.fl, row0, rows, sm.slot[s], sm.st_fill));
+        }
+        HIPCHK(hipEventRecord(sm.ev_filled[s], sm.st_fill));
+        HIPCHK(hipStreamWaitEvent(h->st, sm.ev_filled[s], 0));
+        const PanelView pv{packed ? nullptr : (const int8_t*)sm.slot[s], packed ? (const uint8_t*)sm.slot[s] : nullptr, row0, rows, rows_pad, p};
+        CHK(fn(pv));
+        HIPCHK(hipEventRecord(sm.ev_free[s], h->st)); sm.free_pending[s] = 1;
+    }
+    return GPCA_OK;
+}
+

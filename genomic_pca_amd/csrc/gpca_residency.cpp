@@ -1,0 +1,348 @@
+// Genotype residency: uploads, panel sources, the out-of-core panel ring (include/gpca.h sections "genotype residency" and "g").
+#include "gpca_internal.h"
+
+using namespace gpca;
+
+void free_stats(gpca_handle* h) {
+    dfree(h->d_mu); dfree(h->d_sigma); dfree(h->d_r); dfree(h->d_b); dfree(h->d_keep); dfree(h->d_reason);
+    dfree(h->d_counts); dfree(h->d_flags); dfree(h->d_pca_rows);
+    h->have_stats = false; h->n_pca = 0; h->pca_rows.clear();
+}
+void free_ws(gpca_handle* h) {
+    dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
+    dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
+    dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
+    dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_cholflag); if (h->h_pin) { (void)hipHostFree(h->h_pin); h->h_pin = nullptr; } dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
+    dfree(h->d_amax_run); dfree(h->d_yint); h->cap_yint = 0;
+    h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
+    h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
+    h->have_rsvd = false;
+}
+static void filler_close(Filler& f) {
+    dfree(f.d_thresh); dfree(f.d_scratch8); dfree(f.d_raw); dfree(f.d_flags);
+    for (int i = 0; i < 2; ++i) {
+        if (f.ev_stage[i]) { (void)hipEventSynchronize(f.ev_stage[i]); (void)hipEventDestroy(f.ev_stage[i]); f.ev_stage[i] = nullptr; }
+        if (f.h_stage[i]) { (void)hipHostFree(f.h_stage[i]); f.h_stage[i] = nullptr; }
+        f.stage_pending[i] = 0;
+    }
+    f.open = false;
+}
+void stream_close(gpca_handle* h) {
+    StreamState& sm = h->sm;
+    if (sm.st_fill) (void)hipStreamSynchronize(sm.st_fill);
+    if (h->st) (void)hipStreamSynchronize(h->st);
+    filler_close(sm.fl);
+    for (void* p : sm.slot) if (p) (void)hipFree(p);
+    for (auto e : sm.ev_filled) (void)hipEventDestroy(e);
+    for (auto e : sm.ev_free) (void)hipEventDestroy(e);
+    sm.slot.clear(); sm.ev_filled.clear(); sm.ev_free.clear(); sm.free_pending.clear();
+    if (sm.st_fill) { (void)hipStreamDestroy(sm.st_fill); sm.st_fill = nullptr; }
+    sm.on = false; sm.seq = 0; sm.n_panels = 0;
+}
+
+// ---- genotype residency -------------------------------------------------------------------------------
+
+// dimensions + (resident = true) the device matrix; streamed mode only records the dimensions
+static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident = true) {
+    if (M <= 0 || N <= 0) return fail(h, GPCA_ERR_BAD_ARG, "genotype matrix must have M > 0 SNPs and N > 0 samples");
+    HIPCHK(hipSetDevice(h->device));
+    stream_close(h);
+    free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
+    h->M = M; h->N = N; h->Mpad = round_up(M, kGQRowsPerWave); h->pack_flags = 0;
+    if (h->storage == GPCA_STORE_2BIT) {
+        h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4; h->ld8 = h->ldg;
+        if (!resident) return GPCA_OK;
+        HIPCHK(hipMalloc((void**)&h->dG2, (size_t)h->Mpad * (size_t)h->ld2));
+        if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG2 + (size_t)M * (size_t)h->ld2, 0, (size_t)(h->Mpad - M) * (size_t)h->ld2, h->st));
+        return GPCA_OK;
+    }
+    h->ldg = round_up(N, kSamplePad); h->ld2 = 0;
+    // Row pitch vs HBM channel interleave: rows an EVEN multiple of 256 B apart (10 240 B for 10 000 samples) stream 2-5 % slower
+    // than rows an odd multiple apart (profiles/r1_kbench_summary.md section 6): 8 rows of one DMA piece then spread over fewer
+    // channels.  The pitch gets one extra 256-byte block in that case; the kernels never read past ldg.
+    h->ld8 = ((h->ldg / 256) & 1) ? h->ldg : h->ldg + 256;
+    if (getenv("GPCA_PITCH_PAD") && atoi(getenv("GPCA_PITCH_PAD")) == 0) h->ld8 = h->ldg;
+    if (!resident) return GPCA_OK;
+    HIPCHK(hipMalloc((void**)&h->dG, (size_t)h->Mpad * (size_t)h->ld8));
+    if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG + (size_t)M * (size_t)h->ld8, 0, (size_t)(h->Mpad - M) * (size_t)h->ld8, h->st));
+    return GPCA_OK;
+}
+
+// rows per chunk of the bounded staging buffers (<= 256 MiB of int8 rows)
+static int64_t pack_chunk_rows(gpca_handle* h) {
+    int64_t r = ((int64_t)256 << 20) / h->ldg;
+    if (r < 1) r = 1;
+    return r < h->M ? r : h->M;
+}
+int finish_pack_flags(gpca_handle* h, unsigned* d_flags, hipStream_t st) {
+    unsigned f = 0;
+    HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->pack_flags |= f;
+    return GPCA_OK;
+}
+
+extern "C" int gpca_upload_genotypes_i8(gpca_handle* h, const int8_t* src, int64_t M, int64_t N, int64_t ld) {
+    if (!h || !src || ld < N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_upload_genotypes_i8: bad arguments");
+    LOCK(h);
+    CHK(alloc_genotypes(h, M, N));
+    if (h->storage == GPCA_STORE_2BIT) {
+        const int64_t cr = pack_chunk_rows(h);
+        int8_t* scratch = nullptr; unsigned* d_flags = nullptr;
+        HIPCHK(hipMalloc((void**)&scratch, (size_t)cr * (size_t)h->ldg));
+        hipError_t e = hipMalloc((void**)&d_flags, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 16, h->st);
+        if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, (size_t)cr * (size_t)h->ldg, h->st);
+        for (int64_t r0 = 0; r0 < M && e == hipSuccess; r0 += cr) {
+            const int64_t rows = std::min(cr, M - r0);
+            e = hipMemcpy2DAsync(scratch, (size_t)h->ldg, src + r0 * ld, (size_t)ld, (size_t)N, (size_t)rows, hipMemcpyHostToDevice, h->st);
+            if (e == hipSuccess) { launch_pack_i8(h->st, scratch, h->ldg, h->dG2 + (size_t)r0 * h->ld2, rows, N, h->ld2, d_flags); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipStreamSynchronize(h->st);   // the host source of the next chunk may be pageable
+        }
+        int rc = e == hipSuccess ? finish_pack_flags(h, d_flags, h->st) : GPCA_OK;
+        (void)hipFree(scratch); (void)hipFree(d_flags);
+        HIPCHK(e);
+        return rc;
+    }
+    if (h->ld8 != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ld8, h->st));
+    HIPCHK(hipMemcpy2DAsync(h->dG, (size_t)h->ld8, src, (size_t)ld, (size_t)N, (size_t)M, hipMemcpyHostToDevice, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    return GPCA_OK;
+}
+
+// The .bed payload travels in row chunks through a bounded device staging buffer (<= 256 MiB) and is recoded chunk by
+// chunk, so the peak is the resident matrix + 256 MiB (a 250 GB .bed of 10M x 100k fits one MI355X as 2-bit codes) and no
+// launch exceeds 2^32 work-items.
+extern "C" int gpca_upload_bed2bit(gpca_handle* h, const uint8_t* bed_rows, int64_t M, int64_t N) {
+    if (!h || !bed_rows) return fail(h, GPCA_ERR_BAD_ARG, "gpca_upload_bed2bit: bad arguments");
+    LOCK(h);
+    CHK(alloc_genotypes(h, M, N));
+    const int64_t bpr = (N + 3) / 4;
+    int64_t cr = ((int64_t)256 << 20) / bpr;
+    cr = std::max<int64_t>(1, std::min(cr, M));
+    uint8_t* d_bed = nullptr;
+    HIPCHK(hipMalloc((void**)&d_bed, (size_t)cr * (size_t)bpr));
+    hipError_t e = hipSuccess;
+    for (int64_t r0 = 0; r0 < M && e == hipSuccess; r0 += cr) {
+        const int64_t rows = std::min(cr, M - r0);
+        e = hipMemcpyAsync(d_bed, bed_rows + (size_t)r0 * (size_t)bpr, (size_t)rows * (size_t)bpr, hipMemcpyHostToDevice, h->st);
+        if (e != hipSuccess) break;
+        if (h->storage == GPCA_STORE_2BIT) launch_bed_to_codes(h->st, d_bed, bpr, h->dG2 + (size_t)r0 * h->ld2, rows, N, h->ld2);   // stays 2-bit
+        else launch_bed_decode(h->st, d_bed, bpr, h->dG + (size_t)r0 * h->ld8, rows, N, h->ld8);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->st);   // the staging buffer is reused; the host source may be pageable
+    }
+    (void)hipFree(d_bed);
+    HIPCHK(e);
+    return GPCA_OK;
+}
+
+extern "C" int gpca_synth_genotypes(gpca_handle* h, int64_t M, int64_t N, uint64_t seed, const uint32_t* thresh,
+                                    int32_t P, int64_t snp_offset) {
+    if (!h || !thresh || P <= 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_synth_genotypes: bad arguments");
+    gpca_panel_source src{};
+    src.kind = GPCA_PANEL_SYNTH; src.n_pop = P; src.thresh = thresh; src.seed = seed; src.snp_offset = snp_offset;
+    return gpca_load_from_source(h, &src, M, N);
+}
+
+// ---- panel sources ------------------------------------------------------------------------------------------
+static int check_source(gpca_handle* h, const gpca_panel_source* src, const char* who) {
+    if (!src) return fail(h, GPCA_ERR_BAD_ARG, std::string(who) + ": source is NULL");
+    switch (src->kind) {
+        case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED:
+            if (!src->fill) return fail(h, GPCA_ERR_BAD_ARG, std::string(who) + ": host panel source without a fill callback");
+            return GPCA_OK;
+        case GPCA_PANEL_SYNTH: case GPCA_PANEL_SYNTH16:
+            if (!src->thresh || src->n_pop <= 0 || src->snp_offset < 0) return fail(h, GPCA_ERR_BAD_ARG, std::string(who) + ": generator source needs thresh, n_pop > 0, snp_offset >= 0");
+            return GPCA_OK;
+        default: return fail(h, GPCA_ERR_BAD_ARG, std::string(who) + ": unknown panel kind");
+    }
+}
+
+// staging of one source for chunks of up to chunk_rows rows of the handle's current M x N matrix
+static int filler_open(gpca_handle* h, Filler& f, const gpca_panel_source& src, int64_t chunk_rows, hipStream_t st) {
+    filler_close(f);
+    f.src = src; f.chunk_rows = chunk_rows; f.stage_idx = 0;
+    f.open = true;
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    if (src.kind == GPCA_PANEL_SYNTH || src.kind == GPCA_PANEL_SYNTH16) {
+        const size_t tb = (size_t)h->M * (size_t)src.n_pop * sizeof(uint32_t);
+        HIPCHK(hipMalloc((void**)&f.d_thresh, tb));
+        HIPCHK(hipMemcpyAsync(f.d_thresh, src.thresh, tb, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));   // the caller's table may be freed after open
+    }
+    if (packed && (src.kind == GPCA_PANEL_SYNTH || src.kind == GPCA_PANEL_HOST_I8)) {
+        HIPCHK(hipMalloc((void**)&f.d_scratch8, (size_t)chunk_rows * (size_t)h->ldg));
+        HIPCHK(hipMemsetAsync(f.d_scratch8, 0, (size_t)chunk_rows * (size_t)h->ldg, st));   // pad columns stay 0
+        HIPCHK(hipMalloc((void**)&f.d_flags, 16));
+        HIPCHK(hipMemsetAsync(f.d_flags, 0, 16, st));
+    }
+    if (src.kind == GPCA_PANEL_HOST_BED) {
+        f.stage_ld = (h->N + 3) / 4;
+        HIPCHK(hipMalloc((void**)&f.d_raw, (size_t)chunk_rows * (size_t)f.stage_ld));
+    }
+    if (src.kind == GPCA_PANEL_HOST_I8) f.stage_ld = h->N;
+    if (src.kind == GPCA_PANEL_HOST_I8 || src.kind == GPCA_PANEL_HOST_BED) {
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipHostMalloc(&f.h_stage[i], (size_t)chunk_rows * (size_t)f.stage_ld, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&f.ev_stage[i], hipEventDisableTiming));
+        }
+    }
+    return GPCA_OK;
+}
+
+// rows [row0, row0 + rows) of the matrix -> dst (int8 rows of pitch ldg, or 2-bit rows of pitch ld2), enqueued on st
+int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst, hipStream_t st) {
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    const gpca_panel_source& s = f.src;
+    switch (s.kind) {
+        case GPCA_PANEL_SYNTH:
+            if (packed) {
+                launch_synth(st, f.d_scratch8, rows, h->N, h->ldg, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
+                launch_pack_i8(st, f.d_scratch8, h->ldg, (uint8_t*)dst, rows, h->N, h->ld2, f.d_flags);
+            } else launch_synth(st, (int8_t*)dst, rows, h->N, h->ld8, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
+            HIPCHK(hipGetLastError());
+            return GPCA_OK;
+        case GPCA_PANEL_SYNTH16:
+            launch_synth16(st, dst, packed ? 1 : 0, rows, h->N, packed ? h->ld2 : h->ld8, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
+            HIPCHK(hipGetLastError());
+            return GPCA_OK;
+        case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED: {
+            const int b = f.stage_idx; f.stage_idx ^= 1;
+            if (f.stage_pending[b]) { HIPCHK(hipEventSynchronize(f.ev_stage[b])); f.stage_pending[b] = 0; }   // its last copy has left the buffer
+            if (s.fill(s.user, row0, rows, f.h_stage[b], f.stage_ld) != 0) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "panel source callback failed for rows [%lld, %lld)", (long long)row0, (long long)(row0 + rows));
+                return fail(h, GPCA_ERR_BAD_ARG, buf);
+            }
+            if (s.kind == GPCA_PANEL_HOST_BED) {
+                HIPCHK(hipMemcpyAsync(f.d_raw, f.h_stage[b], (size_t)rows * (size_t)f.stage_ld, hipMemcpyHostToDevice, st));
+                if (packed) launch_bed_to_codes(st, f.d_raw, f.stage_ld, (uint8_t*)dst, rows, h->N, h->ld2);
+                else launch_bed_decode(st, f.d_raw, f.stage_ld, (int8_t*)dst, rows, h->N, h->ld8);
+                HIPCHK(hipGetLastError());
+            } else if (packed) {
+                HIPCHK(hipMemcpy2DAsync(f.d_scratch8, (size_t)h->ldg, f.h_stage[b], (size_t)f.stage_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
+                launch_pack_i8(st, f.d_scratch8, h->ldg, (uint8_t*)dst, rows, h->N, h->ld2, f.d_flags);
+                HIPCHK(hipGetLastError());
+            } else {
+                HIPCHK(hipMemcpy2DAsync(dst, (size_t)h->ld8, f.h_stage[b], (size_t)f.stage_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
+            }
+            HIPCHK(hipEventRecord(f.ev_stage[b], st)); f.stage_pending[b] = 1;
+            return GPCA_OK;
+        }
+        default: return fail(h, GPCA_ERR_BAD_ARG, "unknown panel kind");
+    }
+}
+
+extern "C" int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    CHK(check_source(h, src, "gpca_load_from_source"));
+    CHK(alloc_genotypes(h, M, N));
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    if (!packed && h->ld8 != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ld8, h->st));   // pad columns of host-copied rows
+    const int64_t cr = pack_chunk_rows(h);
+    Filler f;
+    int rc = filler_open(h, f, *src, cr, h->st);
+    for (int64_t r0 = 0; r0 < M && rc == GPCA_OK; r0 += cr) {
+        const int64_t rows = std::min(cr, M - r0);
+        void* dst = packed ? (void*)(h->dG2 + (size_t)r0 * h->ld2) : (void*)(h->dG + (size_t)r0 * h->ld8);
+        rc = filler_fill(h, f, r0, rows, dst, h->st);
+    }
+    if (rc == GPCA_OK && f.d_flags) rc = finish_pack_flags(h, f.d_flags, h->st);
+    if (hipStreamSynchronize(h->st) != hipSuccess && rc == GPCA_OK) rc = fail(h, GPCA_ERR_HIP, "gpca_load_from_source: stream failed");
+    filler_close(f);
+    return rc;
+}
+
+extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N, int64_t panel_rows,
+                                int32_t ring_slots) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    CHK(check_source(h, src, "gpca_stream_open"));
+    if (h->precision != GPCA_PREC_I8_EXACT) return fail(h, GPCA_ERR_BAD_ARG, "gpca_stream_open: streamed panels need GPCA_PREC_I8_EXACT (integer partial sums make the panel order irrelevant)");
+    if (ring_slots == 0) ring_slots = 3;
+    if (ring_slots < 2 || ring_slots > 16 || panel_rows < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_stream_open: ring_slots must be in [2, 16], panel_rows >= 0");
+    CHK(alloc_genotypes(h, M, N, /*resident=*/false));
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    const int64_t row_bytes = packed ? h->ld2 : h->ld8;
+    if (panel_rows == 0) {
+        // K1 gives every wave 128 SNP rows and sweeps all samples with them: a panel needs gq_waves_target x 128 rows (131 072)
+        // to fill the chip, however wide the rows are (a 1 GiB panel of 500k-sample rows holds 8k rows and leaves three quarters
+        // of the CUs idle).  Take that many rows when the ring fits in half of the free HBM after the M- and N-sized workspace.
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const double workspace = (double)h->Mpad * (64 * 4 + 2 * 32 * kDigits + 48) + (double)h->ldg * (64 * 8 * 3 + 2 * 32 * kDigits + 32 * 8 * 4);
+        const double budget = 0.5 * ((double)free_b - workspace);
+        int64_t rows = (int64_t)h->gq_waves_target * kGQRowsPerWave;
+        const int64_t fit = (int64_t)(budget / ((double)ring_slots * (double)row_bytes));
+        if (rows > fit) rows = fit;
+        if (src->kind == GPCA_PANEL_HOST_I8 || src->kind == GPCA_PANEL_HOST_BED) {
+            // callback sources also need two pinned host staging panels: keep each within 2 GiB (such a source is bound by the
+            // host link, ~55 GB/s, long before the row-parallel K1 runs out of rows)
+            const int64_t host_ld = src->kind == GPCA_PANEL_HOST_BED ? (N + 3) / 4 : N;
+            const int64_t cap = ((int64_t)2 << 30) / host_ld;
+            if (rows > cap) rows = cap;
+        }
+        panel_rows = rows / kGQRowsPerWave * kGQRowsPerWave;
+        if (panel_rows < kGQRowsPerWave) panel_rows = kGQRowsPerWave;
+    }
+    panel_rows = round_up(std::max<int64_t>(panel_rows, 1), kGQRowsPerWave);
+    if (panel_rows > h->Mpad) panel_rows = h->Mpad;
+    StreamState& sm = h->sm;
+    sm.panel_rows = panel_rows;
+    sm.n_panels = (int)((M + panel_rows - 1) / panel_rows);
+    sm.ring = ring_slots; sm.seq = 0; sm.fused = 1;
+    HIPCHK(hipStreamCreateWithFlags(&sm.st_fill, hipStreamNonBlocking));
+    sm.on = true;   // from here on stream_close() releases whatever was set up
+    int rc = GPCA_OK;
+    for (int i = 0; i < ring_slots && rc == GPCA_OK; ++i) {
+        void* p = nullptr; hipEvent_t a = nullptr, b = nullptr;
+        hipError_t e = hipMalloc(&p, (size_t)panel_rows * (size_t)row_bytes);
+        if (e == hipSuccess) { sm.slot.push_back(p); e = hipMemsetAsync(p, 0, (size_t)panel_rows * (size_t)row_bytes, sm.st_fill); }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
+        if (e == hipSuccess) { sm.ev_filled.push_back(a); e = hipEventCreateWithFlags(&b, hipEventDisableTiming); }
+        if (e == hipSuccess) { sm.ev_free.push_back(b); sm.free_pending.push_back(0); }
+        if (e != hipSuccess) rc = fail(h, e == hipErrorOutOfMemory ? GPCA_ERR_OOM : GPCA_ERR_HIP, std::string("gpca_stream_open: panel ring: ") + hipGetErrorString(e));
+    }
+    if (rc == GPCA_OK) rc = filler_open(h, sm.fl, *src, panel_rows, sm.st_fill);
+    if (rc == GPCA_OK && hipStreamSynchronize(sm.st_fill) != hipSuccess) rc = fail(h, GPCA_ERR_HIP, "gpca_stream_open: stream failed");
+    if (rc != GPCA_OK) { std::string keep = h->err; stream_close(h); h->M = h->N = 0; h->err = keep; }
+    return rc;
+}
+
+extern "C" int gpca_stream_set_fused(gpca_handle* h, int32_t fused) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    if (!h->sm.on) return fail(h, GPCA_ERR_STATE, "gpca_stream_set_fused: no panel stream open");
+    h->sm.fused = fused != 0;
+    return GPCA_OK;
+}
+
+extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t ld) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    if (h->sm.on) return fail(h, GPCA_ERR_STATE, "gpca_download_genotypes_i8: the matrix is streamed, not resident");
+    if (!out || (!h->dG && !h->dG2) || ld < h->N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_download_genotypes_i8: bad arguments / nothing resident");
+    if (h->storage == GPCA_STORE_2BIT) {   // debug/test path: copy the packed rows and unpack on the host
+        HIPCHK(hipStreamSynchronize(h->st));
+        std::vector<uint8_t> row((size_t)h->ld2);
+        static const int8_t lut[4] = {0, 1, 2, -127};
+        for (int64_t i = 0; i < h->M; ++i) {
+            HIPCHK(hipMemcpy(row.data(), h->dG2 + (size_t)i * h->ld2, (size_t)h->ld2, hipMemcpyDeviceToHost));
+            for (int64_t n = 0; n < h->N; ++n) out[i * ld + n] = lut[(row[(size_t)(n >> 2)] >> (2 * (n & 3))) & 3];
+        }
+        return GPCA_OK;
+    }
+    HIPCHK(hipMemcpy2D(out, (size_t)ld, h->dG, (size_t)h->ld8, (size_t)h->N, (size_t)h->M, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    if (M) *M = h->M;
+    if (N) *N = h->N;
+    return GPCA_OK;
+}
+

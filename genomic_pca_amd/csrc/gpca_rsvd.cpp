@@ -1,0 +1,581 @@
+// The randomized-PCA driver: host eigen step, the stages over the resident matrix or the streamed panels, gpca_rsvd, result getters,
+// gpca_transform (include/gpca.h section a5/a6).
+#include "gpca_internal.h"
+
+using namespace gpca;
+
+// ---- small dense (host, f64) ----------------------------------------------------------------------------------
+// Symmetric eigenproblem of the l x l Gram of the projection (l <= 64): Householder tridiagonalisation + implicit QL
+// (the EISPACK tred2 / tql2 pair).  It replaced a cyclic Jacobi solver: at l = 30 Jacobi's ~8 sweeps of 435 rotations kept
+// the stream idle for ~190 us per call while the host worked; this pair needs ~20 us.  (The parity checker of tests/ uses LAPACK,
+// oracle/oracle.py:rsvd -- no code in common.)  A: symmetric, row-major, destroyed; V: eigenvectors in columns; w: eigenvalues,
+// sorted descending.
+static void tred2(int n, double* V, double* d, double* e) {
+    for (int j = 0; j < n; ++j) d[j] = V[(n - 1) * n + j];
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = V[(i - 1) * n + j]; V[i * n + j] = 0.0; V[j * n + i] = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g; h -= f * g; d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; V[j * n + i] = f; g = e[j] + V[j * n + j] * f;
+                for (int k = j + 1; k <= i - 1; ++k) { g += V[k * n + j] * d[k]; e[k] += V[k * n + j] * f; }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; g = e[j];
+                for (int k = j; k <= i - 1; ++k) V[k * n + j] -= (f * e[k] + g * d[k]);
+                d[j] = V[(i - 1) * n + j]; V[i * n + j] = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    for (int i = 0; i < n - 1; ++i) {        // accumulate the transformations
+        V[(n - 1) * n + i] = V[i * n + i]; V[i * n + i] = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = V[k * n + (i + 1)] / h;
+            for (int j = 0; j <= i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += V[k * n + (i + 1)] * V[k * n + j];
+                for (int k = 0; k <= i; ++k) V[k * n + j] -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) V[k * n + (i + 1)] = 0.0;
+    }
+    for (int j = 0; j < n; ++j) { d[j] = V[(n - 1) * n + j]; V[(n - 1) * n + j] = 0.0; }
+    V[(n - 1) * n + (n - 1)] = 1.0; e[0] = 0.0;
+}
+static void tql2(int n, double* V, double* d, double* e) {
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n - 1 && std::fabs(e[m]) > eps * tst1) ++m;     // e[n-1] = 0 ends the search
+        if (m > l) {
+            int iter = 0;
+            do {
+                ++iter;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r); d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i]; h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r; s = e[i] / r; c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        h = V[k * n + i + 1];
+                        V[k * n + i + 1] = s * V[k * n + i] + c * h;
+                        V[k * n + i] = c * V[k * n + i] - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p; d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1 && iter < 200);
+        }
+        d[l] += f; e[l] = 0.0;
+    }
+}
+static void host_eigh_desc(std::vector<double>& A, std::vector<double>& V, std::vector<double>& w, int n) {
+    std::vector<double> e((size_t)n);
+    V = A;
+    if (n == 1) { w[0] = A[0]; V[0] = 1.0; return; }
+    tred2(n, V.data(), w.data(), e.data());
+    tql2(n, V.data(), w.data(), e.data());
+    for (int i = 0; i < n - 1; ++i) {        // selection sort, descending
+        int m = i;
+        for (int j = i + 1; j < n; ++j) if (w[j] > w[m]) m = j;
+        if (m != i) { std::swap(w[i], w[m]); for (int k = 0; k < n; ++k) std::swap(V[k * n + i], V[k * n + m]); }
+    }
+}
+// test hook (host only, no GPU): eigen-decomposition of a symmetric n x n row-major matrix, eigenvalues descending
+extern "C" int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, double* v) {
+    if (!a_sym || !w || !v || n < 1 || n > 64) return GPCA_ERR_BAD_ARG;
+    std::vector<double> A(a_sym, a_sym + (size_t)n * n), V((size_t)n * n), W((size_t)n);
+    host_eigh_desc(A, V, W, n);
+    std::copy(W.begin(), W.end(), w); std::copy(V.begin(), V.end(), v);
+    return GPCA_OK;
+}
+
+// ---- rsvd stages -----------------------------------------------------------------------------------------------
+static int stage_sum_c(gpca_handle* h, int64_t parts) {
+    launch_sum_partials_f32(h->st, h->d_cpart, parts, h->L, h->d_c, h->d_scratch64);
+    HIPCHK(hipGetLastError());
+    return GPCA_OK;
+}
+
+
+// K2 of one 32-column half over one panel: Ypart = (digit planes of T')^T G, exact integers
+static int k2_panel(gpca_handle* h, const PanelView& pv, const int8_t* Td_half, const Gtt8Plan& plan) {
+    const int8_t* Td = Td_half + (size_t)(pv.row0 >> 5) * kPlaneBytesPerBlock;
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    if (h->lds_planes && h->gtt_dma && !packed) {
+        const int e = launch_gtt_d(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d launch failed (hip error " + std::to_string(e) + ")");
+    } else if (((h->lds_planes && h->gtt_dma) || h->nd == 3) && packed) {   // (three planes: only this kernel)
+        const int e = launch_gtt_p(h->st, pv.g2, h->ld2, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->nd, h->ko);
+        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_p launch failed (hip error " + std::to_string(e) + ")");
+    } else if (h->lds_planes) launch_gtt_x(h->st, packed ? (const void*)pv.g2 : (const void*)pv.g8, packed, packed ? h->ld2 : h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+    else if (packed) launch_gtt_2bit(h->st, pv.g2, h->ld2, pv.rows_pad, h->ldg, Td, h->dYpart64, plan);
+    else launch_gtt_i8(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+    HIPCHK(hipGetLastError());
+    return GPCA_OK;
+}
+
+// Y = A^T T  (T' = r o T already in dT, c = b^T T in d_c); rank-local part, the exchange of Y follows in the caller
+static int stage_AtT_local(gpca_handle* h) {
+    const double elems = (double)h->M * (double)h->N;
+    if (h->precision == GPCA_PREC_I8_EXACT) {
+        // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64.
+        // The kernels are 32 columns wide: a 64-column sketch (32 < l <= 64) runs as two column halves over the same genotypes.
+        const int L = h->L, halves = L / 32;
+        const size_t td_half = (size_t)h->Mpad * 32 * kDigits;
+        for (int hf = 0; hf < halves; ++hf) {
+            const float* Th = h->dT + 32 * hf;
+            double* tsc = h->d_tscale + 32 * hf; double* tin = h->d_tinv + 32 * hf;
+            if (h->apart_valid) launch_quantize_f32_premax(h->st, Th, h->Mpad, h->Mpad, h->apart_src[hf], h->apart_parts, tsc, tin, h->dTd + hf * td_half, 0, h->nd, L);
+            else launch_quantize_f32(h->st, Th, h->Mpad, h->Mpad, h->d_part64, tsc, tin, h->dTd + hf * td_half, 0, h->nd, L);
+            HIPCHK(hipGetLastError());
+        }
+        h->apart_valid = false;
+        const bool streamed = h->sm.on;
+        const size_t yint_half = (size_t)h->N * 32;
+        {
+            // resident: one record per launch (the roofline figure of bench.py); streamed: one record per sweep over the panels
+            const double by = h->storage == GPCA_STORE_2BIT ? elems / 4 : elems;
+            ScopedTimer sweep(h, "gemm_GtT", 2.0 * elems * h->l, by * halves, nullptr, streamed);
+            CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
+                const Gtt8Plan plan = streamed ? gtt8_plan(pv.rows_pad, h->ldg, h->gtt_waves_target) : h->plan8;
+                for (int hf = 0; hf < halves; ++hf) {
+                    {
+                        ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l / halves, by, nullptr, !streamed);
+                        CHK(k2_panel(h, pv, h->dTd + hf * td_half, plan));
+                    }
+                    if (streamed) launch_accum_y_i8(h->st, h->dYpart64, plan.W, h->ldg, h->N, h->d_yint + hf * yint_half, pv.index == 0);
+                    else launch_reduce_y_i8(h->st, h->dYpart64, plan.W, h->ldg, h->N, h->d_c + 32 * hf, h->d_tscale + 32 * hf, h->dY + 32 * hf, L);
+                    HIPCHK(hipGetLastError());
+                }
+                return GPCA_OK;
+            }));
+        }
+        if (streamed)
+            for (int hf = 0; hf < halves; ++hf) {
+                launch_finish_y_i8(h->st, h->d_yint + hf * yint_half, h->N, h->d_c + 32 * hf, h->d_tscale + 32 * hf, h->dY + 32 * hf, L);
+                HIPCHK(hipGetLastError());
+            }
+        return GPCA_OK;
+    }
+    {
+        const bool packed = h->storage == GPCA_STORE_2BIT;
+        ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l, packed ? elems / 4 : elems);
+        launch_gtt_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ld8, h->Mpad, h->ldg, h->dTb, h->L, h->dYpart, h->plan);
+    }
+    HIPCHK(hipGetLastError());
+    launch_reduce_y(h->st, h->dYpart, h->plan.W, h->ldg, h->N, h->L, h->d_c, h->dY);
+    HIPCHK(hipGetLastError());
+    return GPCA_OK;
+}
+
+// T = A Q (scale_out: r o T and c)
+static int stage_AQ(gpca_handle* h, int scale_out) {
+    const double elems = (double)h->M * (double)h->N;
+    if (h->precision == GPCA_PREC_I8_EXACT) {
+        const int L = h->L, halves = L / 32;
+        const bool packed = h->storage == GPCA_STORE_2BIT, streamed = h->sm.on;
+        const size_t qhalf = (size_t)h->ldg * 32 * kDigits;            // digit planes of one 32-column half of Q
+        const size_t chalf = (size_t)h->Mpad;                           // per-unit partials of c of one half: [Mpad / 32][32]
+        const size_t ahalf = (size_t)h->gqplan.waves * 32;              // per-wave abs-max partials of one launch
+        if (streamed && scale_out) HIPCHK(hipMemsetAsync(h->d_amax_run, 0, 64 * 8, h->st));
+        {
+            const double by = packed ? elems / 4 : elems;
+            ScopedTimer sweep(h, "gemm_GQ", 2.0 * elems * h->l, by * halves, nullptr, streamed);
+            CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
+                const GqPlan plan = streamed ? gq_plan(pv.rows_pad, h->gq_waves_target) : h->gqplan;
+                for (int hf = 0; hf < halves; ++hf) {
+                    const int8_t* Qd = h->dQd + hf * qhalf;
+                    const double* qsc = h->d_qscale + 32 * hf;
+                    const float* s32 = h->d_s32 + 32 * hf;
+                    const float* rr = h->d_r + pv.row0; const float* bb = h->d_b + pv.row0;
+                    float* Th = h->dT + (size_t)pv.row0 * L + 32 * hf;
+                    float* cp = h->d_cpart + hf * chalf + (size_t)pv.row0;          // (row0 / 32) units x 32 columns
+                    double* ap = h->d_apart + hf * ahalf;
+                    ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l / halves, by, nullptr, !streamed);
+                    if (packed) launch_gq_2bit(h->st, pv.g2, h->ld2, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, h->nd, L);
+                    else if (h->lds_planes && h->gq_dma) {
+                        const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
+                        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
+                    }
+                    else if (h->lds_planes) launch_gq_x(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
+                    else launch_gq_i8(h->st, pv.g8, h->ld8, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, scale_out, L, h->ko);
+                    HIPCHK(hipGetLastError());
+                    if (streamed && scale_out && (packed || h->lds_planes)) {   // (streamed: the per-launch timer above is disabled) fold this panel's column abs-max before the next launch reuses ap
+                        launch_absmax_fold(h->st, ap, plan.waves, h->d_amax_run + 32 * hf);
+                        HIPCHK(hipGetLastError());
+                    }
+                }
+                return GPCA_OK;
+            }));
+        }
+        if (scale_out)
+            for (int hf = 0; hf < halves; ++hf) {   // c = b^T T of this half: one partial per 32-row unit, summed in a fixed order
+                launch_sum_partials_f32(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, 32, h->d_c + 32 * hf, h->d_scratch64);
+                HIPCHK(hipGetLastError());
+            }
+        h->apart_valid = scale_out != 0 && (packed || h->lds_planes);   // (k_gq_i8 has no abs-max epilogue)
+        for (int hf = 0; hf < 2; ++hf) h->apart_src[hf] = streamed ? h->d_amax_run + 32 * hf : h->d_apart + hf * ahalf;
+        h->apart_parts = streamed ? 1 : h->gqplan.waves;
+        return GPCA_OK;
+    }
+    {
+        const bool packed = h->storage == GPCA_STORE_2BIT;
+        ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l, packed ? elems / 4 : elems);
+        launch_gq_f32(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, packed, packed ? h->ld2 : h->ld8, h->gqplan, h->ldg, h->dQ, h->L, h->d_r, h->d_b,
+                      h->d_s32, h->dT, scale_out ? h->dTb : nullptr, h->d_cpart);
+    }
+    HIPCHK(hipGetLastError());
+    if (scale_out) CHK(stage_sum_c(h, h->gqplan.waves));
+    return GPCA_OK;
+}
+
+// One power iteration Y = A^T (A Q) of a STREAMED matrix with every panel read once: K1 on the panel (its rows of T' = r o (A Q), its
+// units' shares of c, its column maxima), the panel's rows of T' quantised against the panel's own maxima, K2 on the same panel,
+// and the panel's integer sums added into Yacc with the panel's scale.  4 passes over the source per call instead of 6 -- the
+// "fused read" SURVEY.md 8(d) counts, which HBM-resident data cannot use (no on-chip room for the N x l accumulators) but a
+// panel that sits in HBM between its two kernels can.  Per-panel scales put the 28-bit fixed point on a per-panel grid, so the
+// result differs from the resident engine at the 1e-9 level, like a row-sharded run does; gpca_stream_set_fused(h, 0) selects
+// the 6-pass form that is bit-identical to the resident engine.
+static int stage_power_fused(gpca_handle* h) {
+    const double elems = (double)h->M * (double)h->N;
+    const int L = h->L, halves = L / 32;
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    const size_t qhalf = (size_t)h->ldg * 32 * kDigits, chalf = (size_t)h->Mpad, ahalf = (size_t)h->gqplan.waves * 32;
+    const size_t td_half = (size_t)h->Mpad * 32 * kDigits, yint_half = (size_t)h->N * 32;
+    {
+        const double by = packed ? elems / 4 : elems;
+        ScopedTimer sweep(h, "gemm_fused", 4.0 * elems * h->l, by * halves);
+        CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
+            const GqPlan plan1 = gq_plan(pv.rows_pad, h->gq_waves_target);
+            const Gtt8Plan plan2 = gtt8_plan(pv.rows_pad, h->ldg, h->gtt_waves_target);
+            const float* rr = h->d_r + pv.row0; const float* bb = h->d_b + pv.row0;
+            for (int hf = 0; hf < halves; ++hf) {
+                const int8_t* Qd = h->dQd + hf * qhalf;
+                float* Th = h->dT + (size_t)pv.row0 * L + 32 * hf;
+                float* cp = h->d_cpart + hf * chalf + (size_t)pv.row0;
+                double* ap = h->d_apart + hf * ahalf;
+                if (packed) launch_gq_2bit(h->st, pv.g2, h->ld2, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, h->nd, L);
+                else if (h->gq_dma) {
+                    const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
+                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
+                } else launch_gq_x(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
+                HIPCHK(hipGetLastError());
+                // this panel's rows of T' -> digit planes against this panel's column maxima
+                launch_quantize_f32_premax(h->st, Th, pv.rows_pad, pv.rows_pad, ap, plan1.waves, h->d_tscale + 32 * hf, h->d_tinv + 32 * hf,
+                                           h->dTd + hf * td_half + (size_t)(pv.row0 >> 5) * kPlaneBytesPerBlock, 0, h->nd, L);
+                HIPCHK(hipGetLastError());
+            }
+            for (int hf = 0; hf < halves; ++hf) {
+                CHK(k2_panel(h, pv, h->dTd + hf * td_half, plan2));
+                launch_accum_y_scaled(h->st, h->dYpart64, plan2.W, h->ldg, h->N, h->d_tscale + 32 * hf, h->d_yint + hf * yint_half, pv.index == 0);
+                HIPCHK(hipGetLastError());
+            }
+            return GPCA_OK;
+        }));
+    }
+    for (int hf = 0; hf < halves; ++hf) {
+        launch_sum_partials_f32(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, 32, h->d_c + 32 * hf, h->d_scratch64);
+        HIPCHK(hipGetLastError());
+        launch_finish_y_sum(h->st, h->d_yint + hf * yint_half, h->N, h->d_c + 32 * hf, h->dY + 32 * hf, L);
+        HIPCHK(hipGetLastError());
+    }
+    h->apart_valid = false;
+    return GPCA_OK;
+}
+
+// CholeskyQR2 of dY -> dQ (f32, padded), s = 1^T Q
+static int stage_orth(gpca_handle* h) {
+    const int L = h->L, l = h->l;
+    for (int round = 0; round < 2; ++round) {      // CholeskyQR2, entirely on the stream (no host round trip)
+        const int64_t parts = gram_num_parts(h->N);
+        launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
+        HIPCHK(hipGetLastError());
+        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
+        HIPCHK(hipGetLastError());
+        launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
+        HIPCHK(hipGetLastError());
+        if (round == 0) launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, nullptr, h->ldg);
+        else launch_apply_right_tail(h->st, h->dY, h->N, L, h->dZ, h->dQ, h->ldg, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L);
+        HIPCHK(hipGetLastError());
+    }
+    // dY now holds the orthonormal basis in f64: s = Q^T 1 and (exact-integer path) the digit scale of Q, then its planes
+    const bool i8 = h->precision == GPCA_PREC_I8_EXACT;
+    launch_finish_q(h->st, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L, tail_num_parts(h->ldg), L, h->d_s64, h->d_s32,
+                    i8 ? h->d_qscale : nullptr, i8 ? h->d_qinv : nullptr, h->nd);
+    HIPCHK(hipGetLastError());
+    if (i8) {
+        for (int hf = 0; hf < L / 32; ++hf) {
+            launch_quantize_f64_prescaled(h->st, h->dY + 32 * hf, h->N, h->ldg, h->d_qinv + 32 * hf, h->dQd + (size_t)hf * h->ldg * 32 * kDigits,
+                                          h->storage == GPCA_STORE_2BIT ? 1 : 0, h->nd, L);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return GPCA_OK;
+}
+
+static int ensure_workspace(gpca_handle* h) {
+    const int L = h->L;
+    const int64_t Npad = h->ldg, M = h->M, N = h->N;
+    // streamed mode: the GEMM grids are sized per panel (all panels but the last have panel_rows rows)
+    const int64_t gemm_rows = h->sm.on ? h->sm.panel_rows : h->Mpad;
+    h->plan = gtt_plan(h->Mpad, Npad, L, h->gtt_waves_target);
+    h->gqplan = gq_plan(gemm_rows, h->gq_waves_target);
+    CHK(ensure(h, h->dQ, h->cap_Q, (size_t)Npad * L));
+    CHK(ensure(h, h->dT, h->cap_T, (size_t)h->Mpad * L));
+    if (h->precision == GPCA_PREC_F32_MFMA) CHK(ensure(h, h->dTb, h->cap_Tb, (size_t)h->Mpad * L));
+    if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dT + (size_t)M * L, 0, (size_t)(h->Mpad - M) * L * 4, h->st));
+    if (h->precision == GPCA_PREC_F32_MFMA) CHK(ensure(h, h->dYpart, h->cap_Ypart, (size_t)h->plan.W * (size_t)Npad * L));
+    // c partials: per wave x L (f32 path, Omega: 64-row groups), or per 32-row unit x 32 per column half (exact path)
+    const int64_t cparts = std::max({h->gqplan.waves * (int64_t)L, omega_num_parts(h->Mpad) * (int64_t)L, h->Mpad * (int64_t)(L / 32)});
+    CHK(ensure(h, h->d_cpart, h->cap_cpart, (size_t)cparts));
+    CHK(ensure(h, h->dY, h->cap_Y, (size_t)N * L));
+    const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L, absmax_num_parts(h->Mpad) * (int64_t)32, 2 * tail_num_parts(Npad) * (int64_t)L});
+    CHK(ensure(h, h->d_part64, h->cap_part64, (size_t)p64));
+    if (!h->d_c) {
+        HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));
+        HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, 64 * 64 * 8));
+        HIPCHK(hipMalloc((void**)&h->dZ, 2 * 64 * 64 * 8));
+        HIPCHK(hipHostMalloc((void**)&h->h_pin, (3 * 64 * 64 + 16) * 8, hipHostMallocDefault)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
+        HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
+        HIPCHK(hipMalloc((void**)&h->d_cholflag, 4));
+    }
+    if (h->precision == GPCA_PREC_I8_EXACT) {
+        h->plan8 = gtt8_plan(gemm_rows, Npad, h->gtt_waves_target);
+        CHK(ensure(h, h->dQd, h->cap_Qd, (size_t)Npad * 32 * kDigits * (size_t)(L / 32)));
+        CHK(ensure(h, h->dTd, h->cap_Td, (size_t)h->Mpad * 32 * kDigits * (size_t)(L / 32)));
+        CHK(ensure(h, h->dYpart64, h->cap_Ypart64, (size_t)h->plan8.W * (size_t)Npad * 32));
+        CHK(ensure(h, h->d_apart, h->cap_apart, (size_t)h->gqplan.waves * 32 * (size_t)(L / 32)));
+        if (h->sm.on) CHK(ensure(h, h->d_yint, h->cap_yint, (size_t)N * 32 * (size_t)(L / 32)));
+        if (!h->d_qscale) {
+            HIPCHK(hipMalloc((void**)&h->d_qscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, 64 * 8));
+            HIPCHK(hipMalloc((void**)&h->d_tscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, 64 * 8));
+            HIPCHK(hipMalloc((void**)&h->d_amax_run, 64 * 8));
+        }
+    }
+    size_t cap2 = h->cap_scores;
+    CHK(ensure(h, h->d_scores64, h->cap_scores, (size_t)N * h->k));
+    CHK(ensure(h, h->d_scores32, cap2, (size_t)N * h->k));
+    CHK(ensure(h, h->d_load32, h->cap_load, (size_t)std::max<int64_t>(h->n_pca, 1) * h->k));
+    return GPCA_OK;
+}
+
+// argument / state checks of gpca_rsvd + workspace: everything that can fail on one rank only before the first exchange
+static int rsvd_preflight(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters) {
+    if (!have_genotypes(h)) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: no genotypes resident and no panel stream open");
+    if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: run gpca_snp_stats or gpca_set_standardization first");
+    if (k <= 0) return fail(h, GPCA_ERR_BAD_ARG, "Number of components (-k) must be > 0.");  // main.rs:607-609
+    if (oversample < 0 || power_iters < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: negative oversample/power_iters");
+    if (h->N < 2) return fail(h, GPCA_ERR_BAD_ARG, "PCA requires at least 2 samples.");   // main.rs:614-616
+    if (!multi_rank(h) && h->n_pca == 0) return fail(h, GPCA_ERR_BAD_ARG, "PCA requires at least 1 variant (feature), found 0.");  // main.rs:617-619
+    const int l = k + oversample;
+    if (l > 64) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: k + oversample must be <= 64");
+    if (l > h->N || (!multi_rank(h) && l > h->n_pca)) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: k + oversample exceeds min(samples, PCA SNPs)");
+    if (h->flags & 1u) return fail(h, GPCA_ERR_MISSING_GENOTYPE,
+        "Unexpected missing genotype (-127i8) in a PCA SNP. This should have been filtered by QC.");  // prepare.rs:1909-1911
+    if (h->flags & 2u) return fail(h, GPCA_ERR_INVALID_GENOTYPE, "a PCA SNP holds a dosage outside {0,1,2}");
+    if (h->sm.on && h->precision != GPCA_PREC_I8_EXACT) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: streamed panels need GPCA_PREC_I8_EXACT");
+    HIPCHK(hipSetDevice(h->device));
+    h->k = k; h->l = l; h->L = l <= 32 ? 32 : 64;
+    h->have_rsvd = false;
+    CHK(ensure_workspace(h));
+    HIPCHK(hipMemsetAsync(h->d_cholflag, 0, 4, h->st));
+    return GPCA_OK;
+}
+
+extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    // Ranks of a sharded run leave together: agree on the preflight status before the first exchange ...
+    int lrc = agree_status(h, rsvd_preflight(h, k, oversample, power_iters), "gpca_rsvd (before the sketch)");
+    if (lrc != GPCA_OK) return lrc;
+    const int l = h->l, L = h->L;
+    const bool mr = multi_rank(h);
+    // ... and from here on a rank-local failure is remembered (lrc) while the rank keeps entering every exchange of the call, so
+    // that its peers are not left inside a collective; the second agreement below returns the failure on every rank.
+#define LOCAL(x) do { if (lrc == GPCA_OK) lrc = (x); if (lrc != GPCA_OK && !mr) return lrc; } while (0)
+#define EXCHANGE(buf, count) do { const int xrc_ = allreduce_f64(h, (buf), (count)); if (xrc_ != GPCA_OK) return xrc_; } while (0)
+    auto omega = [&]() -> int {
+        // 1. sketch: T' = r o Omega, c = b^T Omega
+        ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
+        if (h->precision == GPCA_PREC_I8_EXACT) {
+            HIPCHK(hipMemsetAsync(h->d_apart, 0, 32 * 8, h->st));
+            launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart, L == 32 ? h->d_apart : nullptr, 0);
+            h->apart_valid = L == 32; h->apart_parts = 1; h->apart_src[0] = h->d_apart; h->apart_src[1] = nullptr;
+        } else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart, nullptr, 1);
+        HIPCHK(hipGetLastError());
+        return GPCA_OK;
+    };
+    LOCAL(omega());
+    LOCAL(stage_sum_c(h, omega_num_parts(h->Mpad)));
+    LOCAL(stage_AtT_local(h));                       // Y = A^T Omega
+    EXCHANGE(h->dY, h->N * (int64_t)L);
+    LOCAL(stage_orth(h));
+    // 2. power iterations
+    const bool fused = h->sm.on && h->sm.fused && (h->storage == GPCA_STORE_2BIT || h->lds_planes);   // (k_gq_i8 has no abs-max epilogue)
+    for (int it = 0; it < power_iters; ++it) {
+        if (fused) LOCAL(stage_power_fused(h));
+        else { LOCAL(stage_AQ(h, 1)); LOCAL(stage_AtT_local(h)); }
+        EXCHANGE(h->dY, h->N * (int64_t)L);
+        LOCAL(stage_orth(h));
+    }
+    // 3. projection B = A Q, small eigenproblem of B^T B
+    LOCAL(stage_AQ(h, 0));
+    auto gram_b = [&]() -> int {
+        const int64_t parts = gram_num_parts(h->M);
+        launch_gram_f32(h->st, h->dT, h->M, L, h->d_part64);
+        HIPCHK(hipGetLastError());
+        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
+        HIPCHK(hipGetLastError());
+        return GPCA_OK;
+    };
+    LOCAL(gram_b());
+    EXCHANGE(h->dW, (int64_t)L * L);
+    // The only host step: the l x l eigenproblem.  Pinned staging + a busy-polled stream keep the round trip short
+    // (pageable copies and a sleeping hipStreamSynchronize cost ~220 us here); everything after it is enqueued at once.
+    std::vector<double> C((size_t)l * l), V((size_t)l * l), w((size_t)l);
+    double* Wfull = h->h_pin;
+    double* Zpin = h->h_pin + 64 * 64;                    // [scores Z (L x k) | loadings Z (L x k)]
+    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * 64 * 64);
+    auto fetch_w = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipMemcpyAsync(flagpin, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(stream_wait(h));
+        if (*flagpin) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not positive (rank-deficient sketch)", *flagpin - 1, l);
+            return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
+        }
+        return GPCA_OK;
+    };
+    LOCAL(fetch_w());
+    lrc = agree_status(h, lrc, "gpca_rsvd (after the last exchange)");
+    if (lrc != GPCA_OK) return lrc;
+#undef LOCAL
+#undef EXCHANGE
+    for (int a2 = 0; a2 < l; ++a2) for (int c = 0; c < l; ++c) C[(size_t)a2 * l + c] = 0.5 * (Wfull[(size_t)a2 * L + c] + Wfull[(size_t)c * L + a2]);
+    host_eigh_desc(C, V, w, l);
+    h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
+    for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
+    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
+    // 4. scores = Q V_k diag(s) ; sign ; loadings = B V_k diag(sign/s)   (the sign is applied to the loadings' Z on the device)
+    const size_t zk = (size_t)L * k;
+    for (size_t e = 0; e < 2 * zk; ++e) Zpin[e] = 0.0;
+    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) {
+        Zpin[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
+        Zpin[zk + (size_t)j * k + c] = h->sv[(size_t)c] > 0 ? V[(size_t)j * l + c] / h->sv[(size_t)c] : 0.0;
+    }
+    HIPCHK(hipMemcpyAsync(h->dZ, Zpin, sizeof(double) * 2 * zk, hipMemcpyHostToDevice, h->st));
+    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);   // dY = Q in f64
+    HIPCHK(hipGetLastError());
+    launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
+    HIPCHK(hipGetLastError());
+    launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
+    HIPCHK(hipGetLastError());
+    launch_scale_cols(h->st, h->dZ + zk, (float*)nullptr, L, k, h->d_sign);
+    HIPCHK(hipGetLastError());
+    launch_rightmul_gather_f32(h->st, h->dT, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);
+    HIPCHK(hipGetLastError());
+    HIPCHK(stream_wait(h));
+    h->have_rsvd = true;
+    return GPCA_OK;
+}
+
+#define NEED_RSVD(name) \
+    if (!h || !out) return GPCA_ERR_BAD_ARG; \
+    LOCK(h); \
+    if (!h->have_rsvd) return fail(h, GPCA_ERR_STATE, name ": run gpca_rsvd first")
+
+extern "C" int gpca_get_scores(gpca_handle* h, float* out) {
+    NEED_RSVD("gpca_get_scores");
+    HIPCHK(hipMemcpy(out, h->d_scores32, (size_t)h->N * h->k * 4, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+extern "C" int gpca_get_scores_f64(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_get_scores_f64");
+    HIPCHK(hipMemcpy(out, h->d_scores64, (size_t)h->N * h->k * 8, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+extern "C" int gpca_get_eigenvalues(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_get_eigenvalues");
+    std::copy(h->eig.begin(), h->eig.end(), out);
+    return GPCA_OK;
+}
+extern "C" int gpca_get_singular_values(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_get_singular_values");
+    std::copy(h->sv.begin(), h->sv.end(), out);
+    return GPCA_OK;
+}
+extern "C" int gpca_get_loadings(gpca_handle* h, float* out) {
+    NEED_RSVD("gpca_get_loadings");
+    if (h->n_pca) HIPCHK(hipMemcpy(out, h->d_load32, (size_t)h->n_pca * h->k * 4, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+
+// PCA::transform (main.rs:659): scores = A^T U on the resident (or streamed) matrix, U = loadings.
+extern "C" int gpca_transform(gpca_handle* h, double* out) {
+    NEED_RSVD("gpca_transform");
+    HIPCHK(hipSetDevice(h->device));
+    const int L = h->L, k = h->k;
+    const bool mr = multi_rank(h);
+    int lrc = GPCA_OK;
+#define LOCAL(x) do { if (lrc == GPCA_OK) lrc = (x); if (lrc != GPCA_OK && !mr) return lrc; } while (0)
+    auto prep = [&]() -> int {
+        // T' = r o U (zero rows for dropped SNPs), c = b^T U
+        HIPCHK(hipMemsetAsync(h->dT, 0, (size_t)h->Mpad * L * 4, h->st));
+        launch_expand_loadings(h->st, h->d_load32, h->d_pca_rows, h->n_pca, k, L, h->dT);
+        HIPCHK(hipGetLastError());
+        if (h->precision == GPCA_PREC_I8_EXACT) launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dT, h->d_cpart, 0);   // in place, row-major
+        else launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dTb, h->d_cpart);
+        HIPCHK(hipGetLastError());
+        h->apart_valid = false;
+        return stage_sum_c(h, omega_num_parts(h->Mpad));
+    };
+    LOCAL(prep());
+    LOCAL(stage_AtT_local(h));
+    { const int xrc = allreduce_f64(h, h->dY, h->N * (int64_t)L); if (xrc != GPCA_OK) return xrc; }
+    lrc = agree_status(h, lrc, "gpca_transform");
+    if (lrc != GPCA_OK) return lrc;
+#undef LOCAL
+    std::vector<double> Y((size_t)h->N * L);
+    HIPCHK(hipMemcpyAsync(Y.data(), h->dY, (size_t)h->N * L * 8, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    for (int64_t n = 0; n < h->N; ++n) for (int c = 0; c < k; ++c) out[n * k + c] = Y[(size_t)n * L + c];
+    h->have_rsvd = true;  // dT (=B) is consumed, but scores/loadings/eigenvalues stay valid
+    return GPCA_OK;
+}
+
