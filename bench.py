@@ -244,8 +244,8 @@ def streamed_main(a, g, rank, world, local_rank, dist, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--snps", type=int, default=1_000_000, help="SNP rows per GPU")
     ap.add_argument("--samples", type=int, default=10_000)
     ap.add_argument("--components", "-k", type=int, default=20)

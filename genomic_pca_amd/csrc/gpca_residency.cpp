@@ -51,6 +51,9 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     h->M = M; h->N = N; h->Mpad = round_up(M, kGQRowsPerWave); h->pack_flags = 0;
     if (h->storage == GPCA_STORE_2BIT) {
         h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4; h->ld8 = h->ldg;
+        // row pitch an odd multiple of 256 B, like the int8 rows below: 1.9 % on the packed K1 (in-process A/B, both engine orders:
+        // 1.145 / 1.142 ms padded vs 1.167 / 1.164), nothing on K2; GPCA_PITCH_PAD=0 restores ldg / 4
+        if (!(getenv("GPCA_PITCH_PAD") && atoi(getenv("GPCA_PITCH_PAD")) == 0) && !((h->ld2 / 256) & 1)) h->ld2 += 256;
         if (!resident) return GPCA_OK;
         HIPCHK(hipMalloc((void**)&h->dG2, (size_t)h->Mpad * (size_t)h->ld2));
         if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG2 + (size_t)M * (size_t)h->ld2, 0, (size_t)(h->Mpad - M) * (size_t)h->ld2, h->st));

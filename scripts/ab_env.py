@@ -20,7 +20,7 @@ engs = []
 for setting in (a, b):
     name, val = setting.split("=")
     os.environ[name] = val
-    e = g.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_INT8)
+    e = g.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT if os.environ.get("GPCA_AB_STORAGE") == "2bit" else _lib.STORE_INT8)
     e.synth_genotypes(M, N, 1, th)          # (GPCA_PITCH_PAD is read when the matrix is allocated)
     os.environ.pop(name)
     e.snp_stats(g.QcConfig.none(), fetch=False)

@@ -27,7 +27,7 @@ if ks:
     rows = list(csv.DictReader(open(ks[0])))
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
         f.write(open(ks[0]).read())
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (5 timed + 1 warm-up step per path; default = exact-integer path, then the f32-MFMA path)", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (20 timed + 2 warm-up steps per path; default = exact-integer path, then the f32-MFMA path, 2-bit residency, three planes)", "",
               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for r in rows[:22]:
         lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
