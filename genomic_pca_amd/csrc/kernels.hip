@@ -215,11 +215,17 @@ __global__ __launch_bounds__(256) void k_snp_stats(const int8_t* __restrict__ G,
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const uint4* p = reinterpret_cast<const uint4*>(G + row * ld);
-    const int64_t nvec = (N + 15) >> 4;  // the row's samples; bytes between N and the pitch are zero pads (the pitch may exceed the padded sample count)
+    // The row pitch is an odd multiple of 256 B (alloc_genotypes), so rows start 0/256/512/768 B into a KiB: the sweep runs over
+    // KiB-ALIGNED wave loads (64 lanes x 16 B = 8 whole lines; unaligned they touch 9 and the pass was 13 % slower) starting at the
+    // KiB that holds the row start, and the lanes in front of the row start sit the first trip out.
+    const uintptr_t rstart = reinterpret_cast<uintptr_t>(G + row * ld);
+    const int64_t skip = (int64_t)((rstart & 1023u) >> 4);                       // 16-byte vectors between the KiB boundary and the row
+    const uint4* p = reinterpret_cast<const uint4*>(rstart & ~(uintptr_t)1023u);
+    const int64_t nvec = skip + ((N + 15) >> 4);  // the row's samples; bytes between N and the pitch are zero pads
     int nmiss = 0, sum = 0, sq = 0;
     unsigned weird = 0;
     for (int64_t v0 = lane; v0 < nvec; v0 += 64) {
+        if (v0 < skip) continue;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + v0);   // one pass, nothing re-read: nt
         const unsigned w[4] = {q.x, q.y, q.z, q.w};

@@ -111,10 +111,14 @@ __global__ __launch_bounds__(256) void k_snp_stats_2bit(const uint8_t* __restric
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const uint4* p = reinterpret_cast<const uint4*>(G2 + row * ld2);
-    const int64_t nvec = ld2 >> 4;
+    // KiB-aligned wave loads over the row's samples (the pitch is an odd multiple of 256 B: see k_snp_stats)
+    const uintptr_t rstart = reinterpret_cast<uintptr_t>(G2 + row * ld2);
+    const int64_t skip = (int64_t)((rstart & 1023u) >> 4);
+    const uint4* p = reinterpret_cast<const uint4*>(rstart & ~(uintptr_t)1023u);
+    const int64_t nvec = skip + ((N + 63) >> 6);        // 64 samples per 16-byte vector; fields between N and the pitch are 0
     int c1 = 0, c2 = 0, c3 = 0;
     for (int64_t v0 = lane; v0 < nvec; v0 += 64) {
+        if (v0 < skip) continue;
         const uint4 q = p[v0];
         const unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
