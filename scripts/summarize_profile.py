@@ -22,6 +22,20 @@ b = f"{out}/bench_{tag}.json"
 if os.path.exists(b) and os.path.getsize(b):
     d = json.loads(open(b).read().strip().splitlines()[-1])
     lines += ["## bench.py line", "```json", json.dumps(d, indent=1), "```", ""]
+# the bench line the PROFILED process printed: its HIP-event averages are the ones the rocprofv3 table below must agree with (two
+# processes on one box can differ by a few per cent in both GEMMs: where the 10 GB buffer lands, profiles/r1_kbench_summary.md 7)
+pl = f"{out}/prof_{tag}.log"
+if os.path.exists(pl):
+    cand = [ln[ln.index('{"metric'):] for ln in open(pl, errors="replace") if '{"metric' in ln]
+    if cand:
+        try:
+            dp = json.loads(cand[-1])
+            r = dp["roofline"]
+            lines += ["## the same command under `rocprofv3 --kernel-trace --stats` (the process the table below comes from): HIP-event figures",
+                      "", f"ms_per_step {dp['ms_per_step']:.3f}; dominant kernel `{r['kernel']}` avg launch {r['avg_launch_ms'] * 1e3:.1f} us "
+                      f"(HIP events on the engine's stream), frac {r['frac']:.3f}; per-step GEMM totals {json.dumps(r['all_kernels_ms_per_step'])}", ""]
+        except Exception:
+            pass
 ks = glob.glob(f"{out}/prof_{tag}/*/*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks[0])))
