@@ -120,7 +120,8 @@ typedef enum gpca_panel_kind {
                                 population (n / 16) % n_pop */
 } gpca_panel_kind;
 /* Write rows [row0, row0 + rows) of the matrix into dst (pinned host memory owned by the library).  Return 0, or
- * non-zero to abort the pass (reported as GPCA_ERR_BAD_ARG with the row range in the message). */
+ * non-zero to abort the pass (reported as GPCA_ERR_BAD_ARG with the row range in the message).  Called on the thread that runs
+ * the pass, with the handle's lock held: it may block on I/O, it must not wait for another thread that calls into the same handle. */
 typedef int (*gpca_panel_fn)(void* user, int64_t row0, int64_t rows, void* dst, int64_t ld);
 typedef struct gpca_panel_source {
     int32_t kind;           /* gpca_panel_kind */
@@ -199,7 +200,8 @@ GPCA_API int gpca_comm_get_unique_id(void* out_id /* GPCA_UNIQUE_ID_BYTES */);
  * Creates an RCCL communicator; the N x l sketch and l x l Gram blocks are all-reduced. */
 GPCA_API int gpca_comm_init(gpca_handle* h, int32_t world, int32_t rank, const void* unique_id, int64_t snp_offset);
 /* Host-staged all-reduce hook (sum, in place, f64) used instead of RCCL when set: lets any
- * transport (MPI, gloo) carry the exchange; also how the CPU tests exercise the N>1 path. */
+ * transport (MPI, gloo) carry the exchange; also how the CPU tests exercise the N>1 path.  Called with the handle's lock held
+ * (other handles -- the peers' -- are unaffected). */
 typedef int (*gpca_allreduce_fn)(void* user, double* host_buf, int64_t count);
 GPCA_API int gpca_set_allreduce_hook(gpca_handle* h, gpca_allreduce_fn fn, void* user, int32_t world,
                             int32_t rank, int64_t snp_offset);
