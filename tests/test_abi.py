@@ -103,3 +103,34 @@ def test_host_eigensolver_against_lapack(gpca):
             assert np.max(np.abs(V.T @ V - np.eye(n))) < 1e-12                         # orthonormal eigenvectors
             assert np.max(np.abs(A @ V - V * w)) < 1e-11 * scale                       # residual
     assert lib.gpca_host_eigh_desc(None, 3, None, None) == -1
+
+
+def _build_c_client(tmp_path):
+    exe = str(tmp_path / "c_abi_host")
+    pkg = os.path.join(ROOT, "genomic_pca_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_host.c"), "-L" + pkg, "-lgpca", "-Wl,-rpath," + pkg, "-lm", "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c99_and_links(tmp_path, gpca):
+    """include/gpca.h compiles as strict C99 (no C++ in the boundary) and a C program links against libgpca.so; without a GPU
+    it runs the host-only entry points and sees gpca_create fail loudly with GPCA_ERR_NO_DEVICE."""
+    gpca.load()
+    exe = _build_c_client(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_c_client_full_path")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "no CPU fallback" in out.stdout and "libgpca version 200" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_client_full_path(tmp_path, gpca):
+    """The same C program end to end on the GPU: upload -> QC -> randomized PCA, then the same matrix out of core through a host
+    panel callback written in C, bit-identical eigenvalues."""
+    exe = _build_c_client(tmp_path)
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ok" in out.stdout.splitlines()[-1] and "streamed :" in out.stdout
