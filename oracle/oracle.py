@@ -250,6 +250,26 @@ def exact_pca(G, N, r, b, k):
     return dict(scores=scores * sgn, eigenvalues=w / (N - 1), loadings=load * sgn, singular_values=s)
 
 
+def exact_pca_centred_only(G, N, keep, k):
+    """The reference's own "Exact PCA Reference" (tests/pca.py:81-141, the script its sweep analysis compares every run
+    against): per-variant CENTRING only (no sigma scaling), missing -> 0 after centring, GRM = sum X X^T / kept over the variants
+    that pass QC, eigh, PCs = evecs * sqrt(evals).  (pca.py reads with count_A1=False, i.e. 2 - g: centring makes that a sign
+    flip of every variant, which the GRM does not see.)  `keep` = the QC decisions (its filters are the Rust ones of
+    prepare.rs:1281-1363 up to the monomorphic guard, which the MAF filter subsumes)."""
+    X = np.asarray(G[:, :N], np.float64)[np.asarray(keep).astype(bool)]
+    miss = X == MISSING
+    X = np.where(miss, np.nan, X)
+    X = X - np.nanmean(X, axis=1, keepdims=True)
+    X = np.nan_to_num(X)
+    kept = X.shape[0]
+    gram = (X.T @ X) / kept
+    w, V = np.linalg.eigh(gram)
+    w = w[::-1][:k]; V = V[:, ::-1][:, :k]
+    pcs = V * np.sqrt(np.maximum(w, 0))
+    sgn = np.sign(pcs[np.abs(pcs).argmax(axis=0), np.arange(k)])
+    return dict(pcs=pcs * sgn, evals=w, kept=kept)
+
+
 def sign_align(X, ref):
     """Flip columns of X to maximise agreement with ref."""
     s = np.sign(np.sum(X * ref, axis=0)); s[s == 0] = 1

@@ -289,3 +289,33 @@ def test_vcf_fast_path_equals_per_sample_rules(tmp_path):
     _, ids2, G2 = gio.read_vcf(str(tmp_path / "big.vcf"), 0.0)
     dt = time.perf_counter() - t0
     assert G2.shape == (nv2, ns2) and dt < 5.0, dt          # 5M genotypes; the per-genotype loop needed ~10 s for this
+
+
+@pytest.mark.gpu
+def test_against_the_references_own_exact_pca_definition(gpca, oracle):
+    """The reference validates its runs against tests/pca.py ("Exact PCA Reference": centre only, GRM / kept, eigh,
+    PCs = evecs * sqrt(evals)).  The engine with caller-supplied standardisation (mu = per-SNP mean, sigma = 1) and enough
+    power iterations to converge on N = 64 samples reproduces that definition on the reference's own chr22_subset50 genotypes:
+    eigenvalues (rescaled (N-1)/kept) and the leading PCs."""
+    from genomic_pca_amd import _lib
+    z = np.load(os.path.join(GOLD, "chr22_subset50_120k.npz"))
+    rows = z["bed_rows"]; n = int(z["n_samples"])
+    lut = np.array([2, -127, 1, 0], np.int8)
+    G = np.empty((rows.shape[0], rows.shape[1] * 4), np.int8)
+    for s in range(4):
+        G[:, s::4] = lut[(rows >> (2 * s)) & 3]
+    G = G[:, :n]
+    k = 6
+    for store in (_lib.STORE_INT8, _lib.STORE_2BIT):
+        with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=store) as e:
+            e.upload_bed2bit(rows, n)
+            st = e.snp_stats(gpca.QcConfig())                       # the QC both the Rust path and pca.py apply
+            E = oracle.exact_pca_centred_only(G, n, st["keep"], k)
+            e.set_standardization(st["mu"], np.ones_like(st["sigma"]), st["keep"])      # centre only
+            e.rsvd(k, 20, 12, seed=1)                               # l = 26 of 63 dimensions, 12 power iterations: converged
+            ev = e.eigenvalues() * (n - 1) / E["kept"]              # s^2/(N-1)  ->  s^2/kept
+            pcs = e.scores(f64=True) / np.sqrt(E["kept"])           # V s        ->  V s / sqrt(kept)
+            assert np.max(np.abs(ev[:4] - E["evals"][:4]) / E["evals"][:4]) < 1e-6          # (the oracle's rsvd reaches 1e-10 here)
+            assert oracle.max_abs_dpc(pcs[:, :3], E["pcs"][:, :3]) < 1e-4                    # north_star's bar, against the EXACT answer
+            al = oracle.sign_align(pcs[:, :3], E["pcs"][:, :3])
+            assert np.max(np.abs(al - E["pcs"][:, :3])) < 1e-4 * np.max(np.abs(E["pcs"][:, :3]))

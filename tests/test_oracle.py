@@ -237,3 +237,25 @@ def test_golden_fixture(oracle):
     R = oracle.rsvd(G, N, r, b, int(z["k"]), 10, 2, seed=int(z["seed"]))
     assert np.allclose(R["eigenvalues"], z["eigenvalues"], rtol=1e-10)
     assert oracle.max_abs_dpc(R["scores"], z["scores"]) < 1e-9
+
+
+def test_checker_against_the_references_exact_pca_script(oracle):
+    """The reference's own validation target (tests/pca.py:81-141, "Exact PCA Reference": centre only, GRM / kept, eigh) on the
+    reference's own chr22_subset50 genotypes: the oracle's randomized PCA with mu = mean, sigma = 1 and 12 power iterations
+    converges to it (eigenvalues 1e-9, leading PCs 1e-5) -- the only place where a number defined by the reference's own files
+    pins this path's PCA output."""
+    z = np.load(os.path.join(GOLD, "chr22_subset50_120k.npz"))
+    rows = z["bed_rows"]; n = int(z["n_samples"])
+    lut = np.array([2, -127, 1, 0], np.int8)
+    G = np.empty((rows.shape[0], rows.shape[1] * 4), np.int8)
+    for s4 in range(4):
+        G[:, s4::4] = lut[(rows >> (2 * s4)) & 3]
+    G = G[:, :n]
+    st = oracle.snp_stats(G, n, 0.98, 0.01, 1e-6)
+    E = oracle.exact_pca_centred_only(G, n, st["keep"], 6)
+    assert E["kept"] == int(st["keep"].sum()) and not (G[st["keep"].astype(bool)] == -127).any()
+    r, b = oracle.scale_shift(st["mu"], np.ones_like(st["sigma"]), st["keep"])
+    R = oracle.rsvd(G, n, r, b, 6, 20, 12, seed=1)
+    ev = R["eigenvalues"] * (n - 1) / E["kept"]
+    assert np.max(np.abs(ev[:4] - E["evals"][:4]) / E["evals"][:4]) < 1e-8
+    assert oracle.max_abs_dpc(R["scores"][:, :3] / np.sqrt(E["kept"]), E["pcs"][:, :3]) < 1e-5
