@@ -319,3 +319,18 @@ def test_against_the_references_own_exact_pca_definition(gpca, oracle):
             assert oracle.max_abs_dpc(pcs[:, :3], E["pcs"][:, :3]) < 1e-4                    # north_star's bar, against the EXACT answer
             al = oracle.sign_align(pcs[:, :3], E["pcs"][:, :3])
             assert np.max(np.abs(al - E["pcs"][:, :3])) < 1e-4 * np.max(np.abs(E["pcs"][:, :3]))
+
+
+def test_cli_defaults_are_claps_effective_defaults():
+    """main.rs:545-588 (`default_value_if("eigensnp", "true", ...)`), the values the authors' own sweep driver treats as the
+    baseline (tests/sweep_run.py:31-45): the flag surface and its effective defaults."""
+    from genomic_pca_amd.cli import build_parser
+    a = build_parser().parse_args(["--eigensnp", "--bed-file", "x.bed", "--ld-block-file", "l.txt", "--out", "p"])
+    assert (a.eigensnp_min_call_rate, a.eigensnp_min_maf, a.eigensnp_max_hwe_p) == (0.98, 0.01, 1e-6)
+    assert (a.eigensnp_k_global, a.eigensnp_components_per_block, a.eigensnp_subset_factor) == (10, 7, 0.075)
+    assert (a.eigensnp_min_subset_size, a.eigensnp_max_subset_size) == (10000, 40000)
+    assert (a.eigensnp_global_oversampling, a.eigensnp_global_power_iter) == (10, 2)
+    assert (a.eigensnp_local_oversampling, a.eigensnp_local_power_iter) == (10, 2)
+    assert (a.eigensnp_seed, a.eigensnp_snp_strip_size, a.eigensnp_refine_passes) == (2025, 2000, 1)
+    v = build_parser().parse_args(["-d", "vcfs", "-k", "10", "--maf", "0.05", "--rfit-seed", "1", "-o", "p", "-t", "8"])   # BASELINE configs[0]
+    assert (v.vcf_dir, v.components, v.maf, v.rfit_seed, v.output_prefix, v.eigensnp) == ("vcfs", 10, 0.05, 1, "p", False)
