@@ -259,3 +259,26 @@ def test_checker_against_the_references_exact_pca_script(oracle):
     ev = R["eigenvalues"] * (n - 1) / E["kept"]
     assert np.max(np.abs(ev[:4] - E["evals"][:4]) / E["evals"][:4]) < 1e-8
     assert oracle.max_abs_dpc(R["scores"][:, :3] / np.sqrt(E["kept"]), E["pcs"][:, :3]) < 1e-5
+
+
+def test_hwe_against_the_references_python_definition(oracle, gpca):
+    """The reference holds a second, independent definition of the HWE test in its own validation script (tests/pca.py:54-66:
+    allele frequency, expected counts, chi-squared statistic, 1 - scipy chi2.cdf(., 1)).  Where both definitions are regular (all
+    three expected counts > 0) the Rust restatement (prepare.rs:1641-1745) and the library's host helper agree with it."""
+    from scipy.stats import chi2 as chi2_dist
+
+    def pca_py_hwe(a_aa, a_ab, a_bb):                       # restated from tests/pca.py:54-66
+        n = a_aa + a_ab + a_bb
+        p = (2 * a_aa + a_ab) / (2 * n)
+        q = 1.0 - p
+        exp = np.array([n * p * p, 2 * n * p * q, n * q * q])
+        obs = np.array([a_aa, a_ab, a_bb])
+        return 1.0 - chi2_dist.cdf(((obs - exp) ** 2 / exp).sum(), 1)
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n0, n1, n2 = (int(x) for x in rng.integers(1, 4000, 3))
+        ref = pca_py_hwe(n0, n1, n2)
+        assert abs(oracle.hwe_p(n0, n1, n2) - ref) <= 1e-12 + 1e-9 * ref
+        assert gpca.GpcaEngine.hwe_chi_squared_p_value(n0, n1, n2) == oracle.hwe_p(n0, n1, n2)
+    for n in ((25, 50, 25), (10, 50, 40), (640, 320, 40), (1, 2, 400)):
+        assert abs(oracle.hwe_p(*n) - pca_py_hwe(*n)) <= 1e-12
