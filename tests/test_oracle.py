@@ -282,3 +282,19 @@ def test_hwe_against_the_references_python_definition(oracle, gpca):
         assert gpca.GpcaEngine.hwe_chi_squared_p_value(n0, n1, n2) == oracle.hwe_p(n0, n1, n2)
     for n in ((25, 50, 25), (10, 50, 40), (640, 320, 40), (1, 2, 400)):
         assert abs(oracle.hwe_p(*n) - pca_py_hwe(*n)) <= 1e-12
+
+
+def test_bed_fixture_against_the_references_own_decoder():
+    """tests/disk.py:89-135 is the reference's own reading of the .bed bytes (2 bits per sample, LSB first, codes 00 -> 0,
+    10 -> 1, 11 -> 2, 01 -> missing: the count of the OTHER allele).  The count-A1 dosages committed with the chr22 slice (what
+    bed_reader's count_a1 read of prepare.rs:622-629 returns, and what the device decode is tested against) must be its mirror
+    image: 2 - g, missing <-> missing."""
+    z = np.load(os.path.join(GOLD, "chr22_subset50_slice.npz"))
+    rows = z["bed_rows"]; n = int(z["n_samples"]); a1 = z["dosage_count_a1"]
+    disk_py = np.array([0, 255, 1, 2], np.int16)            # indexed by the 2-bit code, as tests/disk.py maps it
+    other = np.empty((rows.shape[0], rows.shape[1] * 4), np.int16)
+    for s4 in range(4):
+        other[:, s4::4] = disk_py[(rows >> (2 * s4)) & 3]
+    other = other[:, :n]
+    assert np.array_equal(np.where(a1 == -127, 255, 2 - a1.astype(np.int16)), other)
+    assert (a1 == -127).sum() == (other == 255).sum() and set(np.unique(a1)) <= {-127, 0, 1, 2}
