@@ -334,3 +334,28 @@ def test_cli_defaults_are_claps_effective_defaults():
     assert (a.eigensnp_seed, a.eigensnp_snp_strip_size, a.eigensnp_refine_passes) == (2025, 2000, 1)
     v = build_parser().parse_args(["-d", "vcfs", "-k", "10", "--maf", "0.05", "--rfit-seed", "1", "-o", "p", "-t", "8"])   # BASELINE configs[0]
     assert (v.vcf_dir, v.components, v.maf, v.rfit_seed, v.output_prefix, v.eigensnp) == ("vcfs", 10, 0.05, 1, "p", False)
+
+
+def test_outputs_are_what_the_references_consumers_read(tmp_path):
+    """The reference's own downstream scripts define what the output files must look like: tests/metrics.py:227-234 reads the PCA
+    table with pandas (whitespace separated) and requires the columns SampleID, PC1..PCk; tests/plot.py:15-18,214-231 looks for
+    `<prefix>.eigenvalues.tsv` (columns PC, Eigenvalue), `.eigensnp.pca.tsv` and `.eigensnp.loadings.tsv` (columns Pos,
+    PC1_loading).  Written by the writers here, read back the way they read them."""
+    import pandas as pd
+    pre = str(tmp_path / "run")
+    rng = np.random.default_rng(0)
+    ids = [f"HG{i:05d}" for i in range(7)]
+    pcs = rng.standard_normal((7, 4)).astype(np.float32)
+    gio.write_principal_components(pre, "eigensnp.pca.tsv", ids, pcs)
+    gio.write_eigenvalues(pre, [3.5, 2.25, 1.0, 0.5])
+    gio.write_loadings(pre, [f"22:{p}" for p in (100, 200, 300)], ["22"] * 3, [100, 200, 300], rng.standard_normal((3, 4)).astype(np.float32))
+    pca_table = pd.read_csv(pre + ".eigensnp.pca.tsv", sep=r"\s+")                                   # metrics.py:227
+    assert list(pca_table.columns) == ["SampleID"] + [f"PC{i + 1}" for i in range(4)]                  # metrics.py:230
+    assert pca_table["SampleID"].astype(str).str.strip().tolist() == ids                               # plot.py:219
+    assert np.allclose(pca_table[[f"PC{i + 1}" for i in range(4)]].to_numpy(), pcs, atol=5e-7)          # '{:.6}' rounding
+    ev = pd.read_csv(pre + ".eigenvalues.tsv", sep="\t")
+    assert list(ev.columns) == ["PC", "Eigenvalue"] and len(ev) == 4                                   # plot.py:215-216
+    ld = pd.read_csv(pre + ".eigensnp.loadings.tsv", sep="\t")
+    assert {"Pos", "PC1_loading"} <= set(ld.columns) and ld["Pos"].tolist() == [100, 200, 300]          # plot.py:230
+    pc_cols = sorted([c for c in pca_table.columns if c.startswith("PC") and c[2:].isdigit()], key=lambda x: int(x[2:]))
+    assert int(pc_cols[-1][2:]) == 4                                                                    # plot.py:221-224
