@@ -138,8 +138,10 @@ GPCA_API int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* src,
 /* Out-of-core mode: the matrix is never resident.  Every pass of gpca_snp_stats / gpca_rsvd / gpca_transform walks
  * ceil(M / panel_rows) panels through a ring of `ring_slots` (>= 2) HBM panel buffers; panel p + 1 is generated or
  * copied on a second stream while panel p is multiplied.  panel_rows is rounded up to a multiple of 128; 0 picks
- * 131 072 rows (a full grid of the row-parallel GEMM) or as many as fit the ring in half of the free HBM.  Requires GPCA_PREC_I8_EXACT (either storage).  Results are bit-identical to the resident engine on the
- * same matrix.  The pull API (gpca_standardize_block) and gpca_download_genotypes_i8 need a resident matrix. */
+ * 131 072 rows (a full grid of the row-parallel GEMM) or as many as fit the ring in half of the free HBM (callback sources: at most
+ * 2 GiB of pinned host staging per panel).  Requires GPCA_PREC_I8_EXACT (either storage).  With gpca_stream_set_fused(h, 0) the
+ * results are bit-identical to the resident engine on the same matrix; the default (fused) form is described below.  The pull API
+ * (gpca_standardize_block) and gpca_download_genotypes_i8 need a resident matrix. */
 GPCA_API int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N, int64_t panel_rows,
                               int32_t ring_slots);
 /* fused = 1 (the default after gpca_stream_open): a power iteration reads every panel ONCE -- G Q, quantisation and G^T T per panel
