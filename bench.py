@@ -385,6 +385,15 @@ def main():
                                               "device generator (GPCA_PANEL_SYNTH16; a different synthetic draw than the resident matrix)",
                                       "value": M_local * N / (dts / min(a.steps, 3)), "unit": "SNPs*samples/s",
                                       "ms_per_step": dts / min(a.steps, 3) * 1e3, **streamed_summary(tims, min(a.steps, 3), M_local, N, l, a.storage)}
+        # bench lines of the other BASELINE.json configs, measured with this build by the scripts named in DESIGN.md (too large or too
+        # long for the default run; each file holds one line in this same format)
+        out["see_also"] = {k_: v_ for k_, v_ in {
+            "configs[2] chr22_subset50 shape, 1 066 557 x 64": "profiles/r2_config3_chr22_shape_1066557x64.json",
+            "configs[3] per-GPU shard, 1.25M x 100k int8": "profiles/r2_bench_c4shard_1.25Mx100k_int8.json",
+            "10M x 100k on ONE GPU, 2-bit rows, exact path": "profiles/r2_bench_10Mx100k_2bit_one_gpu.json",
+            "north_star literal: 10M x 100k on ONE GPU, MFMA-fp32 path": "profiles/r2_northstar_10Mx100k_f32_mfma_2bit_one_gpu.json",
+            "configs[4] per-GPU shard streamed out of core, 6.25M x 500k, k = 40": "profiles/r2_stream_config5_6.25Mx500k_k40_2bit.json",
+        }.items() if os.path.exists(os.path.join(ROOT, v_))}
         if world == 1 and not a.no_cpu_baseline:
             out["parity"] = parity_check(g, PREC[a.precision], a.rfit_seed)
             out["cpu_baseline"] = cpu_baseline(N, k, a.oversample, a.power_iters, a.rfit_seed)
