@@ -422,3 +422,39 @@ def test_compute_pca_honours_ld_blocks(gpca, oracle):
             gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, [gpca.LdBlockSpecification("x", [n_pca])])
         with pytest.raises(ValueError):
             gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, [])
+
+
+def test_config5_sample_count_k40(gpca, oracle):
+    """BASELINE.json configs[4]'s sample count and sketch width (N = 500 000, k = 40 -> l = 50, two column halves) on a matrix small
+    enough to hold: property checks, int8-resident == 2-bit-resident, streamed (6-pass) == resident bit for bit, fused within 2e-8,
+    and spot rows of the loadings re-derived in f64 from the oracle's bytes."""
+    M, N, k, seed = 16_384, 500_000, 40, 11
+    th = gpca.synth_thresholds(M, 3, seed=seed, fst=0.1)
+    out = {}
+    for store in ("int8", "2bit"):
+        with gpca.GpcaEngine(**_modes(store)) as e:
+            e.synth_genotypes(M, N, seed, th)
+            st = e.snp_stats()
+            e.rsvd(k, 10, 2, seed=seed)
+            sc = e.scores(f64=True); ev = e.eigenvalues(); sv = e.singular_values(); ld = e.loadings()
+            gram = sc.T @ sc
+            assert np.allclose(np.diag(gram), sv[:k] ** 2, rtol=1e-6)
+            assert np.max(np.abs(gram - np.diag(np.diag(gram)))) < 1e-6 * sv[0] ** 2
+            assert np.max(np.abs(sc.sum(axis=0))) < 1e-6 * np.abs(sc).sum(axis=0).max()
+            assert ev[1] > 5 * ev[2]                                   # 3 populations -> 2 structured PCs
+            V = sc[:, :2] / sv[:2]
+            for i in (0, 7777, M - 1):
+                g_row = oracle.synth_genotypes(1, N, seed, th[i:i + 1], snp_offset=int(i)).astype(np.float64)[0]
+                a_i = (g_row - float(st["mu"][i])) / float(st["sigma"][i])
+                assert np.max(np.abs(a_i @ V / sv[:2] - ld[i, :2].astype(np.float64))) < 1e-5
+            out[store] = (ev, sc, ld)
+    assert np.max(np.abs(out["int8"][0] - out["2bit"][0]) / out["int8"][0]) < 1e-8
+    assert oracle.max_abs_dpc(out["int8"][1][:, :2], out["2bit"][1][:, :2]) < 1e-8
+    with gpca.GpcaEngine(**_modes("2bit")) as e:
+        e.stream_open(gpca.PanelSource.synth(th, seed), M, N, panel_rows=4096, ring_slots=2, fused=False)
+        e.snp_stats(); e.rsvd(k, 10, 2, seed=seed)
+        assert np.array_equal(e.eigenvalues(), out["2bit"][0]) and np.array_equal(e.scores(f64=True), out["2bit"][1])
+        e.stream_open(gpca.PanelSource.synth(th, seed), M, N, panel_rows=4096, ring_slots=2)        # fused
+        e.snp_stats(); e.rsvd(k, 10, 2, seed=seed)
+        assert np.max(np.abs(e.eigenvalues() - out["2bit"][0]) / out["2bit"][0]) < 2e-8
+        assert oracle.max_abs_dpc(e.scores(f64=True)[:, :2], out["2bit"][1][:, :2]) < 2e-7
