@@ -67,7 +67,12 @@ def parity_check(g, precision, seed):
         e.rsvd(k, 10, 2, seed=seed)
         r, b = O.scale_shift(st["mu"], st["sigma"], st["keep"])
         R = O.rsvd(G, N, r, b, k, 10, 2, seed=seed)     # the checker: LAPACK QR / SVD, no small-dense code shared with the product
+        E = O.exact_pca(G, N, r, b, k)                  # BASELINE.md's parity metric: exact f64 PCA (eigh of the Gram); q = 2 convergence-limited
         return {"case": f"{M}x{N} k={k} vs oracle f64 (same sketch; Householder QR + LAPACK SVD)",
+                "vs_exact_pca_eigh": {"max_abs_dPC_scores_top3": O.max_abs_dpc(e.scores(f64=True)[:, :3], E["scores"][:, :3]),
+                                      "max_rel_d_eigenvalue_top3": float(np.max(np.abs(e.eigenvalues()[:3] - E["eigenvalues"][:3]) / E["eigenvalues"][:3])),
+                                      "note": "exact PCA of the standardised matrix; the gap is the convergence of q = 2 power iterations, "
+                                              "the same for the oracle's randomized PCA"},
                 "max_abs_dPC_scores": O.max_abs_dpc(e.scores(f64=True), R["scores"]),
                 "max_abs_dPC_loadings": O.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"]),
                 "max_rel_d_eigenvalue": float(np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"])),
