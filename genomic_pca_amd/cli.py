@@ -60,6 +60,10 @@ def build_parser() -> argparse.ArgumentParser:
     # engine selection (extensions; the defaults are the path bench.py's headline times)
     p.add_argument("--gpca-precision", default="i8", choices=["i8", "f32"], help="i8 = exact-integer GEMMs (default); f32 = f32 matrix cores")
     p.add_argument("--gpca-storage", default="int8", choices=["int8", "2bit"], help="HBM residency of the genotypes (2bit needs --gpca-precision i8)")
+    p.add_argument("--gpca-stream", default="auto", choices=["auto", "on", "off"],
+                   help="EigenSNP workflow: walk the .bed out of core through a ring of HBM panels instead of holding it resident "
+                        "(auto = when the resident load runs out of device memory; needs --gpca-precision i8)")
+    p.add_argument("--gpca-panel-rows", type=int, default=0, help="--gpca-stream: SNP rows per panel (0 = engine default)")
     return p
 
 
@@ -111,6 +115,35 @@ def run_vcf_workflow(a) -> int:
     return 0
 
 
+def _load_bed(eng, a, fs, cols):
+    """The .bed payload into the engine: resident (decoded on the GPU from 256 MiB row chunks of the memory map), or -- when
+    it does not fit the device, or on request -- out of core: every pass walks the memory map panel by panel through a ring
+    of HBM buffers, and the HBM that is left keeps the leading panels (gpca_stream_set_cache).  The reference's solver pulls
+    strips through the accessor on every pass in the same way (prepare.rs:1839-2022, main.rs:322)."""
+    from . import _lib
+    from .engine import PanelSource
+    rows = fs.bed_rows
+    lut = np.array([2, -127, 1, 0], np.int8)                                         # count_a1 (prepare.rs:622-629)
+    shift = None if cols is None else (2 * (cols % 4)).astype(np.uint8)
+
+    def subset(r0, n):                                                               # kept sample columns of rows [r0, r0 + n)
+        return lut[(np.asarray(rows[r0:r0 + n])[:, cols // 4] >> shift) & 3]
+    n_samples = fs.n_samples if cols is None else len(cols)
+    if a.gpca_stream != "on":
+        try:
+            if cols is None:
+                eng.upload_bed2bit(rows, fs.n_samples)
+            else:
+                eng.load_from_source(PanelSource.host_i8(subset), rows.shape[0], n_samples)
+            return
+        except _lib.GpcaError as e:
+            if a.gpca_stream == "off" or e.status != _lib.GPCA_ERR_OOM:
+                raise
+            _log("the genotype matrix does not fit the device: walking it out of core")
+    src = PanelSource.host_bed(lambda r0, n: rows[r0:r0 + n]) if cols is None else PanelSource.host_i8(subset)
+    eng.stream_open(src, rows.shape[0], n_samples, panel_rows=a.gpca_panel_rows, cache_bytes=-1)
+
+
 def run_eigensnp_workflow(a) -> int:
     if not a.bed_file or not a.ld_block_file:
         raise SystemExit("error: --bed-file and --ld-block-file are required when --eigensnp is used")   # main.rs:296-301
@@ -119,18 +152,14 @@ def run_eigensnp_workflow(a) -> int:
     prec, store = _engine_modes(a)
     eng = GpcaEngine(device=a.device, precision=prec, storage=store)
     sample_ids = fs.sample_ids
+    cols = None
     if a.eigensnp_sample_keep_file:                                                  # prepare.rs:1058-1096
         keep_ids = set(gio.read_sample_keep_file(a.eigensnp_sample_keep_file))
         cols = np.array([i for i, s in enumerate(fs.sample_ids) if s in keep_ids], np.int64)
         if len(cols) == 0:
             _log("No samples available after sample QC."); return 0
-        lut = np.array([2, -127, 1, 0], np.int8)
-        rows = np.asarray(fs.bed_rows)
-        G = lut[(rows[:, cols // 4] >> (2 * (cols % 4)).astype(np.uint8)) & 3]
-        eng.upload_genotypes_i8(np.ascontiguousarray(G))
         sample_ids = [fs.sample_ids[i] for i in cols]
-    else:
-        eng.upload_bed2bit(fs.bed_rows, fs.n_samples)    # the memory-mapped payload goes up in 256 MiB row chunks, decoded on the GPU
+    _load_bed(eng, a, fs, cols)
     st = eng.snp_stats(QcConfig(a.eigensnp_min_call_rate, a.eigensnp_min_maf, a.eigensnp_max_hwe_p))
     blocks = gio.parse_ld_block_file(a.ld_block_file)
     keep, by_tag = gio.map_snps_to_ld_blocks(blocks, fs.chromosomes, fs.positions, st["keep"])

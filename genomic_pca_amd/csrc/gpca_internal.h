@@ -91,6 +91,11 @@ struct StreamState {
     hipStream_t st_fill = nullptr;
     int64_t seq = 0;                 // panels filled so far: slot = seq % ring
     int fused = 1;                   // power iterations read every panel once (K1 -> quantise -> K2 per panel): 4 passes per call, not 6
+    // panel cache (gpca_stream_set_cache): the leading panels keep a buffer of their own in the HBM the ring and the workspace
+    // leave free; they are asked of the source once and read in place on every later pass
+    std::vector<void*> cache;
+    std::vector<hipEvent_t> ev_cache;
+    std::vector<char> cache_filled;
 };
 
 struct gpca_handle {
@@ -243,6 +248,22 @@ inline int for_each_panel(gpca_handle* h, F&& fn) {
         const int64_t row0 = (int64_t)p * sm.panel_rows;
         const int64_t rows = std::min(sm.panel_rows, h->M - row0);
         const int64_t rows_pad = round_up(rows, kGQRowsPerWave);
+        if (p < (int)sm.cache.size()) {                      // cached panel: filled on first use, never again
+            void* buf = sm.cache[p];
+            if (!sm.cache_filled[p]) {
+                {
+                    ScopedTimer t(h, "panel_fill", 0.0, (double)rows * (double)h->N, sm.st_fill);
+                    if (rows_pad > rows) HIPCHK(hipMemsetAsync((char*)buf + (size_t)rows * row_bytes, 0, (size_t)(rows_pad - rows) * row_bytes, sm.st_fill));
+                    CHK(filler_fill(h, sm.fl, row0, rows, buf, sm.st_fill));
+                }
+                HIPCHK(hipEventRecord(sm.ev_cache[p], sm.st_fill));
+                HIPCHK(hipStreamWaitEvent(h->st, sm.ev_cache[p], 0));
+                sm.cache_filled[p] = 1;
+            }
+            const PanelView pv{packed ? nullptr : (const int8_t*)buf, packed ? (const uint8_t*)buf : nullptr, row0, rows, rows_pad, p};
+            CHK(fn(pv));
+            continue;
+        }
         const int s = (int)(sm.seq % sm.ring); sm.seq++;
         if (sm.free_pending[s]) HIPCHK(hipStreamWaitEvent(sm.st_fill, sm.ev_free[s], 0));   // the slot's last reader has finished
         {

@@ -36,6 +36,9 @@ void stream_close(gpca_handle* h) {
     for (auto e : sm.ev_filled) (void)hipEventDestroy(e);
     for (auto e : sm.ev_free) (void)hipEventDestroy(e);
     sm.slot.clear(); sm.ev_filled.clear(); sm.ev_free.clear(); sm.free_pending.clear();
+    for (void* p : sm.cache) if (p) (void)hipFree(p);
+    for (auto e : sm.ev_cache) (void)hipEventDestroy(e);
+    sm.cache.clear(); sm.ev_cache.clear(); sm.cache_filled.clear();
     if (sm.st_fill) { (void)hipStreamDestroy(sm.st_fill); sm.st_fill = nullptr; }
     sm.on = false; sm.seq = 0; sm.n_panels = 0;
 }
@@ -258,6 +261,7 @@ extern "C" int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* sr
     return rc;
 }
 
+static double workspace_estimate(const gpca_handle* h);
 extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N, int64_t panel_rows,
                                 int32_t ring_slots) {
     if (!h) return GPCA_ERR_BAD_ARG;
@@ -275,8 +279,7 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
         // of the CUs idle).  Take that many rows when the ring fits in half of the free HBM after the M- and N-sized workspace.
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const double workspace = (double)h->Mpad * (64 * 4 + 2 * 32 * kDigits + 48) + (double)h->ldg * (64 * 8 * 3 + 2 * 32 * kDigits + 32 * 8 * 4);
-        const double budget = 0.5 * ((double)free_b - workspace);
+        const double budget = 0.5 * ((double)free_b - workspace_estimate(h));
         int64_t rows = (int64_t)h->gq_waves_target * kGQRowsPerWave;
         const int64_t fit = (int64_t)(budget / ((double)ring_slots * (double)row_bytes));
         if (rows > fit) rows = fit;
@@ -320,6 +323,52 @@ extern "C" int gpca_stream_set_fused(gpca_handle* h, int32_t fused) {
     if (!h->sm.on) return fail(h, GPCA_ERR_STATE, "gpca_stream_set_fused: no panel stream open");
     h->sm.fused = fused != 0;
     return GPCA_OK;
+}
+
+// M- and N-sized device memory gpca_snp_stats / gpca_rsvd will ask for at up to 64 sketch columns.  An upper estimate: per SNP
+// row T (256 B), its digit planes (256 B), the loadings (<= 256 B), mu/sigma/r/b/keep/reason/counts (48 B); per sample Q, Y,
+// the digit planes and the K2 partial sums of up to 16 column slices.
+static double workspace_estimate(const gpca_handle* h) {
+    return (double)h->Mpad * 1024.0 + (double)h->ldg * 8192.0 + 1073741824.0;
+}
+
+extern "C" int gpca_stream_set_cache(gpca_handle* h, int64_t max_bytes, int32_t* n_cached) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    StreamState& sm = h->sm;
+    if (!sm.on) return fail(h, GPCA_ERR_STATE, "gpca_stream_set_cache: no panel stream open");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(sm.st_fill));
+    HIPCHK(hipStreamSynchronize(h->st));
+    const size_t panel_bytes = (size_t)sm.panel_rows * (size_t)(h->storage == GPCA_STORE_2BIT ? h->ld2 : h->ld8);
+    if (max_bytes < 0) {   // what is free now, less the workspace the solver has not allocated yet and a 4 GiB margin
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const double left = (double)free_b + (double)sm.cache.size() * (double)panel_bytes - workspace_estimate(h) - 4.0 * 1073741824.0;
+        max_bytes = left > 0 ? (int64_t)left : 0;
+    }
+    size_t want = (size_t)max_bytes / panel_bytes;
+    if (want > (size_t)sm.n_panels) want = (size_t)sm.n_panels;
+    while (sm.cache.size() > want) {
+        (void)hipFree(sm.cache.back()); (void)hipEventDestroy(sm.ev_cache.back());
+        sm.cache.pop_back(); sm.ev_cache.pop_back(); sm.cache_filled.pop_back();
+    }
+    int rc = GPCA_OK;
+    while (sm.cache.size() < want) {
+        void* p = nullptr; hipEvent_t e = nullptr;
+        hipError_t err = hipMalloc(&p, panel_bytes);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            if (p) (void)hipFree(p);
+            (void)hipGetLastError();
+            rc = fail(h, err == hipErrorOutOfMemory ? GPCA_ERR_OOM : GPCA_ERR_HIP, std::string("gpca_stream_set_cache: ") + hipGetErrorString(err)
+                      + " after " + std::to_string(sm.cache.size()) + " panels (they stay cached)");
+            break;
+        }
+        sm.cache.push_back(p); sm.ev_cache.push_back(e); sm.cache_filled.push_back(0);
+    }
+    if (n_cached) *n_cached = (int32_t)sm.cache.size();
+    return rc;
 }
 
 extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t ld) {

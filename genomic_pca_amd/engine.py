@@ -178,16 +178,26 @@ class GpcaEngine:
             raise src.error
         self._chk(rc)
 
-    def stream_open(self, src: "PanelSource", M: int, N: int, panel_rows: int = 0, ring_slots: int = 3, fused: bool = True):
+    def stream_open(self, src: "PanelSource", M: int, N: int, panel_rows: int = 0, ring_slots: int = 3, fused: bool = True,
+                    cache_bytes: int = 0):
         """Out-of-core mode: later snp_stats / rsvd / transform calls walk the matrix panel by panel through a ring of
         HBM buffers (the source object must outlive them; it is kept referenced here).  fused = True: a power iteration
-        reads every panel once (4 passes per rsvd at q = 2); False: 6 passes, bit-identical to the resident engine."""
+        reads every panel once (4 passes per rsvd at q = 2); False: 6 passes, bit-identical to the resident engine.
+        cache_bytes: HBM for the panel cache (stream_set_cache; -1 = what is free, 0 = none)."""
         cs = src.c_struct()
         if src.thresh is not None and src.thresh.shape[0] != M:
             raise ValueError("thresh must be uint32 [M, P]")
         self._source_ref = (src, cs)
         self._chk(self._lib.gpca_stream_open(self._h, C.byref(cs), M, N, panel_rows, ring_slots))
         self._chk(self._lib.gpca_stream_set_fused(self._h, int(fused)))
+        if cache_bytes:
+            self.stream_set_cache(cache_bytes)
+
+    def stream_set_cache(self, max_bytes: int = -1) -> int:
+        """Keep the leading panels in spare HBM (asked of the source once, read in place afterwards); returns how many."""
+        n = C.c_int32()
+        self._chk(self._lib.gpca_stream_set_cache(self._h, int(max_bytes), C.byref(n)))
+        return n.value
 
     def download_genotypes_i8(self) -> np.ndarray:
         M, N = self.dims()

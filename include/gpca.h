@@ -150,6 +150,13 @@ GPCA_API int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int6
  * maxima: results differ from the resident engine at the 1e-9 level of the 28-bit fixed point (as a row-sharded run does).
  * fused = 0: the 6-pass form, bit-identical to the resident engine. */
 GPCA_API int gpca_stream_set_fused(gpca_handle* h, int32_t fused);
+/* Panel cache: HBM the ring and the solver's workspace leave free holds the LEADING panels for good -- each is asked of the
+ * source once (normally during gpca_snp_stats) and read in place on every later pass, so a matrix 3x the HBM costs 2/3 of the
+ * source traffic per pass, and one that fits is read once.  max_bytes: upper bound for the cache (whole panels are taken);
+ * < 0 = all free device memory less the solver's workspace estimate and a 4 GiB margin; 0 drops the cache.  The source must
+ * return the same rows every time it is asked (it must anyway: every pass re-reads it).  Results do not change.
+ * *n_cached (may be NULL) receives the number of cached panels.  GPCA_ERR_OOM keeps the panels allocated so far. */
+GPCA_API int gpca_stream_set_cache(gpca_handle* h, int64_t max_bytes, int32_t* n_cached);
 GPCA_API int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N);
 
 /* ---- a1/a3: SNP QC + standardisation parameters (prepare.rs:1100-1422, 1641-1745) -------- */

@@ -231,6 +231,57 @@ def test_streamed_fused_power_iteration(gpca, oracle, store, planes, k):
     assert oracle.max_abs_dpc(stm["sc"][:, :kk], R["scores"][:, :kk]) < 1e-4
 
 
+@pytest.mark.parametrize("store,fused", [("int8", False), ("2bit", False), ("2bit", True)])
+def test_panel_cache_reads_the_source_once(gpca, store, fused):
+    """gpca_stream_set_cache: the leading panels keep an HBM buffer of their own -- the source is asked for them once (during
+    snp_stats) and never again; results are the same bits as without the cache (and, unfused, as the resident engine).  A cache
+    that covers every panel turns the stream into a resident matrix loaded through the ring's code path."""
+    M, N, k, seed, pr = 20_000, 1000, 6, 1, 4096
+    th = gpca.synth_thresholds(M, 4, seed=seed, fst=0.2)
+    fills = []
+
+    def rows_i8(row0, rows):
+        fills.append(row0)
+        return G[row0:row0 + rows]
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.synth_genotypes(M, N, seed, th)
+        G = e.download_genotypes_i8()
+        res = _run(e, k, seed)
+    npanels = -(-M // pr)
+    passes = 1 + (4 if fused else 6) + 1                     # stats, rsvd, transform
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.stream_open(gpca.PanelSource.host_i8(rows_i8), M, N, panel_rows=pr, ring_slots=2, fused=fused)
+        plain = _run(e, k, seed)
+        assert len(fills) == npanels * passes
+    panel_bytes = pr * (1280 if store == "int8" else 256)   # row pitches of alloc_genotypes at N = 1000: 1024 + 256 B / 1024 / 4 B
+    for want in (2, npanels):
+        del fills[:]
+        with gpca.GpcaEngine(**_modes(store)) as e:
+            e.stream_open(gpca.PanelSource.host_i8(rows_i8), M, N, panel_rows=pr, ring_slots=2, fused=fused)
+            got = e.stream_set_cache(want * panel_bytes + 100)
+            assert got == want
+            cached = _run(e, k, seed)
+            assert len(fills) == want + (npanels - want) * passes
+            assert sorted(set(fills[:npanels])) == [p * pr for p in range(npanels)]
+            _same(plain, cached)
+            if want == npanels:
+                assert e.stream_set_cache(-1) == npanels         # "what is free": every panel fits on this card
+                n0 = len(fills)
+                again = _run(e, k, seed)
+                assert len(fills) == n0                          # nothing asked of the source any more
+                _same(cached, again)
+                assert e.stream_set_cache(1 * panel_bytes) == 1  # shrink: the dropped panels stream again
+                less = _run(e, k, seed)
+                assert len(fills) == n0 + (npanels - 1) * passes
+                _same(cached, less)
+                assert e.stream_set_cache(0) == 0
+    if not fused:
+        _same(res, plain)
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        with pytest.raises(gpca.GpcaError):
+            e.stream_set_cache(-1)                               # no stream open
+
+
 def test_stream_open_argument_errors(gpca):
     from genomic_pca_amd import _lib
     th = gpca.synth_thresholds(256, 3, seed=1)

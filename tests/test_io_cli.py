@@ -224,6 +224,38 @@ def test_cli_config3_chr22_subset50(tmp_path, gpca, oracle, storage):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("keep_file", [False, True])
+def test_cli_out_of_core_equals_resident(tmp_path, gpca, keep_file):
+    """--gpca-stream on: the CLI walks the memory-mapped .bed panel by panel (8 panels here, the HBM cache on) instead of
+    holding it resident -- the mode a .bed larger than the device gets by itself -- and writes the same three files as the
+    resident run (scores / loadings within the 6-decimal TSV rounding; the streamed power iterations quantise per panel).
+    With a sample keep file the panels are the kept columns, decoded on the host."""
+    from genomic_pca_amd.cli import main
+    pre, z, G, pos = _chr22_fileset(tmp_path)
+    ld = tmp_path / "ld.txt"
+    ld.write_text("22 1 500000000\n")
+    extra = []
+    if keep_file:
+        kf = tmp_path / "keep.txt"
+        kf.write_text("".join(f"{i}\n" for i in list(z["iids"])[::2] + ["not_in_the_fam"]))
+        extra = ["--eigensnp-sample-keep-file", str(kf)]
+    outs = {}
+    for mode in ("off", "on"):
+        out = str(tmp_path / "res" / mode)
+        assert main(["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--eigensnp-k-global", "8", "--out", out,
+                     "--gpca-stream", mode, "--gpca-panel-rows", "16384"] + extra) == 0
+        outs[mode] = [_read_tsv(out + sfx) for sfx in (".eigensnp.pca.tsv", ".eigenvalues.tsv", ".eigensnp.loadings.tsv")]
+    (h0, sc0), (_, ev0), (_, ld0) = outs["off"]
+    (h1, sc1), (_, ev1), (_, ld1) = outs["on"]
+    assert h0 == h1 and [r[0] for r in sc0] == [r[0] for r in sc1] and [r[:3] for r in ld0] == [r[:3] for r in ld1]
+    assert len(sc0) == (32 if keep_file else 64)
+    num = lambda rows, c: np.array([[float(x) for x in r[c:]] for r in rows])
+    assert np.allclose(num(ev0, 1), num(ev1, 1), rtol=1e-6)
+    assert np.max(np.abs(num(sc0, 1) - num(sc1, 1))) < 5e-6 * max(1.0, np.max(np.abs(num(sc0, 1))))
+    assert np.max(np.abs(num(ld0, 3) - num(ld1, 3))) < 5e-6
+
+
+@pytest.mark.gpu
 def test_engine_config3_full_precision(gpca, oracle):
     """The same data through the C ABI without the TSV rounding: unit-norm sign-aligned PCs within 1e-4 of the oracle on all
     three GEMM paths (N = 64 is padded to 256 / 1024 samples by the kernels' tiles)."""
