@@ -317,33 +317,59 @@ void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, i
 }
 
 // Y[n][j] = c[j] + tscale[j] * sum_w Ypart[w][n][j]    (the integer sum is exact and order-independent)
+// SPLIT = 8: the W slices are shared between 8 thread groups of a block (32 consecutive elements each) and folded through LDS --
+// for few samples the one-thread-per-element form leaves a handful of blocks walking W (thousands of) slices one load at a
+// time: 224 us per launch at 1 066 557 x 64 (configs[2]), 30 % of that call.  Same bits either way: the partial sums are integers.
+template <int SPLIT>
+__device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart, int W, int64_t stride, int64_t total, int64_t& e, bool& live) {
+    if (SPLIT == 1) {
+        e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        live = e < total;
+        double s = 0.0;
+        if (live) for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
+        return s;
+    }
+    __shared__ double part[256];
+    const int grp = threadIdx.x >> 5, le = threadIdx.x & 31;
+    e = (int64_t)blockIdx.x * 32 + le;
+    live = e < total;
+    double s = 0.0;
+    if (live) for (int w = grp; w < W; w += 8) s += Ypart[w * stride + e];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (grp != 0) { live = false; return 0.0; }
+#pragma unroll
+    for (int g = 1; g < 8; ++g) s += part[g * 32 + le];
+    return s;
+}
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
                                                      const double* __restrict__ cvec, const double* __restrict__ tscale,
                                                      double* __restrict__ Y, int64_t ldy) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * 32) return;
+    int64_t e; bool live;
+    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
+    if (!live) return;
     const int j = (int)(e & 31);
-    const int64_t stride = Npad * 32;
-    double s = 0.0;
-    for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
     Y[(e >> 5) * ldy + j] = fma(tscale[j], s, cvec[j]);   // one rounding, the same in k_finish_y_i8
 }
+// one thread per element while that still fills the chip (>= 1024 blocks), 8 threads per element below
+static inline bool reduce_split(int64_t total) { return total < (int64_t)256 * 1024; }
 void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
                         const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
-    hipLaunchKernelGGL(k_reduce_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_reduce_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
+    else hipLaunchKernelGGL(k_reduce_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
 }
 
 // Streamed panels: the integer partial sums of every panel are added into Yint (exact in f64 while |sum| < 2^53, so the
 // order of the panels does not matter) and scaled once at the end -- the same value, bit for bit, as the one-launch reduce.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_accum_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
                                                     double* __restrict__ Yint, int first) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * 32) return;
-    const int64_t stride = Npad * 32;
-    double s = first ? 0.0 : Yint[e];
-    for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
-    Yint[e] = s;
+    int64_t e; bool live;
+    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
+    if (!live) return;
+    Yint[e] = first ? s : Yint[e] + s;
 }
 __global__ __launch_bounds__(256) void k_finish_y_i8(const double* __restrict__ Yint, int64_t N, const double* __restrict__ cvec,
                                                      const double* __restrict__ tscale, double* __restrict__ Y, int64_t ldy) {
@@ -354,7 +380,8 @@ __global__ __launch_bounds__(256) void k_finish_y_i8(const double* __restrict__ 
 }
 void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first) {
     const int64_t total = N * 32;
-    hipLaunchKernelGGL(k_accum_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
+    else hipLaunchKernelGGL(k_accum_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
 }
 void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
@@ -362,13 +389,12 @@ void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const dou
 }
 // Fused streamed power iteration: every panel quantises its rows of T' against its OWN column maximum, so its integer sums carry
 // their own scale: Yacc[n][j] (+)= tscale_p[j] * sum_w Ypart[w][n][j]  (exact integer sum, one fma per panel, fixed panel order).
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_accum_y_scaled(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
                                                         const double* __restrict__ tscale, double* __restrict__ Yacc, int first) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * 32) return;
-    const int64_t stride = Npad * 32;
-    double s = 0.0;
-    for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
+    int64_t e; bool live;
+    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
+    if (!live) return;
     Yacc[e] = fma(tscale[e & 31], s, first ? 0.0 : Yacc[e]);
 }
 __global__ __launch_bounds__(256) void k_finish_y_sum(const double* __restrict__ Yacc, int64_t N, const double* __restrict__ cvec,
@@ -379,7 +405,8 @@ __global__ __launch_bounds__(256) void k_finish_y_sum(const double* __restrict__
 }
 void launch_accum_y_scaled(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first) {
     const int64_t total = N * 32;
-    hipLaunchKernelGGL(k_accum_y_scaled, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_scaled<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
+    else hipLaunchKernelGGL(k_accum_y_scaled<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
 }
 void launch_finish_y_sum(hipStream_t st, const double* Yacc, int64_t N, const double* c, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
