@@ -302,8 +302,9 @@ def test_stream_open_argument_errors(gpca):
 # ------------------------------------------------------------------------------------------------
 # row-sharded runs fail together
 # ------------------------------------------------------------------------------------------------
-def _two_shard_run(gpca, G, poison, k=4):
-    """Two engines on one GPU, each a row shard, exchanging through a host hook (threads)."""
+def _two_shard_run(gpca, G, poison, k=4, streamed=None, store="int8"):
+    """Two engines on one GPU, each a row shard, exchanging through a host hook (threads).  streamed = (panel_rows, fused,
+    cache_bytes per rank): the shards walk their rows out of core instead of holding them."""
     M, N = G.shape
     world = 2
     spans = [gpca.shard_rows(M, world, r) for r in range(world)]
@@ -311,12 +312,17 @@ def _two_shard_run(gpca, G, poison, k=4):
 
     def run(rank):
         a, b_ = spans[rank]
-        e = gpca.GpcaEngine(**_modes("int8"))
+        e = gpca.GpcaEngine(**_modes(store))
         try:
             shard = G[a:b_].copy()
             if poison is not None and poison[0] == rank:
                 shard[poison[1], poison[2]] = poison[3]
-            e.upload_genotypes_i8(shard); e.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0))
+            if streamed is None:
+                e.upload_genotypes_i8(shard)
+            else:
+                e.stream_open(gpca.PanelSource.host_i8(lambda r0, r: shard[r0:r0 + r]), b_ - a, N, panel_rows=streamed[0], ring_slots=2,
+                              fused=streamed[1], cache_bytes=streamed[2][rank])
+            e.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0))
 
             def hook(buf):
                 bufs[rank] = buf.copy(); barrier.wait()
@@ -324,7 +330,7 @@ def _two_shard_run(gpca, G, poison, k=4):
             e.set_allreduce_hook(hook, world, rank, a)
             try:
                 e.rsvd(k, 10, 2, seed=5)
-                out[rank] = ("ok", e.eigenvalues())
+                out[rank] = ("ok", e.eigenvalues(), e.scores(f64=True), e.loadings())
             except gpca.GpcaError as err:
                 out[rank] = ("err", err.status, err.message)
         finally:
@@ -349,6 +355,33 @@ def test_sharded_ranks_fail_together(gpca, oracle):
     # an invalid dosage on shard 0: -9 everywhere
     out = _two_shard_run(gpca, G, (0, 3, 9, 7))
     assert [o[1] for o in out] == [-9, -9]
+
+
+@pytest.mark.parametrize("store,fused", [("int8", False), ("2bit", True)])
+def test_sharded_and_streamed(gpca, oracle, store, fused):
+    """BASELINE.json configs[4] is both at once: row shards (one per GPU) that each walk their rows out of core.  Two shards
+    with different panel counts (rank 1 also caches one panel): the ranks hold the same replicated results, the streamed
+    unfused shards give the resident shards' bits, and everything sits within the sharded tolerance of the unsharded engine;
+    a poisoned panel on one rank fails both."""
+    M, N, k = 9000, 384, 6
+    G = oracle.synth_genotypes(M, N, 37, gpca.synth_thresholds(M, 8, seed=37, fst=0.3))
+    res = _two_shard_run(gpca, G, None, k=k, store=store)
+    stm = _two_shard_run(gpca, G, None, k=k, store=store, streamed=(1024, fused, (0, 1024 * 1024)))
+    for o in (res, stm):
+        assert o[0][0] == "ok" and o[1][0] == "ok"
+        assert np.array_equal(o[0][1], o[1][1]) and np.array_equal(o[0][2], o[1][2])     # replicated eigenvalues / scores
+    if not fused:
+        for r in range(2):
+            for i in (1, 2, 3):
+                assert np.array_equal(res[r][i], stm[r][i])
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0)); e.rsvd(k, 10, 2, seed=5)
+        assert np.max(np.abs(stm[0][1] - e.eigenvalues()) / e.eigenvalues()) < 1e-7
+        assert oracle.max_abs_dpc(stm[0][2], e.scores(f64=True)) < 1e-7
+        ld = np.concatenate([stm[0][3], stm[1][3]], axis=0).astype(np.float64)
+        assert oracle.max_abs_dpc(ld, e.loadings().astype(np.float64)) < 1e-6
+    bad = _two_shard_run(gpca, G, (1, 3000, 5, -127), k=k, store=store, streamed=(1024, fused, (0, 0)))     # third panel of rank 1
+    assert [o[0] for o in bad] == ["err", "err"] and [o[1] for o in bad] == [-5, -5]
 
 
 def _proc_worker(rank, world, port, M, N, k, seed, out_dir, poison_rank):
