@@ -174,7 +174,9 @@ struct gpca_handle {
     std::vector<gpca_kernel_timing> agg;
 };
 constexpr size_t kMaxTimingRecs = 32768;
-#define LOCK(h) std::lock_guard<std::recursive_mutex> lock_guard_(h->mu)
+// every entry point: take the handle's lock and make its device the calling thread's current one (a host thread that drives
+// several handles on different GPUs, or that last touched another device, would otherwise launch on the wrong one)
+#define LOCK(h) std::lock_guard<std::recursive_mutex> lock_guard_(h->mu); (void)hipSetDevice(h->device)
 
 extern thread_local std::string g_last_global_err;
 int fail(gpca_handle* h, int code, const std::string& msg);

@@ -16,7 +16,8 @@
  *
  * Threading: one handle = one GPU.  Every entry point takes the handle's (recursive) lock, so a handle may be shared
  * between host threads the way the reference shares its `Clone + Send + Sync` accessor between rayon workers
- * (prepare.rs:1770-1779, 1838): calls are serialised per handle, different handles run concurrently.  gpca_destroy
+ * (prepare.rs:1770-1779, 1838): calls are serialised per handle, different handles run concurrently (one host thread may
+ * drive handles on several GPUs: every entry point makes the handle's device the calling thread's current HIP device).  gpca_destroy
  * must not race with other calls on the same handle; gpca_last_error() returns the handle's last message (read it
  * before another thread's call on the same handle overwrites it).  Functions return GPCA_OK (0) or a negative
  * gpca_status.

@@ -134,3 +134,24 @@ def test_c_client_full_path(tmp_path, gpca):
     out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ok" in out.stdout.splitlines()[-1] and "streamed :" in out.stdout
+
+
+def test_rccl_constants_match_the_installed_header():
+    """libgpca.so resolves RCCL with dlopen and therefore restates four facts of rccl.h (gpca_internal.h: kNcclFloat64,
+    kNcclSum, the 128-byte unique id passed by value, ncclAllReduce's argument order): pin them to the installed header."""
+    import re
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl.h in this image")
+    txt = open(hdr).read()
+    mine = open(os.path.join(ROOT, "genomic_pca_amd", "csrc", "gpca_internal.h")).read()
+    k = dict(re.findall(r"(kNccl\w+) = (\d+)", mine))
+    assert re.search(r"ncclFloat64\s*=\s*%s\b" % k["kNcclFloat64"], txt) and re.search(r"ncclSum\s*=\s*%s\b" % k["kNcclSum"], txt)
+    assert re.search(r"#define NCCL_UNIQUE_ID_BYTES 128", txt)
+    assert re.search(r"#define GPCA_UNIQUE_ID_BYTES 128", open(os.path.join(ROOT, "include", "gpca.h")).read())
+    proto = re.search(r"ncclResult_t\s+ncclAllReduce\(([^;]*?)\);", txt, re.S).group(1)
+    names = [a.split()[-1].lstrip("*") for a in proto.replace("\n", " ").split(",")]
+    assert names == ["sendbuff", "recvbuff", "count", "datatype", "op", "comm", "stream"]
+    init = re.search(r"ncclResult_t\s+ncclCommInitRank\(([^;]*?)\);", txt, re.S).group(1)
+    assert [a.split()[-1].lstrip("*") for a in init.replace("\n", " ").split(",")] == ["comm", "nranks", "commId", "rank"]
+    assert "ncclUniqueId commId" in init                       # by value
