@@ -477,7 +477,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         HIPCHK(stream_wait(h));
         if (*flagpin) {
             char buf[160];
-            snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not positive (rank-deficient sketch)", *flagpin - 1, l);
+            snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not finite (overflow or NaN in the sketch)", *flagpin - 1, l);
             return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
         }
         return GPCA_OK;

@@ -747,11 +747,12 @@ void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax
 //   * Cholesky, right-looking: step j scales row j by 1/sqrt(pivot) and subtracts its outer product from the trailing
 //     rows (each element sees the same subtractions, in the same order, as a row-by-row Cholesky-Crout).
 //   * R^-1: lane c back-substitutes R x = e_c from the bottom row up; x[k] = 0 for k > c falls out by itself.
-// Rows / columns n..NN-1 are treated as identity.  A non-positive pivot records (j + 1) in *flag (first failure wins)
+// Rows / columns n..NN-1 are treated as identity.  A pivot that is not finite records (j + 1) in *flag (first failure wins)
 // and the factorisation carries on with pivot 1, so nothing downstream spins or faults; the caller checks the flag
-// once, at the end of the rSVD.
+// once, at the end of the rSVD.  A pivot that is zero to rounding drops its column from the basis (see CholStep).
 // (volatile asm tied to the accumulator it feeds: left to itself the scheduler hoists all ~1000 broadcasts ahead of
 //  the FMAs that consume them and then spills ~1400 SGPRs through v_writelane)
+constexpr double kCholRankTol = 1e-13;   // relative to the column's own squared norm (Gram rounding is ~32 x 2.2e-16)
 template <int LANE>
 __device__ __forceinline__ double lane_bcast(double v, double& dep) {
     int lo, hi;
@@ -777,17 +778,23 @@ struct CholRow {   // col[r] -= R[j][r] * R[j][c] for r = R .. NN-1 (compile-tim
 };
 template <int NN, int J>
 struct CholStep {
-    static __device__ __forceinline__ void run(double (&col)[NN], double (&dinv)[NN], int c, int* flag) {
+    static __device__ __forceinline__ void run(double (&col)[NN], double (&dinv)[NN], double& diag0, int c, int* flag) {
         if constexpr (J < NN) {
             double piv = lane_bcast<J>(col[J], col[J]);
-            if (!(piv > 0.0) || !isfinite(piv)) {
+            const double d0 = lane_bcast<J>(diag0, diag0);          // column J's own squared norm before the elimination
+            if (!isfinite(piv) || !isfinite(d0)) {
                 if (c == 0) atomicCAS(flag, 0, J + 1);
                 piv = 1.0;
             }
-            dinv[J] = rsqrt_nr(piv);
+            // Column J lies in the span of the columns before it (what is left of its squared norm is rounding noise, possibly
+            // negative): a sketch wider than the rank of the matrix -- k + oversample = N samples of centred rows have rank N - 1.
+            // The column leaves the basis: row J of R and of R^-1 become zero, so Q's column J is zero and every later product
+            // carries a zero column (zero singular value) instead of the call failing.
+            const bool dependent = !(piv > kCholRankTol * d0);
+            dinv[J] = dependent ? 0.0 : rsqrt_nr(piv);
             col[J] = (c == J) ? piv * dinv[J] : col[J] * dinv[J];
             CholRow<NN, J, J + 1>::run(col);
-            CholStep<NN, J + 1>::run(col, dinv, c, flag);
+            CholStep<NN, J + 1>::run(col, dinv, diag0, c, flag);
         }
     }
 };
@@ -817,7 +824,10 @@ __global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, 
     for (int r = 0; r < NN; ++r) col[r] = Wg[r * NN + (c & (NN - 1))];      // (unconditional: the loads stay in flight together)
 #pragma unroll
     for (int r = 0; r < NN; ++r) col[r] = (r < n && c < n) ? col[r] : ((r == c) ? 1.0 : 0.0);
-    CholStep<NN, 0>::run(col, dinv, c, flag);
+    double diag0 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NN; ++r) diag0 = (r == c) ? col[r] : diag0;
+    CholStep<NN, 0>::run(col, dinv, diag0, c, flag);
     InvStep<NN, NN - 1>::run(col, x, dinv, c);
     if (c < NN) {
 #pragma unroll

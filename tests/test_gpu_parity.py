@@ -279,6 +279,42 @@ def test_errors_and_state(gpca, engine):
         engine.upload_genotypes_i8(np.zeros((3, 3), np.float32))
 
 
+@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("f32", "int8"), ("f32", "2bit")])
+def test_degenerate_inputs(gpca, oracle, prec, store):
+    """The smallest and the emptiest inputs on every path: the reference's own messages where it has one (main.rs:607-619:
+    no variant left / fewer than 2 samples), an argument error when the sketch is wider than the matrix, and the right answer
+    for a 2 x 3 and a 5 x 3 matrix (rank 2: the third eigenvalue is zero to rounding)."""
+    from genomic_pca_amd import _lib
+    kw = dict(precision=_lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA,
+              storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8)
+    rng = np.random.default_rng(1)
+
+    def run(G, k, ov):
+        with gpca.GpcaEngine(**kw) as e:
+            e.upload_genotypes_i8(G)
+            st = e.snp_stats(gpca.QcConfig.none())
+            ref = oracle.snp_stats(G, G.shape[1], 0.0, 0.0, 1.0)
+            assert np.array_equal(st["keep"], ref["keep"]) and np.array_equal(st["mu"], ref["mu"])
+            e.rsvd(k, ov, 2, 1)
+            return e.eigenvalues(), e.scores(f64=True), ref
+    with pytest.raises(gpca.GpcaError, match="at least 1 variant"):
+        run(np.ones((300, 50), np.int8), 2, 2)                       # every SNP monomorphic: nothing left for the PCA
+    for M, N in ((1, 1), (5, 1)):
+        with pytest.raises(gpca.GpcaError, match="at least 2 samples"):
+            run(rng.integers(0, 3, size=(M, N), dtype=np.int8), 1, 0)
+    for M, N, k, ov in ((5, 3, 2, 5), (3, 40, 5, 0)):
+        with pytest.raises(gpca.GpcaError, match="exceeds min"):
+            run(rng.integers(0, 3, size=(M, N), dtype=np.int8), k, ov)
+    for G, k in ((np.array([[0, 1, 2], [2, 0, 1]], np.int8), 2), (rng.integers(0, 3, size=(5, 3), dtype=np.int8), 3)):
+        ev, sc, ref = run(G, k, 0)
+        r, b = oracle.scale_shift(ref["mu"], ref["sigma"], ref["keep"])
+        E = oracle.exact_pca(G, G.shape[1], r, b, k)                 # the sketch spans the whole sample space: the exact answer
+        assert np.allclose(ev[:2], E["eigenvalues"][:2], rtol=1e-5)
+        assert oracle.max_abs_dpc(sc[:, :2], E["scores"][:, :2]) < 1e-4
+        if k == 3:
+            assert abs(ev[2]) < 1e-6 * ev[0]                          # centred rows: rank <= N - 1
+
+
 def test_allreduce_hook_two_shards_one_gpu(gpca, oracle):
     """N>1 exchange step on one GPU: two engines each hold a row shard; the host hook sums their sketches.
     Sharded result must equal the unsharded one (same Omega rows via snp_offset)."""
