@@ -315,6 +315,32 @@ def test_degenerate_inputs(gpca, oracle, prec, store):
             assert abs(ev[2]) < 1e-6 * ev[0]                          # centred rows: rank <= N - 1
 
 
+@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("f32", "int8")])
+def test_handle_reuse_across_widths_and_shapes(gpca, oracle, prec, store):
+    """One handle, many calls: sketch widths 30 -> 50 -> 15 -> 30 (workspaces and launch plans are re-made as l crosses 32),
+    then a different matrix shape on the same handle, then the first one again.  Every call gives the bits a fresh handle
+    gives -- nothing of an earlier call (column halves, partial sums, digit planes, status flags) leaks into a later one."""
+    from genomic_pca_amd import _lib
+    kw = dict(precision=_lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA,
+              storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8)
+    shapes = [(6000, 700, 48, 1), (1500, 2300, 48, 2)]
+    Gs = [oracle.synth_genotypes(M, N, sd, gpca.synth_thresholds(M, P, seed=sd, fst=0.3)) for M, N, P, sd in shapes]
+
+    def fresh(G, k, seed):
+        with gpca.GpcaEngine(**kw) as e:
+            e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig(0.9, 0.01, 1e-6)); e.rsvd(k, 10, 2, seed=seed)
+            return e.eigenvalues(), e.scores(f64=True), e.loadings(), e.transform()
+    want = {(g, k, sd): fresh(Gs[g], k, sd) for g, k, sd in ((0, 20, 1), (0, 40, 1), (0, 5, 7), (1, 20, 1), (1, 40, 3))}
+    with gpca.GpcaEngine(**kw) as e:
+        for g, k, sd in ((0, 20, 1), (0, 40, 1), (0, 5, 7), (0, 20, 1), (1, 40, 3), (1, 20, 1), (0, 40, 1), (0, 5, 7)):
+            if e.dims() != Gs[g].shape:
+                e.upload_genotypes_i8(Gs[g]); e.snp_stats(gpca.QcConfig(0.9, 0.01, 1e-6))
+            e.rsvd(k, 10, 2, seed=sd)
+            got = (e.eigenvalues(), e.scores(f64=True), e.loadings(), e.transform())
+            for a, b in zip(got, want[(g, k, sd)]):
+                assert np.array_equal(a, b), (g, k, sd)
+
+
 def test_allreduce_hook_two_shards_one_gpu(gpca, oracle):
     """N>1 exchange step on one GPU: two engines each hold a row shard; the host hook sums their sketches.
     Sharded result must equal the unsharded one (same Omega rows via snp_offset)."""
