@@ -366,8 +366,19 @@ class PCA:
         if n_features == 0:
             raise ValueError("PCA requires at least 1 variant (feature), found 0.")   # main.rs:617-619
         k = min(k, n_samples, n_features)                                              # main.rs:621-628
-        g = np.ascontiguousarray(x.T).astype(np.int8, copy=False) if x.dtype == np.int8 else \
-            np.ascontiguousarray(np.rint(x.T)).astype(np.int8)
+        if x.dtype == np.int8:
+            g = np.ascontiguousarray(x.T)
+        else:
+            # build_matrix (vcf.rs:317-345) fills x with u8 dosages; this engine keeps them as codes, so anything that is not
+            # a whole number in the int8 range is refused here (values other than 0/1/2 are refused by the device, status -9)
+            g = np.empty((n_features, n_samples), np.int8)
+            step = max(1, (1 << 24) // max(n_features, 1))
+            for s0 in range(0, n_samples, step):
+                blk = np.asarray(x[s0:s0 + step])
+                r = np.rint(blk)
+                if not (np.all(np.abs(r) <= 127) and np.array_equal(r, blk)):
+                    raise ValueError("PCA.rfit: x must hold genotype dosages 0/1/2 (found a value that is not a whole number)")
+                g[:, s0:s0 + step] = r.T.astype(np.int8)
         self._eng.upload_genotypes_i8(g)
         self._eng.snp_stats(QcConfig.none(), fetch=False)
         l = min(k + n_oversamples, n_samples, self._eng.num_pca_snps())

@@ -242,6 +242,16 @@ def test_pca_class_mirror(gpca, oracle):
         gpca.PCA().rfit(x[:1], 2)                                # main.rs:614-616
     model.rfit(x[:, :3], 10, 10, 1)                              # k clamped to min(n, m) (main.rs:621-628)
     assert model.transform().shape == (N, 3)
+    y = x.copy(); y[7, 11] = 0.5
+    with pytest.raises(ValueError, match="whole number"):        # dosage codes only: nothing is rounded behind the caller's back
+        gpca.PCA().rfit(y, 4)
+    y[7, 11] = 3.0
+    with pytest.raises(gpca.GpcaError) as ei:                    # a whole number that is no dosage: the device's own check
+        gpca.PCA().rfit(y, 4)
+    assert ei.value.status == -9
+    # a sketch as wide as the sample count (k + 10 >= N): the centred matrix has rank N - 1, the call still succeeds
+    small = gpca.PCA().rfit(x[:12], 4, 10, 1)
+    assert small.transform().shape == (12, 4) and np.all(np.isfinite(small.transform()))
 
 
 def test_eigensnp_mirror(gpca, oracle, engine):
