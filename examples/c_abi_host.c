@@ -33,6 +33,7 @@ static int run_gpu(void) {
     unsigned s = 12345u;
     int64_t i, n;
     int rc, c;
+    int32_t cached = 0;
     memset(&cfg, 0, sizeof cfg);
     cfg.device = -1; cfg.precision = GPCA_PREC_I8_EXACT; cfg.storage = GPCA_STORE_INT8;
     for (i = 0; i < M; ++i) {                       /* two populations with different allele frequencies */
@@ -64,6 +65,14 @@ static int run_gpu(void) {
     }
     printf("streamed : %d panel fills, eigenvalues %.6f %.6f %.6f\n", rows.calls, ev2[0], ev2[1], ev2[2]);
     for (c = 0; c < K; ++c) if (ev[c] != ev2[c]) { fprintf(stderr, "streamed != resident\n"); return 1; }
+    /* spare HBM keeps the panels: after one more pass the callback is not asked again, and the bits stay the same */
+    if ((rc = gpca_stream_set_cache(h, -1, &cached)) != GPCA_OK || (rc = gpca_rsvd(h, K, 10, 2, 7)) != GPCA_OK) {
+        fprintf(stderr, "panel cache failed: [%d] %s\n", rc, gpca_last_error(h)); return 1;
+    }
+    rows.calls = 0;
+    if ((rc = gpca_rsvd(h, K, 10, 2, 7)) != GPCA_OK || (rc = gpca_get_eigenvalues(h, ev2)) != GPCA_OK) return 1;
+    printf("cached   : %d panels in HBM, %d panel fills, eigenvalues %.6f %.6f %.6f\n", (int)cached, rows.calls, ev2[0], ev2[1], ev2[2]);
+    for (c = 0; c < K; ++c) if (ev[c] != ev2[c] || rows.calls != 0) { fprintf(stderr, "cached != resident\n"); return 1; }
     if (!(ev[0] > 4.0 * ev[1])) { fprintf(stderr, "expected one structured eigenvalue\n"); return 1; }
     gpca_destroy(h);
     free(g); free(scores);
