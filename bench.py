@@ -286,8 +286,6 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="--streamed: 6 passes per call (bit-identical to the resident engine) instead of 4")
     a = ap.parse_args()
 
-    import genomic_pca_amd as g
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -302,6 +300,10 @@ def main():
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # (after torch on purpose: torch loads its own copy of the HIP runtime by absolute path; libgpca.so, loaded afterwards, binds to
+    #  that copy through its SONAME and the process has ONE runtime -- the other order gives two, and the second to initialise
+    #  sees no device)
+    import genomic_pca_amd as g
 
     if a.streamed:
         return streamed_main(a, g, rank, world, local_rank, dist, torch)

@@ -8,6 +8,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def gpu_present() -> bool:
+    """Is there an AMD GPU on this machine?  Asked of the kernel driver's device node, NOT of torch.cuda: torch ships its own
+    copy of the HIP runtime and loads it by absolute path, so torch.cuda.is_available() in a process that has already loaded
+    libgpca.so (linked against /opt/rocm's HIP) brings up a second runtime, and whichever of the two initialises second sees
+    no device ("PyTorch in the same process")."""
+    return os.path.exists("/dev/kfd")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

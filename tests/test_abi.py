@@ -45,8 +45,8 @@ def test_header_cites_the_reference_interfaces():
 
 
 def test_fails_loudly_without_gpu(gpca):
-    import torch
-    if torch.cuda.is_available():
+    from conftest import gpu_present
+    if gpu_present():
         pytest.skip("GPU present")
     with pytest.raises(gpca.GpcaError) as e:
         gpca.GpcaEngine()
@@ -118,8 +118,8 @@ def test_header_is_plain_c99_and_links(tmp_path, gpca):
     it runs the host-only entry points and sees gpca_create fail loudly with GPCA_ERR_NO_DEVICE."""
     gpca.load()
     exe = _build_c_client(tmp_path)
-    import torch
-    if torch.cuda.is_available():
+    from conftest import gpu_present
+    if gpu_present():
         pytest.skip("GPU present: covered by test_c_client_full_path")
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr

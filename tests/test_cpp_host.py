@@ -1,0 +1,225 @@
+"""The native host program (genomic_pca_amd/host: include/gpca.hpp + formats.hpp + genomic_pca.cpp -> bin/genomic_pca): the
+reference's command line as a compiled program over the C ABI.  CPU: its parsers and writers against genomic_pca_amd/io.py
+(through a test-only dump driver), its argument handling, and that it fails loudly without a GPU.  GPU: both workflows end to
+end, byte for byte the files `python -m genomic_pca_amd` writes."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from genomic_pca_amd import io as gio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "genomic_pca_amd", "bin", "genomic_pca")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def host_bin(gpca):
+    gpca.load()                                                   # (builds libgpca.so when it is missing)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "genomic_pca_amd", "host"), "-s"])
+    assert os.path.exists(BIN)
+    return BIN
+
+
+@pytest.fixture(scope="module")
+def dump(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("cpp") / "dump_formats")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "genomic_pca_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "dump_formats.cpp"), "-lz", "-o", exe])
+
+    def run(*args):
+        out = subprocess.run([exe, *map(str, args)], capture_output=True, text=True)
+        return out.returncode, [ln.split("\t") for ln in out.stdout.rstrip("\n").split("\n")]
+    return run
+
+
+def test_cpp_ld_blocks_match_io_py(tmp_path, dump):
+    p = tmp_path / "blocks.txt"
+    p.write_text("# comment\nchr\tstart\tend\nchromosome\tstart\tend\nchr1 100 200\nCHR1\t150\t400\n2 1 50 extra\nbad line\n\nX 5 9\nchrchr7 1 2\n")
+    chroms = ["1", "chr1", "1", "2", "2", "X", "3", "Chr7"]
+    pos = [100, 180, 300, 50, 51, 7, 7, 2]
+    qc = [1, 1, 1, 1, 1, 0, 1, 1]
+    (tmp_path / "snps.txt").write_text("".join(f"{c} {q} {k}\n" for c, q, k in zip(chroms, pos, qc)))
+    rc, rows = dump("ld", p, tmp_path / "snps.txt")
+    assert rc == 0
+    blocks = gio.parse_ld_block_file(str(p))
+    assert [(r[1], int(r[2]), int(r[3]), r[4]) for r in rows if r[0] == "block"] == blocks
+    keep, by_tag = gio.map_snps_to_ld_blocks(blocks, chroms, pos, np.array(qc, np.uint8))
+    assert [int(x) for x in next(r for r in rows if r[0] == "keep")[1:]] == keep.tolist()
+    assert [(r[1], [int(x) for x in r[2:]]) for r in rows if r[0] == "tag"] == by_tag
+
+
+def test_cpp_vcf_reader_matches_io_py(tmp_path, dump):
+    """The rules of vcf.rs:52-63, 109-121, 244-266 on the records of tests/test_io_cli.py::test_vcf_rules plus random ones
+    (GT first / not first, extra FORMAT keys, broken genotypes), plain and gzip, two files with one sample list."""
+    rng = np.random.default_rng(5)
+    ns = 37
+    names = [f"S{i}" for i in range(ns)]
+    head = "##fileformat=VCFv4.2\n##contig=<ID=1>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"
+    gts = np.array(["0|0", "0|1", "1|0", "1|1", "0/1", "1/1"])
+    bad = ["./.", "0|2", "1", "0|1|1", ".|1", "01", ""]
+
+    def body(n, chrom):
+        lines = []
+        for v in range(n):
+            g = gts[rng.integers(0, len(gts), ns)].tolist()
+            fmt = ["GT", "GT:DP", "GT:DP:GQ", "DP:GT", "DP:GQ:GT"][v % 5]
+            if v % 7 == 3:
+                g[int(rng.integers(0, ns))] = bad[v % len(bad)]
+            gi = fmt.split(":").index("GT")
+            fields = [":".join(["7"] * gi + [x] + ["9"] * (len(fmt.split(":")) - gi - 1)) for x in g]
+            ref, alt = [("A", "C"), ("AT", "C"), ("A", "C,T"), ("G", "T")][v % 4 if v % 11 == 0 else 0]
+            if v % 13 == 5:
+                fields = fields[:-1]                                  # a short record
+            lines.append(f"{chrom}\t{v + 1}\trs{v}\t{ref}\t{alt}\t.\tPASS\t.\t{fmt}\t" + "\t".join(fields))
+        return "\n".join(lines) + "\n"
+    f1, f2 = tmp_path / "a.vcf", tmp_path / "b.vcf.gz"
+    f1.write_text(head + body(120, "1"))
+    with gzip.open(f2, "wt") as f:
+        f.write(head + body(90, "chr2"))
+    for maf in (0.0, 0.05, 0.3):
+        want_ids, want_rows = [], []
+        for f in (f1, f2):
+            s, ids, G = gio.read_vcf(str(f), maf)
+            assert s == names
+            want_ids += ids; want_rows += G.tolist()
+        rc, rows = dump("vcf", maf, f1, f2)
+        assert rc == 0 and rows[0] == ["samples"] + names
+        assert [r[0] for r in rows[1:]] == want_ids and len(want_ids) > 20
+        assert [[int(x) for x in r[1:]] for r in rows[1:]] == want_rows
+    other = tmp_path / "c.vcf"
+    other.write_text(head.replace("S3\t", "X3\t") + body(5, "3"))
+    rc, rows = dump("vcf", 0.0, f1, other)
+    assert rc == 1 and "Sample mismatch between VCF files" in rows[-1][1]           # vcf.rs:78-95
+
+
+def test_cpp_plink_reader_and_writers(tmp_path, dump):
+    rng = np.random.default_rng(0)
+    G = rng.integers(0, 3, size=(50, 13), dtype=np.int8)
+    G[3, 4] = -127
+    pre = str(tmp_path / "toy")
+    gio.write_plink(pre, G, [f"s{i}" for i in range(13)], [f"rs{i}" for i in range(50)], ["1"] * 25 + ["chrX"] * 25, list(range(100, 150)))
+    fs = gio.read_plink(pre + ".bed")
+    rc, rows = dump("plink", pre + ".bed")
+    assert rc == 0 and rows[0] == ["dims", "50", "13", "4"]
+    assert [r[1] for r in rows if r[0] == "sample"] == fs.sample_ids
+    snps = [r for r in rows if r[0] == "snp"]
+    assert [r[1] for r in snps] == fs.chromosomes and [r[2] for r in snps] == fs.variant_ids
+    assert [int(r[3]) for r in snps] == fs.positions.tolist()
+    assert np.array_equal(np.array([[int(x) for x in r[4:]] for r in snps], np.uint8), np.asarray(fs.bed_rows))
+    open(pre + ".bed", "r+b").write(b"\x6c\x1b\x00")                              # sample-major magic is rejected
+    rc, rows = dump("plink", pre + ".bed")
+    assert rc == 1 and "not a SNP-major PLINK .bed" in rows[-1][1]
+    # writers: the bytes of io.py's (main.rs:696-839 formats)
+    cpp, py = str(tmp_path / "c" / "run"), str(tmp_path / "p" / "run")
+    os.makedirs(os.path.dirname(py))
+    rc, rows = dump("writers", cpp)
+    assert rc == 0 and rows[-1][0] == "mismatch" and "Mismatch in lengths" in rows[-1][1]
+    pcs = np.array([[1.23456789, -0.5], [2.0, 1e-7]], np.float32)
+    gio.write_principal_components(py, "eigensnp.pca.tsv", ["s1", "s2", "s3"], pcs)
+    gio.write_eigenvalues(py + "_empty", [])
+    gio.write_eigenvalues(py, [12.5, 0.1234567])
+    gio.write_loadings(py, ["rs1", "rs2"], ["1", "2"], [10, 20], np.array([[0.5, -0.25], [0.125, 1.0]], np.float32))
+    for sfx in (".eigensnp.pca.tsv", "_empty.eigenvalues.tsv", ".eigenvalues.tsv", ".eigensnp.loadings.tsv"):
+        assert open(cpp + sfx).read() == open(py + sfx).read(), sfx
+
+
+def test_cpp_cli_arguments_and_no_gpu(tmp_path, host_bin):
+    run = lambda *a: subprocess.run([host_bin, *a], capture_output=True, text=True)
+    h = run("--help")
+    assert h.returncode == 0
+    for flag in ("--vcf-dir", "--bed-file", "--eigensnp", "--out", "--components", "--maf", "--rfit-seed", "--ld-block-file",
+                 "--eigensnp-k-global", "--eigensnp-sample-keep-file", "--eigensnp-seed"):
+        assert flag in h.stdout
+    assert run().returncode == 2 and "--out" in run().stderr
+    assert run("--out", "x").returncode == 2                                        # neither workflow selected
+    assert run("--out", "x", "--eigensnp").returncode == 2                          # main.rs:296-301
+    r = run("--out", "x", "--bogus")
+    assert r.returncode == 2 and "unexpected argument '--bogus'" in r.stderr
+    assert run("--out", "x", "-k", "abc", "-d", ".").returncode == 2
+    r = run("--out", str(tmp_path / "o"), "--eigensnp", "--bed-file", str(tmp_path / "none.bed"), "--ld-block-file", "x")
+    assert r.returncode == 1 and "cannot open" in r.stderr
+    (tmp_path / "empty").mkdir()
+    r = run("--out", str(tmp_path / "o"), "-d", str(tmp_path / "empty"), "-k", "2")
+    assert r.returncode == 1 and "No VCF files found" in r.stderr                  # main.rs:153-155
+    from conftest import gpu_present
+    if gpu_present():
+        return
+    # a parsable input and no GPU: the program stops at gpca_create -- there is no CPU path behind it
+    d = tmp_path / "v"; d.mkdir()
+    (d / "a.vcf").write_text("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\tC\n1\t5\t.\tA\tG\t.\t.\t.\tGT\t0/1\t1/1\t0/0\n")
+    r = run("--out", str(tmp_path / "o"), "-d", str(d), "-k", "1")
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    assert not os.path.exists(str(tmp_path / "o") + ".vcf.pca.tsv")
+
+
+# ------------------------------------------------------------------------------------------------ GPU end to end
+def _chr22_fileset(tmp_path):
+    z = np.load(os.path.join(GOLD, "chr22_subset50_120k.npz"))
+    rows = z["bed_rows"]; M = rows.shape[0]
+    pre = str(tmp_path / "chr22_subset50")
+    with open(pre + ".bed", "wb") as f:
+        f.write(b"\x6c\x1b\x01"); f.write(rows.tobytes())
+    with open(pre + ".fam", "w") as f:
+        for fid, iid in zip(z["fids"], z["iids"]):
+            f.write(f"{fid} {iid} 0 0 0 -9\n")
+    pos = 16_050_000 + 25 * np.arange(M)
+    with open(pre + ".bim", "w") as f:
+        for i in range(M):
+            f.write(f"22\t22:{pos[i]}\t0\t{pos[i]}\tA\tG\n")
+    return pre, z
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--gpca-storage", "2bit"], ["--gpca-stream", "on", "--gpca-panel-rows", "16384"], ["KEEP"],
+                                   ["--gpca-precision", "f32"]])
+def test_cpp_eigensnp_workflow_equals_python_cli(tmp_path, host_bin, extra):
+    """configs[2] data (the reference's chr22_subset50 genotypes, 120k-SNP slice) with several LD blocks, through the compiled
+    host program and through `python -m genomic_pca_amd`: the same three files, byte for byte."""
+    from genomic_pca_amd.cli import main
+    pre, z = _chr22_fileset(tmp_path)
+    ld = tmp_path / "ld.txt"
+    ld.write_text("chr\tstart\tend\nchr22 16050000 16900000\n22 16800000 17500000\n22 18000000 500000000\n")
+    extra = list(extra)
+    if extra == ["KEEP"]:
+        kf = tmp_path / "keep.txt"
+        kf.write_text("".join(f"{i}\n" for i in list(z["iids"])[1::2]))
+        extra = ["--eigensnp-sample-keep-file", str(kf)]
+    common = ["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--eigensnp-k-global", "12", "--eigensnp-seed", "7"] + extra
+    out_c, out_p = str(tmp_path / "c" / "run"), str(tmp_path / "p" / "run")
+    r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "SNPs passed QC" in r.stderr
+    assert main(["--out", out_p] + common) == 0
+    for sfx in (".eigensnp.pca.tsv", ".eigenvalues.tsv", ".eigensnp.loadings.tsv"):
+        a, b = open(out_c + sfx).read(), open(out_p + sfx).read()
+        assert a == b, sfx
+        assert len(a.split("\n")) > 10
+
+
+@pytest.mark.gpu
+def test_cpp_vcf_workflow_equals_python_cli(tmp_path, host_bin, gpca, oracle):
+    from genomic_pca_amd.cli import main
+    M, N = 600, 48
+    G = oracle.synth_genotypes(M, N, 8, gpca.synth_thresholds(M, 4, seed=8, fst=0.3))
+    names = [f"S{i}" for i in range(N)]
+    gt = {0: "0/0", 1: "0|1", 2: "1/1"}
+    d = tmp_path / "vcfs"; d.mkdir()
+    for ci, (lo, hi) in enumerate([(0, 350), (350, 600)]):
+        opener = gzip.open if ci == 0 else open
+        with opener(d / (f"chr{ci + 1}.vcf" + (".gz" if ci == 0 else "")), "wt") as f:
+            f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+            for i in range(lo, hi):
+                f.write(f"{ci + 1}\t{i + 1}\t.\tA\tC\t.\t.\t.\tGT:DP\t" + "\t".join(gt[int(v)] + ":5" for v in G[i]) + "\n")
+    for extra in ([], ["--write-eigenvalues"]):
+        out_c, out_p = str(tmp_path / "c" / "v"), str(tmp_path / "p" / "v")
+        common = ["--vcf-dir", str(d), "-k", "4", "--maf", "0.05", "--rfit-seed", "3"] + extra
+        r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert main(["--out", out_p] + common) == 0
+        for sfx in (".vcf.pca.tsv", ".eigenvalues.tsv"):
+            assert open(out_c + sfx).read() == open(out_p + sfx).read(), sfx
+        assert (len(open(out_c + ".eigenvalues.tsv").read().split("\n")) > 3) == bool(extra)
