@@ -223,3 +223,41 @@ def test_cpp_vcf_workflow_equals_python_cli(tmp_path, host_bin, gpca, oracle):
         for sfx in (".vcf.pca.tsv", ".eigenvalues.tsv"):
             assert open(out_c + sfx).read() == open(out_p + sfx).read(), sfx
         assert (len(open(out_c + ".eigenvalues.tsv").read().split("\n")) > 3) == bool(extra)
+
+
+@pytest.mark.gpu
+def test_gpca_hpp_mirror_types(tmp_path, gpca, oracle):
+    """include/gpca.hpp used directly (accessor pull API and its `Clone`, compute_pca over a union of LD blocks with the
+    accessor restored afterwards, PCA::rfit/transform, the reference's argument errors): the numbers the Python mirror gives."""
+    gpca.load()
+    exe = str(tmp_path / "hpp_client")
+    pkg = os.path.join(ROOT, "genomic_pca_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "hpp_client.cpp"), "-L" + pkg, "-lgpca", "-Wl,-rpath," + pkg, "-o", exe])
+    M, N = 3000, 200
+    G = oracle.synth_genotypes(M, N, 4, gpca.synth_thresholds(M, 6, seed=4, fst=0.3))
+    G[::40] = 1                                                     # monomorphic rows leave the PCA
+    G.tofile(tmp_path / "g.i8")
+    out = subprocess.run([exe, str(tmp_path / "g.i8"), str(M), str(N)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = {r[0]: r[1:] for r in (ln.split("\t") for ln in out.stdout.strip().split("\n"))}
+    with gpca.GpcaEngine() as e:
+        e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig(0.9, 0.01, 1e-6))
+        acc = gpca.MicroarrayGenotypeAccessor(e)
+        D = acc.num_pca_snps()
+        assert rows["dims"] == [str(D), str(N)] and D < M
+        blk = acc.get_standardized_snp_sample_block([0, 3, 5], [1, 0, 7, 2])
+        assert np.array_equal(np.array([float(x) for x in rows["block"]], np.float32), blk.reshape(-1))
+        b1 = gpca.LdBlockSpecification("a", list(range(D // 3)))
+        b2 = gpca.LdBlockSpecification("b", list(range(D // 2, D, 2)))
+        cfg = gpca.EigenSNPCoreAlgorithmConfig(target_num_global_pcs=4, random_seed=9)
+        res, _ = gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, [b1, b2])
+        used = len(b1.pca_snp_ids_in_block) + len(b2.pca_snp_ids_in_block)
+        assert rows["used"] == [str(used), str(N), "4"] and rows["loadings"] == [str(used * 4)] and rows["restored"] == [str(D)]
+        assert np.array_equal(np.array([float(x) for x in rows["eig"]]), res.final_principal_component_eigenvalues)
+        assert np.array_equal(np.array([float(x) for x in rows["scores0"]], np.float32), res.final_sample_principal_component_scores[0])
+    assert "out of range" in rows["range"][0] and rows["pull"] == ["-1"]
+    model = gpca.PCA().rfit(G.T, 3, 10, 1)
+    assert rows["pca"][:2] == ["3", str(N * 3)]
+    assert np.array_equal(np.array([float(x) for x in rows["pca"][2:]]), model.explained_variance())
+    assert "must be > 0" in rows["k0"][0] and "at least 2 samples" in rows["n1"][0] and "before rfit" in rows["unfitted"][0]
