@@ -1,0 +1,88 @@
+// Bare int8 MFMA loops on random operands: v_mfma_i32_32x32x32_i8 against v_mfma_i32_16x16x64_i8 at the same MACs per wave,
+// operands in registers (MI355X_MICROARCH.md, DVFS give-back item 7: the clock the chip holds under load can depend on the MFMA
+// shape; measured there for bf16).  Prints TOP/s and the in-kernel clock (s_memtime / s_memrealtime) of each loop.
+//   build: hipcc --offload-arch=gfx950 -O3 kbench_mfma_shape.hip -o kbench_mfma_shape
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// 4 accumulators of 32x32 (4 digit planes of one 32-row tile, as k_gq_2bit holds them): 4 x 32768 MACs per step
+__global__ __launch_bounds__(256) void k32(const i32x4* __restrict__ in, int* __restrict__ out, int iters, unsigned long long* clk) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    i32x4 a = in[t], b0 = in[t + 65536], b1 = in[t + 2 * 65536], b2 = in[t + 3 * 65536], b3 = in[t + 4 * 65536];
+    i32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b3, c3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    int s = 0;
+    for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+    out[t] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+// the same MACs per step with 16x16x64: 8 instructions of 16384 MACs (2 row halves x 4 planes), 8 accumulators of 4 registers
+__global__ __launch_bounds__(256) void k16(const i32x4* __restrict__ in, int* __restrict__ out, int iters, unsigned long long* clk) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    i32x4 a0 = in[t], a1 = in[t + 5 * 65536], b0 = in[t + 65536], b1 = in[t + 2 * 65536], b2 = in[t + 3 * 65536], b3 = in[t + 4 * 65536];
+    i32x4 c[8] = {};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, c[0], 0, 0, 0);
+        c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, c[1], 0, 0, 0);
+        c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, c[2], 0, 0, 0);
+        c[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b3, c[3], 0, 0, 0);
+        c[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, c[4], 0, 0, 0);
+        c[5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, c[5], 0, 0, 0);
+        c[6] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, c[6], 0, 0, 0);
+        c[7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b3, c[7], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    int s = 0;
+    for (int j = 0; j < 8; ++j) for (int e = 0; e < 4; ++e) s += c[j][e];
+    out[t] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+int main(int argc, char** argv) {
+    const int zero = argc > 1 && atoi(argv[1]) == 0;       // "0": all-zero operands (the clock without data toggling)
+    const int blocks = 256 * 2, iters = 20000;
+    std::vector<int> h(6 * 65536 * 4 + 1024 * 4);
+    srand(1);
+    for (auto& v : h) v = zero ? 0 : (int)(((unsigned)rand() << 16) ^ (unsigned)rand());
+    i32x4* din; int* dout; unsigned long long* dclk;
+    hipMalloc(&din, h.size() * 4); hipMalloc(&dout, blocks * 256 * 4); hipMalloc(&dclk, blocks * 16);
+    hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int which = 0; which < 2; ++which) {
+        for (int rep = 0; rep < 3; ++rep) {
+            // ~2 s of back-to-back launches before the timed one (DVFS settles)
+            const int warm = rep == 0 ? 300 : 2;
+            for (int w = 0; w < warm; ++w) {
+                if (which == 0) hipLaunchKernelGGL(k32, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+                else hipLaunchKernelGGL(k16, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+            }
+            hipEventRecord(e0);
+            if (which == 0) hipLaunchKernelGGL(k32, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+            else hipLaunchKernelGGL(k16, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            std::vector<unsigned long long> c(blocks * 2);
+            hipMemcpy(c.data(), dclk, blocks * 16, hipMemcpyDeviceToHost);
+            std::vector<double> ghz;
+            for (int b = 0; b < blocks; ++b) ghz.push_back((double)c[2 * b] / (double)c[2 * b + 1] * 0.1);
+            std::sort(ghz.begin(), ghz.end());
+            const double macs = (double)blocks * 4 /*waves*/ * iters * 4.0 * 32768.0;
+            printf("%s %s rep %d: %.3f ms  %.1f TOP/s  in-kernel clock %.3f GHz (median over workgroups)\n", zero ? "zeros " : "random",
+                   which == 0 ? "32x32x32" : "16x16x64", rep, ms, 2.0 * macs / (ms * 1e-3) / 1e12, ghz[ghz.size() / 2]);
+        }
+    }
+    return 0;
+}
