@@ -412,7 +412,7 @@ def main():
             "configs[3] per-GPU shard, 1.25M x 100k int8": "profiles/r2_bench_c4shard_1.25Mx100k_int8.json",
             "10M x 100k on ONE GPU, 2-bit rows, exact path": "profiles/r2_bench_10Mx100k_2bit_one_gpu.json",
             "north_star literal: 10M x 100k on ONE GPU, MFMA-fp32 path": "profiles/r2_northstar_10Mx100k_f32_mfma_2bit_one_gpu.json",
-            "configs[4] per-GPU shard streamed out of core, 6.25M x 500k, k = 40": "profiles/r2_stream_config5_6.25Mx500k_k40_2bit.json",
+            "configs[4] per-GPU shard streamed out of core, 6.25M x 500k, k = 40": "profiles/r2_stream_config5_6.25Mx500k_k40_2bit_cache.json",
         }.items() if os.path.exists(os.path.join(ROOT, v_))}
         if world == 1 and not a.no_cpu_baseline:
             out["parity"] = parity_check(g, PREC[a.precision], a.rfit_seed)
