@@ -16,6 +16,24 @@ def gpu_present() -> bool:
     return os.path.exists("/dev/kfd")
 
 
+def gpu_count() -> int:
+    """GPUs a HIP process can use here, asked of a throw-away child process (so that no HIP runtime comes up in this one)."""
+    global _GPU_COUNT
+    if _GPU_COUNT is None:
+        _GPU_COUNT = 0
+        if gpu_present():
+            import subprocess
+            try:
+                out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+                _GPU_COUNT = int(out.stdout.strip().splitlines()[-1])
+            except Exception:
+                _GPU_COUNT = 1
+    return _GPU_COUNT
+
+
+_GPU_COUNT = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
