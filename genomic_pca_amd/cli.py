@@ -129,6 +129,16 @@ def _load_bed(eng, a, fs, cols):
     def subset(r0, n):                                                               # kept sample columns of rows [r0, r0 + n)
         return lut[(np.asarray(rows[r0:r0 + n])[:, cols // 4] >> shift) & 3]
     n_samples = fs.n_samples if cols is None else len(cols)
+    if a.gpca_stream == "auto":
+        # resident needs the matrix (1 B or 0.25 B per genotype, rows padded) plus the solver's workspace (gpca.h,
+        # gpca_get_device_memory): a load that fits with nothing to spare would only fail later, in gpca_rsvd
+        free, _ = eng.device_memory()
+        free = int(os.environ.get("GPCA_CLI_FREE_BYTES", free))       # (test hook: pretend the device is smaller)
+        per_row = -(-n_samples // 1024) * 1024 // (4 if a.gpca_storage == "2bit" else 1) + 512
+        need = rows.shape[0] * (per_row + 1024) + n_samples * 8192 + (1 << 30)
+        if need > free:
+            _log(f"the genotype matrix needs about {need / 2**30:.1f} GiB resident, {free / 2**30:.1f} GiB are free: walking it out of core")
+            a.gpca_stream = "on"
     if a.gpca_stream != "on":
         try:
             if cols is None:

@@ -390,6 +390,16 @@ extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t l
     return GPCA_OK;
 }
 
+extern "C" int gpca_get_device_memory(gpca_handle* h, int64_t* free_bytes, int64_t* total_bytes) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return GPCA_OK;
+}
+
 extern "C" int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N) {
     if (!h) return GPCA_ERR_BAD_ARG;
     LOCK(h);

@@ -199,6 +199,12 @@ class GpcaEngine:
         self._chk(self._lib.gpca_stream_set_cache(self._h, int(max_bytes), C.byref(n)))
         return n.value
 
+    def device_memory(self):
+        """(free, total) bytes of the engine's device."""
+        f, t = C.c_int64(), C.c_int64()
+        self._chk(self._lib.gpca_get_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def download_genotypes_i8(self) -> np.ndarray:
         M, N = self.dims()
         out = np.empty((M, N), np.int8)

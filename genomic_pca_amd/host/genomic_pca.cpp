@@ -227,13 +227,29 @@ void load_bed(gpca::Engine& eng, const Args& a, const gpca_host::PlinkFileset& f
     const int64_t n_samples = kept ? (int64_t)kept->cols.size() : fs.n_samples;
     if (kept) { src.kind = GPCA_PANEL_HOST_I8; src.fill = fill_kept_columns; src.user = kept; }
     else { src.kind = GPCA_PANEL_HOST_BED; src.fill = fill_bed_rows; src.user = const_cast<gpca_host::PlinkFileset*>(&fs); }
-    if (a.stream != "on") {
+    std::string mode = a.stream;
+    if (mode == "auto") {
+        // resident needs the matrix (1 B or 0.25 B per genotype, rows padded) plus the solver's workspace (gpca.h,
+        // gpca_get_device_memory): a load that fits with nothing to spare would only fail later, in gpca_rsvd
+        int64_t free_b = eng.device_memory().first;
+        if (const char* e = std::getenv("GPCA_CLI_FREE_BYTES")) free_b = std::atoll(e);       // (test hook: pretend the device is smaller)
+        const int64_t per_row = (n_samples + 1023) / 1024 * 1024 / (a.storage == "2bit" ? 4 : 1) + 512;
+        const double need = (double)fs.n_snps * (double)(per_row + 1024) + (double)n_samples * 8192.0 + 1073741824.0;
+        if (need > (double)free_b) {
+            char buf[200];
+            std::snprintf(buf, sizeof buf, "the genotype matrix needs about %.1f GiB resident, %.1f GiB are free: walking it out of core",
+                          need / 1073741824.0, (double)free_b / 1073741824.0);
+            logmsg(buf);
+            mode = "on";
+        }
+    }
+    if (mode != "on") {
         try {
             if (kept) eng.load_from_source(src, fs.n_snps, n_samples);
             else eng.upload_bed2bit(fs.bed_rows, fs.n_snps, fs.n_samples);     // the memory map goes up in 256 MiB row chunks, decoded on the GPU
             return;
         } catch (const gpca::Error& e) {
-            if (a.stream == "off" || e.status() != GPCA_ERR_OOM) throw;
+            if (mode == "off" || e.status() != GPCA_ERR_OOM) throw;
             logmsg("the genotype matrix does not fit the device: walking it out of core");
         }
     }

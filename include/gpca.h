@@ -159,6 +159,9 @@ GPCA_API int gpca_stream_set_fused(gpca_handle* h, int32_t fused);
  * *n_cached (may be NULL) receives the number of cached panels.  GPCA_ERR_OOM keeps the panels allocated so far. */
 GPCA_API int gpca_stream_set_cache(gpca_handle* h, int64_t max_bytes, int32_t* n_cached);
 GPCA_API int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N);
+/* Free and total memory of the handle's device in bytes (hipMemGetInfo): what a host needs to choose between a resident load
+ * (M x N bytes int8, M x N / 4 packed, plus about 1 KiB per SNP row and 8 KiB per sample of workspace) and gpca_stream_open. */
+GPCA_API int gpca_get_device_memory(gpca_handle* h, int64_t* free_bytes, int64_t* total_bytes);
 
 /* ---- a1/a3: SNP QC + standardisation parameters (prepare.rs:1100-1422, 1641-1745) -------- */
 /* Any of mu/sigma/keep may be NULL.  mu, sigma are the f32 values the reference stores

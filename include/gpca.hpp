@@ -75,6 +75,7 @@ public:
         check(gpca_stream_set_fused(h_, fused ? 1 : 0));
         if (cache_bytes != 0) check(gpca_stream_set_cache(h_, cache_bytes, nullptr));
     }
+    std::pair<int64_t, int64_t> device_memory() const { int64_t f = 0, t = 0; check(gpca_get_device_memory(h_, &f, &t)); return {f, t}; }   // (free, total) bytes
     std::pair<int64_t, int64_t> dims() const { int64_t M = 0, N = 0; check(gpca_dims(h_, &M, &N)); return {M, N}; }
 
     /* a1/a3 */

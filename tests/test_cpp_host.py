@@ -201,6 +201,30 @@ def test_cpp_eigensnp_workflow_equals_python_cli(tmp_path, host_bin, extra):
 
 
 @pytest.mark.gpu
+def test_both_clis_go_out_of_core_when_the_device_is_too_small(tmp_path, host_bin, monkeypatch):
+    """--gpca-stream auto (the default) asks the device how much memory is free (gpca_get_device_memory) and walks the .bed out
+    of core when matrix + workspace would not fit: pretending the device holds 16 MiB, both programs say so and still write
+    the files of the resident run (within the TSV rounding: the streamed power iterations quantise per panel)."""
+    from genomic_pca_amd.cli import main
+    pre, z = _chr22_fileset(tmp_path)
+    ld = tmp_path / "ld.txt"
+    ld.write_text("22 1 500000000\n")
+    common = ["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--eigensnp-k-global", "6", "--gpca-panel-rows", "32768"]
+    ref = str(tmp_path / "ref" / "run")
+    assert main(["--out", ref] + common) == 0
+    monkeypatch.setenv("GPCA_CLI_FREE_BYTES", str(16 << 20))
+    out_c, out_p = str(tmp_path / "c" / "run"), str(tmp_path / "p" / "run")
+    r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "walking it out of core" in r.stderr, r.stderr
+    assert main(["--out", out_p] + common) == 0
+    num = lambda path, c: np.array([[float(x) for x in ln.split("\t")[c:]] for ln in open(path).read().strip().split("\n")[1:]])
+    for sfx, c in ((".eigensnp.pca.tsv", 1), (".eigenvalues.tsv", 1), (".eigensnp.loadings.tsv", 3)):
+        assert open(out_c + sfx).read() == open(out_p + sfx).read(), sfx
+        a, b = num(out_c + sfx, c), num(ref + sfx, c)
+        assert np.max(np.abs(a - b)) <= 5e-6 * max(1.0, np.max(np.abs(b))), sfx
+
+
+@pytest.mark.gpu
 def test_cpp_vcf_workflow_equals_python_cli(tmp_path, host_bin, gpca, oracle):
     from genomic_pca_amd.cli import main
     M, N = 600, 48

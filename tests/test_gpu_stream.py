@@ -465,6 +465,32 @@ def test_handle_shared_between_threads(gpca, oracle):
         assert not errs, errs[0]
 
 
+def test_no_device_memory_is_lost_across_handles_and_modes(gpca, oracle):
+    """Forty handle lifetimes through every residency mode (int8 / 2-bit upload, panel stream with and without the cache, a
+    re-upload on a live handle, a failed call): the device ends with the free memory it started with."""
+    M, N = 3000, 300
+    G = oracle.synth_genotypes(M, N, 2, gpca.synth_thresholds(M, 4, seed=2, fst=0.2))
+    th = gpca.synth_thresholds(M, 4, seed=2, fst=0.2)
+    with gpca.GpcaEngine(**_modes("int8")) as probe:
+        for rep in range(41):
+            if rep == 1:
+                free0 = probe.device_memory()[0]                  # (after one warm-up lifetime: the runtime's own pools exist)
+            store = "2bit" if rep & 1 else "int8"
+            with gpca.GpcaEngine(**_modes(store)) as e:
+                e.upload_genotypes_i8(G); e.snp_stats(); e.rsvd(4 + 30 * (rep % 2), 10, 2, seed=rep)
+                e.transform()
+                e.stream_open(gpca.PanelSource.synth(th, 2), M, N, panel_rows=1024, ring_slots=2 + rep % 3)
+                e.stream_set_cache(-1 if rep % 4 else 2 << 20)
+                e.snp_stats(); e.rsvd(5, 10, 2, seed=1)
+                with pytest.raises(gpca.GpcaError):
+                    e.rsvd(80, 10, 2, seed=1)                     # l > 64: an error path between two good calls
+                e.upload_genotypes_i8(G[:500])                    # closes the stream, frees ring and cache
+                e.snp_stats(); e.rsvd(3, 5, 1, seed=2)
+        free1, total = probe.device_memory()
+    assert total > 200 * 2**30                                    # 288 GB of HBM3E
+    assert abs(free1 - free0) <= 64 << 20, (free0, free1)         # (allocator granularity, not a per-lifetime drift)
+
+
 def test_timings_are_bounded(gpca, oracle):
     """More pending records than the cap: they are folded into per-name totals, launch counts stay exact."""
     with gpca.GpcaEngine(**_modes("int8")) as e:
