@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GPCA_VERSION 200 /* 0.2.0 */
+#define GPCA_VERSION 210 /* 0.2.1: + gpca_stream_set_cache, gpca_get_device_memory */
 #define GPCA_MISSING_I8 (-127) /* bed_reader i8 missing code, prepare.rs:1224 */
 
 typedef struct gpca_handle gpca_handle;
