@@ -163,12 +163,12 @@ def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn
     eng.stream_open(g.PanelSource.synth16(th16, a.rfit_seed, snp_offset=snp_offset), M, N, panel_rows=a.panel_rows, ring_slots=a.ring,
                     fused=not a.unfused)
     del th16
+    if uid_fn is not None:
+        uid_fn(eng)            # the communicator first: its device buffers exist before the panel cache sizes itself on what is free
     n_cached = eng.stream_set_cache(-1 if cache_gb < 0 else int(cache_gb * 2**30)) if cache_gb else 0
     t0 = time.perf_counter()
     eng.snp_stats(g.QcConfig.none(), fetch=False)
     t_stats = time.perf_counter() - t0
-    if uid_fn is not None:
-        uid_fn(eng)
 
     def barrier():
         if dist is not None:
