@@ -189,6 +189,10 @@ Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves) {
     p.nblocks_n = Npad / 128;
     int64_t W = target_waves / p.nblocks_n;
     if (W < 1) W = 1;
+    // a slice's digit-plane sums live in i32 accumulators: |g| <= 2 times |digit| <= 128 per row keeps 2^22 rows a factor 2 inside
+    // 2^31 (only a resident matrix of > 4M rows AND > 260k samples would get there: more than one GPU holds)
+    const int64_t minW = (Mpad + ((int64_t)1 << 22) - 1) >> 22;
+    if (W < minW) W = minW;
     const int64_t maxW = Mpad / 128;
     if (W > maxW) W = maxW;
     int64_t rpw = (Mpad + W - 1) / W;
