@@ -409,6 +409,9 @@ static int rsvd_preflight(gpca_handle* h, int32_t k, int32_t oversample, int32_t
         "Unexpected missing genotype (-127i8) in a PCA SNP. This should have been filtered by QC.");  // prepare.rs:1909-1911
     if (h->flags & 2u) return fail(h, GPCA_ERR_INVALID_GENOTYPE, "a PCA SNP holds a dosage outside {0,1,2}");
     if (h->sm.on && h->precision != GPCA_PREC_I8_EXACT) return fail(h, GPCA_ERR_STATE, "gpca_rsvd: streamed panels need GPCA_PREC_I8_EXACT");
+    // K1 sums a row's products over all samples in i32 digit-plane accumulators: |g| <= 2 times |digit| <= 128 per sample
+    if (h->precision == GPCA_PREC_I8_EXACT && h->N > ((int64_t)1 << 22))
+        return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: the exact-integer path holds up to 4 194 304 samples per matrix (i32 accumulators); use GPCA_PREC_F32_MFMA beyond");
     HIPCHK(hipSetDevice(h->device));
     h->k = k; h->l = l; h->L = l <= 32 ? 32 : 64;
     h->have_rsvd = false;
