@@ -21,6 +21,11 @@
  * must not race with other calls on the same handle; gpca_last_error() returns the handle's last message (read it
  * before another thread's call on the same handle overwrites it).  Functions return GPCA_OK (0) or a negative
  * gpca_status.
+ *
+ * Limits: k + oversample <= 64 sketch columns; GPCA_PREC_I8_EXACT holds up to 2^22 (4 194 304) samples per matrix (i32
+ * accumulators; GPCA_PREC_F32_MFMA has no such bound); SNP rows per handle are bounded by device memory only (64M rows x 1 000
+ * samples and 10M x 100k as 2-bit codes were run on one MI355X), the bit-for-bit guarantees between partitions of the same
+ * matrix (streamed = resident, any kernel variant) hold up to 2^25 (33.5M) rows per handle, where integer sums stay below 2^53.
  */
 #ifndef GPCA_H
 #define GPCA_H
