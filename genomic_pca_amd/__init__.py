@@ -7,4 +7,4 @@ from .engine import (EigenSNPCoreAlgorithm, EigenSNPCoreAlgorithmConfig, EigenSN
 from .synth import synth_thresholds, synth_thresholds16  # noqa: F401
 from .distributed import shard_rows  # noqa: F401
 
-__version__ = "0.2.1"
+__version__ = "0.2.2"

@@ -82,6 +82,11 @@ PROTOTYPES = {
     "gpca_stream_set_fused": (C.c_int, [_H, C.c_int32]),
     "gpca_stream_set_cache": (C.c_int, [_H, C.c_int64, C.POINTER(C.c_int32)]),
     "gpca_get_device_memory": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gpca_copy_rows": (C.c_int, [_H, _H, C.c_int64, C.c_int64]),
+    "gpca_set_sample_mask": (C.c_int, [_H, C.c_void_p]),
+    "gpca_set_condensed_basis": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
+    "gpca_rsvd_condensed": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
+    "gpca_refine": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "gpca_dims": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gpca_snp_stats": (C.c_int, [_H, C.POINTER(gpca_qc_config), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_get_snp_qc_detail": (C.c_int, [_H, C.c_void_p, C.c_void_p]),

@@ -146,6 +146,14 @@ struct gpca_handle {
     const double* apart_src[2] = {nullptr, nullptr};   // where the partials of each 32-column half sit
     double* d_amax_run = nullptr;    // [2][32] running column abs-max over the panels of a streamed K1 sweep
     double* d_yint = nullptr; size_t cap_yint = 0;   // [halves][N][32] integer partial sums of a streamed K2 sweep
+    // EigenSNP stages (gpca_set_sample_mask / gpca_set_condensed_basis / gpca_rsvd_condensed / gpca_refine, gpca_rsvd.cpp)
+    uint8_t* d_smask = nullptr;      // [N] 1 = the sample takes part in learning the basis (nullptr: all samples)
+    float* d_cw = nullptr; int32_t* d_cfeat0 = nullptr; int c_cmax = 0; int64_t c_R = 0; int c_B = 0;   // block-diagonal W = U_blk Lambda^-1
+    int64_t *d_cblk_row0 = nullptr, *d_cblk_row1 = nullptr; int32_t* d_cblk_feat0 = nullptr;
+    double* dP = nullptr; size_t cap_P = 0;         // [(R + 16)][L] condensed-side factor
+    float* d_lqr = nullptr; size_t cap_lqr = 0;     // [Mpad][L] orthonormal SNP-side factor of a refinement pass
+    float *d_ones = nullptr, *d_zeros = nullptr; size_t cap_ones = 0, cap_zeros = 0;
+    bool loadings_valid = true;      // (gpca_rsvd_condensed leaves scores only)
     double* d_status = nullptr;      // [16] status word the ranks agree on
     double* h_status = nullptr;      // pinned [32]: contribution | agreed histogram
     // persistent scratch of the pull API (no allocation per call)
@@ -230,6 +238,7 @@ inline bool multi_rank(const gpca_handle* h) { return h->world > 1 || h->hook !=
 constexpr size_t kPlaneBytesPerBlock = (size_t)gpca::kDigits * 1024;   // digit planes of one 32-row (or 32-sample) block
 // gpca_residency.cpp
 void free_stats(gpca_handle* h);
+void free_eigensnp(gpca_handle* h);
 void free_ws(gpca_handle* h);
 void stream_close(gpca_handle* h);
 int finish_pack_flags(gpca_handle* h, unsigned* d_flags, hipStream_t st);

@@ -8,7 +8,13 @@ void free_stats(gpca_handle* h) {
     dfree(h->d_counts); dfree(h->d_flags); dfree(h->d_pca_rows);
     h->have_stats = false; h->n_pca = 0; h->pca_rows.clear();
 }
+void free_eigensnp(gpca_handle* h) {
+    dfree(h->d_smask); dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0);
+    dfree(h->dP); dfree(h->d_lqr); dfree(h->d_ones); dfree(h->d_zeros);
+    h->cap_P = h->cap_lqr = h->cap_ones = h->cap_zeros = 0; h->c_cmax = 0; h->c_R = 0; h->c_B = 0; h->loadings_valid = true;
+}
 void free_ws(gpca_handle* h) {
+    free_eigensnp(h);
     dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
     dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
@@ -387,6 +393,26 @@ extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t l
         return GPCA_OK;
     }
     HIPCHK(hipMemcpy2D(out, (size_t)ld, h->dG, (size_t)h->ld8, (size_t)h->N, (size_t)h->M, hipMemcpyDeviceToHost));
+    return GPCA_OK;
+}
+
+// dst <- rows [row0, row0 + rows) of src's resident matrix, device to device (same device, same storage mode, same sample count by
+// construction): an LD block becomes a matrix of its own, so that every M-sized step of a call on it costs the block's rows only.
+extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, int64_t rows) {
+    if (!dst || !src || dst == src) return fail(dst, GPCA_ERR_BAD_ARG, "gpca_copy_rows: two different handles are required");
+    std::lock(dst->mu, src->mu);
+    std::lock_guard<std::recursive_mutex> g1(dst->mu, std::adopt_lock), g2(src->mu, std::adopt_lock);
+    gpca_handle* h = dst;
+    if (src->sm.on || (!src->dG && !src->dG2)) return fail(h, GPCA_ERR_STATE, "gpca_copy_rows: the source matrix is not resident");
+    if (dst->device != src->device || dst->storage != src->storage) return fail(h, GPCA_ERR_BAD_ARG, "gpca_copy_rows: handles differ in device or storage mode");
+    if (row0 < 0 || rows <= 0 || row0 + rows > src->M) return fail(h, GPCA_ERR_BAD_ARG, "gpca_copy_rows: row range outside the source matrix");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(src->st));
+    CHK(alloc_genotypes(dst, rows, src->N));
+    if (dst->storage == GPCA_STORE_2BIT) HIPCHK(hipMemcpyAsync(dst->dG2, src->dG2 + (size_t)row0 * src->ld2, (size_t)rows * src->ld2, hipMemcpyDeviceToDevice, dst->st));
+    else HIPCHK(hipMemcpyAsync(dst->dG, src->dG + (size_t)row0 * src->ld8, (size_t)rows * src->ld8, hipMemcpyDeviceToDevice, dst->st));
+    dst->pack_flags = src->pack_flags;
+    HIPCHK(hipStreamSynchronize(dst->st));
     return GPCA_OK;
 }
 

@@ -321,6 +321,10 @@ static int stage_power_fused(gpca_handle* h) {
 // CholeskyQR2 of dY -> dQ (f32, padded), s = 1^T Q
 static int stage_orth(gpca_handle* h) {
     const int L = h->L, l = h->l;
+    if (h->d_smask) {   // basis learning on a sample subset (gpca_set_sample_mask): the other samples' rows leave the sketch
+        launch_mask_rows(h->st, h->dY, h->N, L, h->d_smask);
+        HIPCHK(hipGetLastError());
+    }
     for (int round = 0; round < 2; ++round) {      // CholeskyQR2, entirely on the stream (no host round trip)
         const int64_t parts = gram_num_parts(h->N);
         launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
@@ -514,7 +518,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     launch_rightmul_gather_f32(h->st, h->dT, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);
     HIPCHK(hipGetLastError());
     HIPCHK(stream_wait(h));
-    h->have_rsvd = true;
+    h->have_rsvd = true; h->loadings_valid = true;
     return GPCA_OK;
 }
 
@@ -545,6 +549,7 @@ extern "C" int gpca_get_singular_values(gpca_handle* h, double* out) {
 }
 extern "C" int gpca_get_loadings(gpca_handle* h, float* out) {
     NEED_RSVD("gpca_get_loadings");
+    if (!h->loadings_valid) return fail(h, GPCA_ERR_STATE, "gpca_get_loadings: the last call (gpca_rsvd_condensed) produced sample scores only");
     if (h->n_pca) HIPCHK(hipMemcpy(out, h->d_load32, (size_t)h->n_pca * h->k * 4, hipMemcpyDeviceToHost));
     return GPCA_OK;
 }
@@ -552,6 +557,7 @@ extern "C" int gpca_get_loadings(gpca_handle* h, float* out) {
 // PCA::transform (main.rs:659): scores = A^T U on the resident (or streamed) matrix, U = loadings.
 extern "C" int gpca_transform(gpca_handle* h, double* out) {
     NEED_RSVD("gpca_transform");
+    if (!h->loadings_valid) return fail(h, GPCA_ERR_STATE, "gpca_transform: the last call (gpca_rsvd_condensed) produced sample scores only");
     HIPCHK(hipSetDevice(h->device));
     const int L = h->L, k = h->k;
     const bool mr = multi_rank(h);
@@ -582,3 +588,209 @@ extern "C" int gpca_transform(gpca_handle* h, double* out) {
     return GPCA_OK;
 }
 
+
+// ---- EigenSNP stages (efficient_pca's EigenSNPCoreAlgorithm, un-vendored: the stage structure of the published
+//      algorithm, parity unpinned -- DESIGN.md 7c) ---------------------------------------------------------------------------------
+// Basis learning on a sample subset (main.rs:314-316 subset_factor / min / max_subset_size_for_local_basis_learning): rows of the
+// N x l sketch that belong to samples outside the subset are zeroed before every orthonormalisation, so T = A Q and everything
+// learnt from it sees the subset's columns only; gpca_transform still projects ALL samples.  mask = NULL: all samples again.
+extern "C" int gpca_set_sample_mask(gpca_handle* h, const uint8_t* mask) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    if (!have_genotypes(h)) return fail(h, GPCA_ERR_STATE, "gpca_set_sample_mask: no genotypes resident and no panel stream open");
+    HIPCHK(hipStreamSynchronize(h->st));
+    if (!mask) { dfree(h->d_smask); return GPCA_OK; }
+    int64_t n_in = 0;
+    for (int64_t n = 0; n < h->N; ++n) n_in += mask[n] != 0;
+    if (n_in < 2) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_sample_mask: fewer than 2 samples in the subset");
+    if (!h->d_smask) HIPCHK(hipMalloc((void**)&h->d_smask, (size_t)h->N));
+    HIPCHK(hipMemcpy(h->d_smask, mask, (size_t)h->N, hipMemcpyHostToDevice));
+    h->have_rsvd = false;
+    return GPCA_OK;
+}
+
+// The block-diagonal condensed basis W = U_blk Lambda^-1: W[i][0..cmax) are SNP row i's coefficients on the condensed features
+// [feat0[i], feat0[i] + cmax) of its LD block (zero-padded when the block has fewer local components; feat0[i] < 0: the SNP is in no
+// block); R = total number of condensed features.
+extern "C" int gpca_set_condensed_basis(gpca_handle* h, const float* W, const int32_t* feat0, int32_t cmax, int64_t R) {
+    if (!h || !W || !feat0 || cmax < 1 || cmax > 64 || R < 1) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_condensed_basis: bad arguments (1 <= cmax <= 64, R >= 1)");
+    LOCK(h);
+    if (h->sm.on || (!h->dG && !h->dG2)) return fail(h, GPCA_ERR_STATE, "gpca_set_condensed_basis: needs a resident matrix");
+    if (multi_rank(h)) return fail(h, GPCA_ERR_STATE, "gpca_set_condensed_basis: not available on row-sharded handles");
+    const int64_t M = h->M;
+    // blocks = distinct feat0 values; each block's row range [first, last + 1) bounds the reduction over its SNPs
+    std::map<int32_t, std::pair<int64_t, int64_t>> range;
+    for (int64_t i = 0; i < M; ++i) {
+        const int32_t f = feat0[i];
+        if (f < 0) continue;
+        if ((int64_t)f + cmax > R + 64 || f >= R) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_condensed_basis: feat0 out of range");
+        auto it = range.find(f);
+        if (it == range.end()) range[f] = {i, i + 1}; else it->second.second = i + 1;
+    }
+    if (range.empty()) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_condensed_basis: no SNP belongs to a block");
+    std::vector<int64_t> r0, r1; std::vector<int32_t> bf;
+    for (const auto& kv : range) { bf.push_back(kv.first); r0.push_back(kv.second.first); r1.push_back(kv.second.second); }
+    HIPCHK(hipStreamSynchronize(h->st));
+    dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0);
+    const size_t B = bf.size();
+    HIPCHK(hipMalloc((void**)&h->d_cw, (size_t)M * cmax * 4)); HIPCHK(hipMalloc((void**)&h->d_cfeat0, (size_t)M * 4));
+    HIPCHK(hipMalloc((void**)&h->d_cblk_row0, B * 8)); HIPCHK(hipMalloc((void**)&h->d_cblk_row1, B * 8)); HIPCHK(hipMalloc((void**)&h->d_cblk_feat0, B * 4));
+    HIPCHK(hipMemcpy(h->d_cw, W, (size_t)M * cmax * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_cfeat0, feat0, (size_t)M * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_cblk_row0, r0.data(), B * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_cblk_row1, r1.data(), B * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_cblk_feat0, bf.data(), B * 4, hipMemcpyHostToDevice));
+    h->c_cmax = cmax; h->c_R = R; h->c_B = (int)B;
+    return GPCA_OK;
+}
+
+// T' = r o X, c = b^T X for an arbitrary M x L f32 factor X sitting in dT (what gpca_transform does for the loadings)
+static int prep_custom_T(gpca_handle* h) {
+    const int L = h->L;
+    if (h->precision == GPCA_PREC_I8_EXACT) launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dT, h->d_cpart, 0);
+    else launch_scale_rows(h->st, h->dT, h->M, h->Mpad, L, h->d_r, h->d_b, h->dTb, h->d_cpart);
+    HIPCHK(hipGetLastError());
+    h->apart_valid = false;
+    return stage_sum_c(h, omega_num_parts(h->Mpad));
+}
+
+// l x l Gram of a tall factor -> host eigen-decomposition (descending); leaves V (l x l, columns) and w
+static int small_eigen(gpca_handle* h, int l, std::vector<double>& V, std::vector<double>& w) {
+    const int L = h->L;
+    double* Wfull = h->h_pin;
+    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * 64 * 64);
+    HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipMemcpyAsync(flagpin, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(stream_wait(h));
+    if (*flagpin) return fail(h, GPCA_ERR_NOT_CONVERGED, "CholeskyQR: a pivot of the sketch is not finite (overflow or NaN in the sketch)");
+    std::vector<double> C((size_t)l * l);
+    V.assign((size_t)l * l, 0.0); w.assign((size_t)l, 0.0);
+    for (int a = 0; a < l; ++a) for (int c = 0; c < l; ++c) C[(size_t)a * l + c] = 0.5 * (Wfull[(size_t)a * L + c] + Wfull[(size_t)c * L + a]);
+    host_eigh_desc(C, V, w, l);
+    return GPCA_OK;
+}
+
+// Initial global PCs from the row-standardised condensed features C* = W^T X (never formed): randomized PCA of C* with its
+// products factored through the genotype GEMMs -- C*^T Z = A^T (W Z), C* Q = W^T (A Q).  Leaves the N x k sample scores
+// (gpca_get_scores / _f64) and the eigenvalues of C*; loadings are not defined for this call.
+extern "C" int gpca_rsvd_condensed(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    if (!h->d_cw) return fail(h, GPCA_ERR_STATE, "gpca_rsvd_condensed: call gpca_set_condensed_basis first");
+    if (h->sm.on || multi_rank(h)) return fail(h, GPCA_ERR_STATE, "gpca_rsvd_condensed: needs a resident, unsharded matrix");
+    if ((int64_t)k + oversample > h->c_R) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd_condensed: k + oversample exceeds the number of condensed features");
+    CHK(rsvd_preflight(h, k, oversample, power_iters));
+    const int l = h->l, L = h->L, cmax = h->c_cmax;
+    const int64_t R = h->c_R, Rpad = round_up(R, 128);
+    CHK(ensure(h, h->dP, h->cap_P, (size_t)(Rpad + 64) * L));
+    CHK(ensure(h, h->d_ones, h->cap_ones, (size_t)Rpad)); CHK(ensure(h, h->d_zeros, h->cap_zeros, (size_t)Rpad));
+    CHK(ensure(h, h->d_lqr, h->cap_lqr, (size_t)h->Mpad * L));      // (f32 staging of the condensed sketch; R <= M)
+    launch_fill_f32(h->st, h->d_ones, Rpad, 1.0f); launch_fill_f32(h->st, h->d_zeros, Rpad, 0.0f);
+    HIPCHK(hipMemsetAsync(h->dP, 0, (size_t)(Rpad + 64) * L * 8, h->st));
+    // 1. sketch of C*: Omega_R (R x l, the engine's Philox stream over feature indices), Y = C*^T Omega = A^T (W Omega)
+    launch_omega(h->st, R, Rpad, l, L, 0, seed, h->d_ones, h->d_zeros, h->d_lqr, h->d_cpart, nullptr, 0);
+    HIPCHK(hipGetLastError());
+    launch_f32_to_f64(h->st, h->d_lqr, h->dP, R * (int64_t)L);
+    HIPCHK(hipGetLastError());
+    auto through_W_back = [&]() -> int {            // dT = W dP ; T' = r o dT, c ; Y = A^T T'
+        launch_bd_expand(h->st, h->d_cw, h->d_cfeat0, cmax, h->dP, h->M, L, h->dT);
+        HIPCHK(hipGetLastError());
+        CHK(prep_custom_T(h));
+        return stage_AtT_local(h);
+    };
+    auto through_W_forward = [&]() -> int {         // dT = A Q ; dP = W^T dT
+        CHK(stage_AQ(h, 0));
+        launch_bd_reduce(h->st, h->d_cw, h->d_cfeat0, cmax, h->dT, L, h->d_cblk_row0, h->d_cblk_row1, h->d_cblk_feat0, h->c_B, h->dP);
+        HIPCHK(hipGetLastError());
+        return GPCA_OK;
+    };
+    CHK(through_W_back());
+    CHK(stage_orth(h));
+    for (int it = 0; it < power_iters; ++it) { CHK(through_W_forward()); CHK(through_W_back()); CHK(stage_orth(h)); }
+    // 2. projection P = C* Q (R x l) and the l x l eigenproblem of P^T P
+    CHK(through_W_forward());
+    launch_gram_f64(h->st, h->dP, R, L, h->d_part64);
+    HIPCHK(hipGetLastError());
+    launch_sum_partials_f64(h->st, h->d_part64, gram_num_parts(R), (int64_t)L * L, h->dW, h->d_scratch64);
+    HIPCHK(hipGetLastError());
+    std::vector<double> V, w;
+    CHK(small_eigen(h, l, V, w));
+    h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
+    for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
+    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
+    double* Zpin = h->h_pin + 64 * 64;
+    const size_t zk = (size_t)L * k;
+    for (size_t e = 0; e < zk; ++e) Zpin[e] = 0.0;
+    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Zpin[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
+    HIPCHK(hipMemcpyAsync(h->dZ, Zpin, sizeof(double) * zk, hipMemcpyHostToDevice, h->st));
+    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);     // scores = Q V diag(s)
+    HIPCHK(hipGetLastError());
+    launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
+    launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
+    HIPCHK(hipGetLastError());
+    HIPCHK(stream_wait(h));
+    h->have_rsvd = true; h->loadings_valid = false;
+    return GPCA_OK;
+}
+
+// One refinement pass from given sample scores S0 (N x k, any basis of the current estimate of the PC subspace):
+//   L = orth(A S0) (SNP side, CholeskyQR2 over the M rows), S = A^T L (N x k), S^T S = W Sigma^2 W^T,
+//   scores = S W, loadings = L W, eigenvalues = Sigma^2 / (N - 1).
+// Results through the usual getters.  (compute_refined_snp_loadings / compute_rotated_final_outputs of the published algorithm.)
+extern "C" int gpca_refine(gpca_handle* h, const double* S0, int32_t k) {
+    if (!h || !S0) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    if (multi_rank(h)) return fail(h, GPCA_ERR_STATE, "gpca_refine: not available on row-sharded handles");
+    const uint8_t* saved_mask = h->d_smask;
+    if (saved_mask) return fail(h, GPCA_ERR_STATE, "gpca_refine: clear the sample mask first (refinement uses every sample)");
+    CHK(rsvd_preflight(h, k, 0, 0));
+    const int l = h->l, L = h->L;
+    CHK(ensure(h, h->d_lqr, h->cap_lqr, (size_t)h->Mpad * L));
+    // Q = orth(S0) (a basis of the same subspace; keeps the digit scales of the exact path well conditioned)
+    {
+        std::vector<double> Y((size_t)h->N * L, 0.0);
+        for (int64_t n = 0; n < h->N; ++n) for (int c = 0; c < k; ++c) Y[(size_t)n * L + c] = S0[(size_t)n * k + c];
+        HIPCHK(hipMemcpyAsync(h->dY, Y.data(), Y.size() * 8, hipMemcpyHostToDevice, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+    }
+    CHK(stage_orth(h));
+    CHK(stage_AQ(h, 0));                                  // dT = A Q   (M x L f32)
+    for (int round = 0; round < 2; ++round) {             // CholeskyQR2 over the SNP rows
+        launch_gram_f32(h->st, h->dT, h->M, L, h->d_part64);
+        HIPCHK(hipGetLastError());
+        launch_sum_partials_f64(h->st, h->d_part64, gram_num_parts(h->M), (int64_t)L * L, h->dW, h->d_scratch64);
+        HIPCHK(hipGetLastError());
+        launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
+        HIPCHK(hipGetLastError());
+        launch_rightmul_inplace_f32(h->st, h->dT, h->M, L, h->dZ);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(h->d_lqr, h->dT, (size_t)h->Mpad * L * 4, hipMemcpyDeviceToDevice, h->st));   // L, kept for the loadings
+    CHK(prep_custom_T(h));
+    CHK(stage_AtT_local(h));                              // dY = S = A^T L   (N x L f64)
+    launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
+    HIPCHK(hipGetLastError());
+    launch_sum_partials_f64(h->st, h->d_part64, gram_num_parts(h->N), (int64_t)L * L, h->dW, h->d_scratch64);
+    HIPCHK(hipGetLastError());
+    std::vector<double> V, w;
+    CHK(small_eigen(h, l, V, w));
+    h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
+    for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
+    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
+    double* Zpin = h->h_pin + 64 * 64;
+    const size_t zk = (size_t)L * k;
+    for (size_t e = 0; e < 2 * zk; ++e) Zpin[e] = 0.0;
+    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Zpin[(size_t)j * k + c] = Zpin[zk + (size_t)j * k + c] = V[(size_t)j * l + c];
+    HIPCHK(hipMemcpyAsync(h->dZ, Zpin, sizeof(double) * 2 * zk, hipMemcpyHostToDevice, h->st));
+    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);             // scores = S W
+    HIPCHK(hipGetLastError());
+    launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
+    launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
+    launch_scale_cols(h->st, h->dZ + zk, (float*)nullptr, L, k, h->d_sign);
+    HIPCHK(hipGetLastError());
+    launch_rightmul_gather_f32(h->st, h->d_lqr, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);   // loadings = L W
+    HIPCHK(hipGetLastError());
+    HIPCHK(stream_wait(h));
+    h->have_rsvd = true; h->loadings_valid = true;
+    return GPCA_OK;
+}

@@ -128,6 +128,14 @@ void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, 
                        float* Tb, float* cpart, int blocked = 1);
 
 
+// EigenSNP stages: block-diagonal condensed basis W (kernels.hip)
+void launch_bd_expand(hipStream_t st, const float* W, const int32_t* feat0, int cmax, const double* P, int64_t M, int L, float* out);
+void launch_bd_reduce(hipStream_t st, const float* W, const int32_t* feat0, int cmax, const float* T, int L, const int64_t* blk_row0,
+                      const int64_t* blk_row1, const int32_t* blk_feat0, int B, double* P);
+void launch_rightmul_inplace_f32(hipStream_t st, float* X, int64_t rows, int L, const double* Z);
+void launch_mask_rows(hipStream_t st, double* Y, int64_t N, int L, const uint8_t* mask);
+void launch_f32_to_f64(hipStream_t st, const float* in, double* out, int64_t n);
+
 // ---- exact-integer path (gemm_i8.hip), 32 columns per launch.  Every K1 here writes cpart[unit][32] = the unit's share of
 // b^T T (one partial per 32-row unit of the launch, partition-independent) and, except k_gq_i8, apart[wave][32] = column abs-max. ----------------------------------------------------------
 constexpr int kDigits = 4;   // signed base-128 digits of the skinny operand

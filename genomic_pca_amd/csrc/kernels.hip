@@ -1086,4 +1086,90 @@ void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, 
     hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, X, M, Mpad, L, r, b, Tb, cpart, blocked);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// EigenSNP stages.  The condensed feature matrix C* = Lambda^-1 U_blk^T X (one row per local eigenSNP of an
+// LD block) is never formed: W = U_blk Lambda^-1 is block diagonal -- SNP row i of block b carries the <= cmax coefficients
+// W[i][0..cmax) of the block's features [feat0[i], feat0[i] + cmax) -- so C* Q = W^T (X Q) and C*^T Z = X^T (W Z) run through the
+// genotype GEMMs with these two O(M l cmax) kernels in between.
+// ------------------------------------------------------------------------------------------------
+// out[i][j] = sum_c W[i][c] P[feat0[i] + c][j]   (rows without a block: 0)
+__global__ __launch_bounds__(256) void k_bd_expand(const float* __restrict__ W, const int32_t* __restrict__ feat0, int cmax,
+                                                   const double* __restrict__ P, int64_t M, int L, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * L) return;
+    const int64_t i = t / L;
+    const int j = (int)(t - i * L);
+    const int32_t f = feat0[i];
+    double a = 0.0;
+    if (f >= 0)
+        for (int c = 0; c < cmax; ++c) a = fma((double)W[i * cmax + c], P[(int64_t)(f + c) * L + j], a);
+    out[t] = (float)a;
+}
+void launch_bd_expand(hipStream_t st, const float* W, const int32_t* feat0, int cmax, const double* P, int64_t M, int L, float* out) {
+    hipLaunchKernelGGL(k_bd_expand, dim3((unsigned)((M * L + 255) / 256)), dim3(256), 0, st, W, feat0, cmax, P, M, L, out);
+}
+// P[bf + c][j] = sum over the rows i of block b (feat0[i] == bf, rows [row0, row1) in ascending order: one fixed summation order)
+// of W[i][c] T[i][j].  One workgroup per block; thread = (c mod 8, j mod 32).
+__global__ __launch_bounds__(256) void k_bd_reduce(const float* __restrict__ W, const int32_t* __restrict__ feat0, int cmax,
+                                                   const float* __restrict__ T, int L, const int64_t* __restrict__ blk_row0,
+                                                   const int64_t* __restrict__ blk_row1, const int32_t* __restrict__ blk_feat0,
+                                                   double* __restrict__ P) {
+    const int b = blockIdx.x;
+    const int64_t r0 = blk_row0[b], r1 = blk_row1[b];
+    const int32_t bf = blk_feat0[b];
+    const int cg = threadIdx.x >> 5, jl = threadIdx.x & 31;
+    for (int c = cg; c < cmax; c += 8)
+        for (int j = jl; j < L; j += 32) {
+            double a = 0.0;
+            for (int64_t i = r0; i < r1; ++i)
+                if (feat0[i] == bf) a = fma((double)W[i * cmax + c], (double)T[i * L + j], a);
+            P[(int64_t)(bf + c) * L + j] = a;
+        }
+}
+void launch_bd_reduce(hipStream_t st, const float* W, const int32_t* feat0, int cmax, const float* T, int L, const int64_t* blk_row0,
+                      const int64_t* blk_row1, const int32_t* blk_feat0, int B, double* P) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(k_bd_reduce, dim3((unsigned)B), dim3(256), 0, st, W, feat0, cmax, T, L, blk_row0, blk_row1, blk_feat0, P);
+}
+// X[i][:] <- X[i][:] Z   (X: rows x L f32 in place, Z: L x L f64 row-major): the triangular factor of a CholeskyQR of a tall f32 matrix
+template <int L>
+__global__ __launch_bounds__(256) void k_rightmul_inplace_f32(float* __restrict__ X, int64_t rows, const double* __restrict__ Z) {
+    __shared__ double zs[L * L];
+    for (int e = threadIdx.x; e < L * L; e += 256) zs[e] = Z[e];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    double x[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) x[k] = (double)X[i * L + k];
+    for (int j = 0; j < L; ++j) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < L; ++k) a = fma(x[k], zs[k * L + j], a);
+        X[i * L + j] = (float)a;
+    }
+}
+void launch_rightmul_inplace_f32(hipStream_t st, float* X, int64_t rows, int L, const double* Z) {
+    const dim3 grid((unsigned)((rows + 255) / 256)), blk(256);
+    if (L == 32) hipLaunchKernelGGL((k_rightmul_inplace_f32<32>), grid, blk, 0, st, X, rows, Z);
+    else hipLaunchKernelGGL((k_rightmul_inplace_f32<64>), grid, blk, 0, st, X, rows, Z);
+}
+// rows of Y (N x L f64) whose sample is outside the subset become zero
+__global__ __launch_bounds__(256) void k_mask_rows(double* __restrict__ Y, int64_t N, int L, const uint8_t* __restrict__ mask) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * L) return;
+    if (!mask[t / L]) Y[t] = 0.0;
+}
+void launch_mask_rows(hipStream_t st, double* Y, int64_t N, int L, const uint8_t* mask) {
+    hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)((N * L + 255) / 256)), dim3(256), 0, st, Y, N, L, mask);
+}
+__global__ __launch_bounds__(256) void k_f32_to_f64(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) out[t] = (double)in[t];
+}
+void launch_f32_to_f64(hipStream_t st, const float* in, double* out, int64_t n) {
+    hipLaunchKernelGGL(k_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+}
+
 }  // namespace gpca

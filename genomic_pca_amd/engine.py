@@ -113,6 +113,7 @@ class GpcaEngine:
                  digit_planes: int = 0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
+        self._device, self.precision, self.storage, self.digit_planes = device, precision, storage, digit_planes
         cfg = _lib.gpca_config(device=device, precision=precision, storage=storage, digit_planes=digit_planes)
         rc = self._lib.gpca_create(C.byref(cfg), C.byref(self._h))
         if rc != _lib.GPCA_OK:
@@ -301,6 +302,35 @@ class GpcaEngine:
         self._chk(self._lib.gpca_transform(self._h, _vp(out)))
         return out
 
+    # -- f3: the stages of EigenSNPCoreAlgorithm (gpca.h)
+    def copy_rows_from(self, src: "GpcaEngine", row0: int, rows: int):
+        """This engine receives rows [row0, row0 + rows) of src's resident matrix (device to device)."""
+        self._chk(self._lib.gpca_copy_rows(self._h, src._h, row0, rows))
+
+    def set_sample_mask(self, mask: Optional[np.ndarray]):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        if m is not None and m.shape != (self.dims()[1],):
+            raise ValueError("mask must have one entry per sample")
+        self._chk(self._lib.gpca_set_sample_mask(self._h, _vp(m)))
+
+    def set_condensed_basis(self, W: np.ndarray, feat0: np.ndarray, R: int):
+        W = np.ascontiguousarray(W, np.float32); feat0 = np.ascontiguousarray(feat0, np.int32)
+        M, _ = self.dims()
+        if W.ndim != 2 or W.shape[0] != M or feat0.shape != (M,):
+            raise ValueError("W must be [SNPs, cmax] and feat0 [SNPs]")
+        self._chk(self._lib.gpca_set_condensed_basis(self._h, _vp(W), _vp(feat0), W.shape[1], R))
+
+    def rsvd_condensed(self, k: int, oversample: int = 10, power_iters: int = 2, seed: int = 1):
+        self._chk(self._lib.gpca_rsvd_condensed(self._h, k, oversample, power_iters, seed))
+        self._k, self._l = k, k + oversample
+
+    def refine(self, scores: np.ndarray):
+        s = np.ascontiguousarray(scores, np.float64)
+        if s.ndim != 2 or s.shape[0] != self.dims()[1]:
+            raise ValueError("scores must be [samples, k]")
+        self._chk(self._lib.gpca_refine(self._h, _vp(s), s.shape[1]))
+        self._k = self._l = s.shape[1]
+
     # -- e
     @staticmethod
     def comm_unique_id() -> bytes:
@@ -467,21 +497,22 @@ class EigenSNPCoreOutput:
 class EigenSNPCoreAlgorithm:
     """``EigenSNPCoreAlgorithm::new(cfg).compute_pca(&accessor, &blocks)`` (main.rs:359-365).
 
-    Implements the GLOBAL randomized-PCA stage on the standardised matrix restricted to the SNPs the caller's
-    ``ld_blocks`` name (``LdBlockSpecification.pca_snp_ids_in_block``, prepare.rs:1540-1543): a PCA SNP that appears in
-    no block does not enter the PCA, exactly as in the reference, where ``D`` = SNPs that passed QC and fell in a block
-    (prepare.rs:1465-1469).  With the README's one genome-wide block this is the plain randomized PCA of all PCA SNPs.
+    Two ways to the same quantity (top-K PCA of the standardised matrix restricted to the SNPs the caller's ``ld_blocks`` name --
+    a PCA SNP in no block does not enter, prepare.rs:1465-1469):
 
-    Which of the 14 config fields (main.rs:311-327) act here:
-
-    * used: ``target_num_global_pcs``, ``global_pca_sketch_oversampling``, ``global_pca_num_power_iterations``, ``random_seed``;
-    * no-ops by construction: ``snp_processing_strip_size`` (the strips the reference pulls through the accessor are the
-      HBM-resident rows / streamed panels here), ``collect_diagnostics`` / ``diagnostic_block_list_id_to_trace`` (the
-      second return value is a small dict of what ran, not the crate's diagnostics struct);
-    * NOT implemented (accepted for signature parity, ignored): ``components_per_ld_block``,
-      ``subset_factor_/min_/max_subset_size_for_local_basis_learning``, ``local_rsvd_*`` and ``refine_pass_count`` --
-      they parameterise the per-LD-block local basis stage and the refinement passes, which are defined only in the
-      un-vendored ``efficient_pca`` crate.
+    * ``local_stage=False`` (default): ONE global randomized PCA over the union of the blocks -- what the GPU does best (6 passes
+      over the genotypes, every power iteration on the full matrix) and the more accurate of the two.  Acting config fields:
+      ``target_num_global_pcs``, ``global_pca_sketch_oversampling``, ``global_pca_num_power_iterations``, ``random_seed``.
+    * ``local_stage=True``: the multi-stage algorithm the 14 config fields (main.rs:311-327) parameterise, as published for the
+      un-vendored ``efficient_pca`` crate (Cargo.toml:30, no pinned revision -- parity UNPINNED):
+        1. a sample subset of ``clamp(subset_factor * N, min_subset, max_subset)`` samples (seeded);
+        2. per LD block, a local randomized PCA on the subset's columns -> ``components_per_ld_block`` local eigenSNP loadings
+           (``local_rsvd_sketch_oversampling`` / ``local_rsvd_num_power_iterations``);
+        3. every sample projected on the local bases -> condensed features, row-standardised;
+        4. an initial global randomized PCA of the condensed features (``global_pca_*``) -> sample scores;
+        5. ``refine_pass_count`` refinement passes on the full matrix: loadings = orth(X scores), scores = X^T loadings, small SVD.
+      Every pass over genotypes runs on the device (gpca.h section f3); the host only assembles the block-diagonal basis.
+      ``snp_processing_strip_size`` stays a no-op (HBM-resident rows); ``collect_diagnostics`` returns a small dict of what ran.
     """
 
     def __init__(self, config: EigenSNPCoreAlgorithmConfig):
@@ -498,29 +529,108 @@ class EigenSNPCoreAlgorithm:
             raise ValueError(f"compute_pca: PcaSnpId {int(ids[0] if ids[0] < 0 else ids[-1])} out of range [0, {n_pca})")
         return ids
 
-    def compute_pca(self, accessor: MicroarrayGenotypeAccessor, ld_blocks: Sequence[LdBlockSpecification]):
+    def compute_pca(self, accessor: MicroarrayGenotypeAccessor, ld_blocks: Sequence[LdBlockSpecification], local_stage: bool = False):
         eng = accessor.engine
         cfg = self.config
         n_pca = accessor.num_pca_snps()
         ids = self._union_of_blocks(ld_blocks, n_pca)
         restore = None
-        if ids.size < n_pca:
+        if ids.size < n_pca or local_stage:
             # SNPs outside every block leave the PCA: keep mask = union of the blocks (same mu/sigma); the accessor's
             # own PCA-SNP numbering is restored afterwards, as the reference never mutates its accessor
             st = eng.get_standardization()
             rows = eng.pca_snp_rows()
             keep2 = np.zeros_like(st["keep"])
             keep2[rows[ids]] = 1
-            eng.set_standardization(st["mu"], st["sigma"], keep2)
-            restore = st
+            if ids.size < n_pca:
+                eng.set_standardization(st["mu"], st["sigma"], keep2)
+                restore = st
+        diag = None
         try:
-            eng.rsvd(cfg.target_num_global_pcs, cfg.global_pca_sketch_oversampling, cfg.global_pca_num_power_iterations,
-                     cfg.random_seed)
+            if local_stage:
+                diag = self._multi_stage(eng, ld_blocks, st, rows)
+            else:
+                eng.rsvd(cfg.target_num_global_pcs, cfg.global_pca_sketch_oversampling, cfg.global_pca_num_power_iterations,
+                         cfg.random_seed)
             out = EigenSNPCoreOutput(eng.scores(), eng.eigenvalues(), eng.loadings(), accessor.num_qc_samples(),
                                      int(ids.size), cfg.target_num_global_pcs)
         finally:
             if restore is not None:
                 eng.set_standardization(restore["mu"], restore["sigma"], restore["keep"])
-        diag = dict(stage="global", num_ld_blocks=len(ld_blocks), num_pca_snps_in_blocks=int(ids.size),
-                    pca_snp_ids_used=ids) if cfg.collect_diagnostics else None
+        if cfg.collect_diagnostics:
+            diag = dict(diag or {}, stage="multi-stage" if local_stage else "global", num_ld_blocks=len(ld_blocks),
+                        num_pca_snps_in_blocks=int(ids.size), pca_snp_ids_used=ids)
+        else:
+            diag = None
         return out, diag
+
+    # ---- the multi-stage algorithm ---------------------------------------------------------------------------------
+    @staticmethod
+    def subset_size(cfg: EigenSNPCoreAlgorithmConfig, n_samples: int) -> int:
+        want = int(round(cfg.subset_factor_for_local_basis_learning * n_samples))
+        want = max(cfg.min_subset_size_for_local_basis_learning, min(cfg.max_subset_size_for_local_basis_learning, want))
+        return max(2, min(n_samples, want))
+
+    @staticmethod
+    def subset_mask(cfg: EigenSNPCoreAlgorithmConfig, n_samples: int) -> Optional[np.ndarray]:
+        """Seeded sample subset for the local bases (None = every sample).  numpy's PCG64 stands in for the crate's ChaCha: which
+        samples are drawn cannot match the reference, only how many."""
+        ns = EigenSNPCoreAlgorithm.subset_size(cfg, n_samples)
+        if ns >= n_samples:
+            return None
+        pick = np.random.default_rng(cfg.random_seed).choice(n_samples, size=ns, replace=False)
+        mask = np.zeros(n_samples, np.uint8); mask[pick] = 1
+        return mask
+
+    def _multi_stage(self, eng: "GpcaEngine", ld_blocks, st, pca_rows):
+        cfg = self.config
+        M, N = eng.dims()
+        K = cfg.target_num_global_pcs
+        mask = self.subset_mask(cfg, N)
+        n_sub = N if mask is None else int(mask.sum())
+        blocks = [(b.user_defined_block_tag, np.sort(pca_rows[np.asarray(b.pca_snp_ids_in_block, np.int64)])) for b in ld_blocks
+                  if len(b.pca_snp_ids_in_block)]
+        cp = max(1, cfg.components_per_ld_block)
+        # stages 1-3: local bases on the subset, all samples projected, feature standard deviations
+        cmax = min(cp, max(len(r) for _, r in blocks), n_sub)
+        W = np.zeros((M, cmax), np.float32)
+        feat0 = np.full(M, -1, np.int32)
+        R = 0
+        kw = dict(device=eng._device, precision=eng.precision, storage=eng.storage, digit_planes=eng.digit_planes)
+        with GpcaEngine(**kw) as sub:
+            for bi, (_, rows) in enumerate(blocks):
+                r0, r1 = int(rows[0]), int(rows[-1]) + 1
+                sub.copy_rows_from(eng, r0, r1 - r0)
+                keep = np.zeros(r1 - r0, np.uint8); keep[rows - r0] = 1
+                sub.set_standardization(st["mu"][r0:r1], st["sigma"][r0:r1], keep)
+                sub.set_sample_mask(mask)
+                c = min(cp, len(rows), n_sub)
+                lo = max(0, min(cfg.local_rsvd_sketch_oversampling, min(len(rows), n_sub) - c))
+                sub.rsvd(c, lo, cfg.local_rsvd_num_power_iterations, cfg.random_seed + 1 + bi)
+                U = sub.loadings()                                   # [block SNPs, c], orthonormal columns
+                feats = sub.transform()                              # [N, c]: every sample on the local basis
+                sd = feats.std(axis=0, ddof=1)
+                ok = sd > 1e-12
+                U = U[:, ok] / sd[ok].astype(np.float32)
+                c = U.shape[1]
+                if c == 0:
+                    continue
+                W[rows, :c] = U
+                feat0[rows] = R
+                R += c
+        if R < 1:
+            raise ValueError("compute_pca: no condensed features (every local component is constant)")
+        # stage 4: initial global PCs from the condensed features (never formed on the host)
+        eng.set_sample_mask(None)
+        eng.set_condensed_basis(W, feat0, R)
+        k0 = min(K, R)
+        go = max(0, min(cfg.global_pca_sketch_oversampling, min(R, N) - k0))
+        eng.rsvd_condensed(k0, go, cfg.global_pca_num_power_iterations, cfg.random_seed)
+        scores = eng.scores(f64=True)
+        # stage 5: refinement on the full matrix
+        for _ in range(max(1, cfg.refine_pass_count)):
+            eng.refine(scores)
+            scores = eng.scores(f64=True)
+        return dict(num_condensed_features=R, subset_size=n_sub, refine_passes=max(1, cfg.refine_pass_count))
+
+

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GPCA_VERSION 210 /* 0.2.1: + gpca_stream_set_cache, gpca_get_device_memory */
+#define GPCA_VERSION 220 /* 0.2.2: + gpca_stream_set_cache, gpca_get_device_memory, the EigenSNP stage calls */
 #define GPCA_MISSING_I8 (-127) /* bed_reader i8 missing code, prepare.rs:1224 */
 
 typedef struct gpca_handle gpca_handle;
@@ -210,6 +210,30 @@ GPCA_API int gpca_get_singular_values(gpca_handle* h, double* out /* [k+oversamp
 GPCA_API int gpca_get_loadings(gpca_handle* h, float* out /* [num_pca_snps][k] */); /* main.rs:407 */
 /* PCA::transform (main.rs:659) on the resident matrix: scores = A^T * loadings, f64 [N][k]. */
 GPCA_API int gpca_transform(gpca_handle* h, double* out);
+
+/* ---- f3: the stages of EigenSNPCoreAlgorithm::compute_pca (main.rs:311-327, 359-366) ------------------------------------------
+ * The algorithm lives in the un-vendored efficient_pca crate (Cargo.toml:30, branch "main", no pinned revision): what follows is
+ * the stage structure of its published description -- per-LD-block local bases learnt on a sample subset, condensed features of
+ * all samples, row standardisation, an initial global randomized PCA of the condensed features, refinement passes on the full
+ * matrix -- with every pass over the genotypes on the device.  Parity with the crate is UNPINNED (no source, no golden vectors);
+ * the host mirror (EigenSNPCoreAlgorithm.compute_pca, local_stage = True) drives these calls and is checked against a numpy
+ * restatement of the same stages and against exact PCA.
+ *
+ * gpca_copy_rows: dst (same device and storage mode) receives rows [row0, row0 + rows) of src's RESIDENT matrix, device to device:
+ *   an LD block as a matrix of its own (follow with gpca_set_standardization on dst).
+ * gpca_set_sample_mask: mask[n] != 0 = sample n takes part in learning the basis; gpca_rsvd then learns scores / loadings from
+ *   those columns only, gpca_transform still projects every sample.  NULL clears.
+ * gpca_set_condensed_basis: W[i][0..cmax) = SNP row i's coefficients (local loading / feature s.d.) on the condensed features
+ *   [feat0[i], feat0[i] + cmax) of its block, zero-padded; feat0[i] < 0 = in no block; R = number of condensed features.
+ * gpca_rsvd_condensed: randomized PCA of the row-standardised condensed feature matrix C* = W^T A (R x N, never formed: its
+ *   products run through the genotype GEMMs).  Leaves N x k sample scores and C*'s eigenvalues; no loadings.
+ * gpca_refine: one refinement pass from sample scores S0 [N][k]: L = orth(A S0), S = A^T L, S^T S = W Sigma^2 W^T;
+ *   scores = S W, loadings = L W, eigenvalues = Sigma^2 / (N - 1), through the usual getters. */
+GPCA_API int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, int64_t rows);
+GPCA_API int gpca_set_sample_mask(gpca_handle* h, const uint8_t* mask /* [N] or NULL */);
+GPCA_API int gpca_set_condensed_basis(gpca_handle* h, const float* W /* [M][cmax] */, const int32_t* feat0 /* [M] */, int32_t cmax, int64_t R);
+GPCA_API int gpca_rsvd_condensed(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed);
+GPCA_API int gpca_refine(gpca_handle* h, const double* S0 /* [N][k] */, int32_t k);
 
 /* ---- e: SNP-row sharding across GPUs ------------------------------------------------------- */
 #define GPCA_UNIQUE_ID_BYTES 128

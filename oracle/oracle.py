@@ -231,6 +231,64 @@ def rsvd(G, N, r, b, k, oversample=10, power_iters=2, seed=1, snp_offset=0, real
     return dict(scores=scores * sgn, eigenvalues=s[:k] ** 2 / (N - 1), loadings=U[:, :k] * sgn, singular_values=s)
 
 
+# ----------------------------------------------------------------------------- f3: the EigenSNP stages (checker of gpca.h section f3)
+def _sign_by_scores(scores):
+    k = scores.shape[1]
+    sgn = np.sign(scores[np.abs(scores).argmax(axis=0), np.arange(k)]); sgn[sgn == 0] = 1
+    return sgn
+
+
+def eigensnp_local_basis(A_rows, mask, c, oversample, power_iters, seed):
+    """Local eigenSNP basis of one LD block: randomized PCA of the block's standardised rows (A_rows: D x N f64, zero rows for
+    SNPs of the row range that are not in the block) learnt on the subset's columns (mask, or None), with the engine's Philox
+    sketch over the rows of the range.  Returns (U [D, c] orthonormal, feats [N, c] = A^T U for ALL samples)."""
+    D, N = A_rows.shape
+    l = c + oversample
+    m = np.ones(N, bool) if mask is None else np.asarray(mask).astype(bool)
+
+    def masked(Y):
+        Y = Y.copy(); Y[~m] = 0.0
+        return Y
+    Q, _ = np.linalg.qr(masked(A_rows.T @ omega(D, l, seed)))
+    for _ in range(power_iters):
+        Q, _ = np.linalg.qr(masked(A_rows.T @ (A_rows @ Q)))
+    B = A_rows @ Q
+    U, s, Wt = np.linalg.svd(B, full_matrices=False)
+    sgn = _sign_by_scores((Q @ Wt.T[:, :c]) * s[:c])
+    U = U[:, :c] * sgn
+    return U, A_rows.T @ U
+
+
+def eigensnp_global_and_refine(A, Wd, k, oversample, power_iters, seed, refine_passes=1):
+    """Stages 4-5 on the dense standardised matrix A (M x N f64) with the block-diagonal condensed basis Wd (M x R, dense here):
+    randomized PCA of C* = Wd^T A (sketch over the R features with the engine's Philox stream), then refinement passes
+    L = orth(A S), S = A^T L, S^T S = V w V^T -> scores S V, loadings L V, eigenvalues w / (N - 1)."""
+    C = Wd.T @ A
+    R, N = C.shape
+    l = k + oversample
+    Q, _ = np.linalg.qr(C.T @ omega(R, l, seed))
+    for _ in range(power_iters):
+        Q, _ = np.linalg.qr(C.T @ (C @ Q))
+    P = C @ Q
+    w, V = np.linalg.eigh(P.T @ P)
+    w = w[::-1]; V = V[:, ::-1]
+    s0 = (Q @ V[:, :k]) * np.sqrt(np.maximum(w[:k], 0))
+    s0 = s0 * _sign_by_scores(s0)
+    scores = s0
+    out = None
+    for _ in range(max(1, refine_passes)):
+        Q0, _ = np.linalg.qr(scores)
+        Lq, _ = np.linalg.qr(A @ Q0)
+        S = A.T @ Lq
+        w2, V2 = np.linalg.eigh(S.T @ S)
+        w2 = w2[::-1]; V2 = V2[:, ::-1]
+        scores = S @ V2
+        sgn = _sign_by_scores(scores)
+        scores = scores * sgn
+        out = dict(scores=scores, loadings=(Lq @ V2) * sgn, eigenvalues=w2 / (N - 1), initial_scores=s0)
+    return out
+
+
 def standardized_dense(G, N, r, b) -> np.ndarray:
     """A[i, n] = g * r_i + b_i in f64 from the f32 r, b (M x N dense; small cases only)."""
     return np.asarray(G[:, :N], np.float64) * np.asarray(r, np.float64)[:, None] + np.asarray(b, np.float64)[:, None]
