@@ -8,7 +8,8 @@ Two workflows, dispatched on --eigensnp like main.rs:109-122:
         -> P.eigensnp.pca.tsv, P.eigenvalues.tsv, P.eigensnp.loadings.tsv
 EigenSNP's per-LD-block local stage is defined only in the un-vendored efficient_pca crate; this CLI runs the global
 randomized PCA over all SNPs that pass QC and fall in an LD block (identical to the reference's own README usage of a
-single genome-wide block).  The local-stage flags are accepted and ignored.
+single genome-wide block) by default; --gpca-eigensnp-local-stage runs the multi-stage algorithm the local-stage / refine
+flags parameterise, as published for that crate (parity unpinned).
 """
 from __future__ import annotations
 
@@ -64,6 +65,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help="EigenSNP workflow: walk the .bed out of core through a ring of HBM panels instead of holding it resident "
                         "(auto = when the resident load runs out of device memory; needs --gpca-precision i8)")
     p.add_argument("--gpca-panel-rows", type=int, default=0, help="--gpca-stream: SNP rows per panel (0 = engine default)")
+    p.add_argument("--gpca-eigensnp-local-stage", action="store_true",
+                   help="EigenSNP workflow: run the multi-stage algorithm the --eigensnp-* local / refine flags parameterise (per-block "
+                        "local bases on a sample subset, condensed features, global PCA, refinement) instead of one global randomized "
+                        "PCA over all blocks (the default: fewer passes, more accurate); needs a resident matrix")
     return p
 
 
@@ -196,7 +201,7 @@ def run_eigensnp_workflow(a) -> int:
     k = min(cfg.target_num_global_pcs, len(sample_ids), len(rows))
     cfg.target_num_global_pcs = k
     cfg.global_pca_sketch_oversampling = max(0, min(cfg.global_pca_sketch_oversampling, min(len(sample_ids), len(rows)) - k))
-    out, _ = EigenSNPCoreAlgorithm(cfg).compute_pca(acc, specs)
+    out, _ = EigenSNPCoreAlgorithm(cfg).compute_pca(acc, specs, local_stage=a.gpca_eigensnp_local_stage)
     _ensure_parent(a.output_prefix)
     gio.write_principal_components(a.output_prefix, "eigensnp.pca.tsv", sample_ids, out.final_sample_principal_component_scores)
     gio.write_eigenvalues(a.output_prefix, out.final_principal_component_eigenvalues)

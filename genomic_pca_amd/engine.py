@@ -573,13 +573,24 @@ class EigenSNPCoreAlgorithm:
 
     @staticmethod
     def subset_mask(cfg: EigenSNPCoreAlgorithmConfig, n_samples: int) -> Optional[np.ndarray]:
-        """Seeded sample subset for the local bases (None = every sample).  numpy's PCG64 stands in for the crate's ChaCha: which
-        samples are drawn cannot match the reference, only how many."""
+        """Seeded sample subset for the local bases (None = every sample): the first ns entries of a Fisher-Yates shuffle driven
+        by SplitMix64(seed) -- defined here rather than taken from a library generator so that the C++ host (gpca.hpp) draws the
+        same samples.  The crate uses ChaCha: WHICH samples are drawn cannot match the reference, only how many."""
         ns = EigenSNPCoreAlgorithm.subset_size(cfg, n_samples)
         if ns >= n_samples:
             return None
-        pick = np.random.default_rng(cfg.random_seed).choice(n_samples, size=ns, replace=False)
-        mask = np.zeros(n_samples, np.uint8); mask[pick] = 1
+        m64 = (1 << 64) - 1
+        state = cfg.random_seed & m64
+        idx = list(range(n_samples))
+        for i in range(ns):
+            state = (state + 0x9E3779B97F4A7C15) & m64
+            z = state
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
+            z ^= z >> 31
+            j = i + z % (n_samples - i)
+            idx[i], idx[j] = idx[j], idx[i]
+        mask = np.zeros(n_samples, np.uint8); mask[idx[:ns]] = 1
         return mask
 
     def _multi_stage(self, eng: "GpcaEngine", ld_blocks, st, pca_rows):

@@ -39,6 +39,7 @@ struct Args {
     int device = -1;
     std::string precision = "i8", storage = "int8", stream = "auto";
     int64_t panel_rows = 0;
+    bool local_stage = false;
 };
 
 [[noreturn]] void usage_error(const std::string& msg) {
@@ -86,6 +87,8 @@ void print_help() {
         "      --gpca-storage <int8|2bit>       HBM residency of the genotypes\n"
         "      --gpca-stream <auto|on|off>      walk the .bed out of core (auto = when it does not fit the device)\n"
         "      --gpca-panel-rows <N>            SNP rows per panel for --gpca-stream (0 = engine default)\n"
+        "      --gpca-eigensnp-local-stage      run the multi-stage algorithm of the --eigensnp-* local / refine flags instead of\n"
+        "                                       one global randomized PCA over all blocks (the default)\n"
         "  -h, --help                           Print help");
 }
 
@@ -147,6 +150,7 @@ Args parse(int argc, char** argv) {
         else if (f == "--gpca-storage") { a.storage = val(); if (a.storage != "int8" && a.storage != "2bit") usage_error("invalid value '" + a.storage + "' for '--gpca-storage' (int8, 2bit)"); }
         else if (f == "--gpca-stream") { a.stream = val(); if (a.stream != "auto" && a.stream != "on" && a.stream != "off") usage_error("invalid value '" + a.stream + "' for '--gpca-stream' (auto, on, off)"); }
         else if (f == "--gpca-panel-rows") a.panel_rows = to_i64(f, val());
+        else if (f == "--gpca-eigensnp-local-stage") a.local_stage = true;
         else usage_error("unexpected argument '" + f + "' found");
     }
     if (a.output_prefix.empty()) usage_error("the following required arguments were not provided:\n  --out <OUTPUT_PREFIX>");
@@ -313,7 +317,7 @@ int run_eigensnp_workflow(const Args& a) {
     cfg.local_rsvd_sketch_oversampling = (int)a.local_oversampling; cfg.local_rsvd_num_power_iterations = (int)a.local_power_iter;
     cfg.random_seed = a.seed; cfg.snp_processing_strip_size = a.strip_size; cfg.refine_pass_count = (int)a.refine_passes;
     cfg.collect_diagnostics = a.collect_diagnostics;
-    const gpca::EigenSNPCoreOutput out = gpca::EigenSNPCoreAlgorithm(cfg).compute_pca(acc, specs);
+    const gpca::EigenSNPCoreOutput out = gpca::EigenSNPCoreAlgorithm(cfg).compute_pca(acc, specs, a.local_stage);
     gpca_host::ensure_parent(a.output_prefix);
     gpca_host::write_principal_components(a.output_prefix, "eigensnp.pca.tsv", sample_ids, out.final_sample_principal_component_scores.data(),
                                           out.num_qc_samples_used, (int)k);

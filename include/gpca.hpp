@@ -17,6 +17,7 @@
 #define GPCA_HPP
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -50,7 +51,8 @@ struct SnpStats { std::vector<float> mu, sigma; std::vector<uint8_t> keep; };
 /* One opaque gpca_handle: one GPU, one SNP-row shard of the genotype matrix. */
 class Engine {
 public:
-    explicit Engine(int device = -1, int precision = GPCA_PREC_I8_EXACT, int storage = GPCA_STORE_INT8, int digit_planes = 0) {
+    explicit Engine(int device = -1, int precision = GPCA_PREC_I8_EXACT, int storage = GPCA_STORE_INT8, int digit_planes = 0)
+        : device_(device), precision_(precision), storage_(storage), digit_planes_(digit_planes) {
         gpca_config cfg{};
         cfg.device = device; cfg.precision = precision; cfg.storage = storage; cfg.digit_planes = digit_planes;
         const int rc = gpca_create(&cfg, &h_);
@@ -59,7 +61,7 @@ public:
     ~Engine() { if (h_) gpca_destroy(h_); }
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;
-    Engine(Engine&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    Engine(Engine&& o) noexcept : h_(o.h_), k_(o.k_), device_(o.device_), precision_(o.precision_), storage_(o.storage_), digit_planes_(o.digit_planes_) { o.h_ = nullptr; }
 
     gpca_handle* handle() const { return h_; }
     void check(int rc) const { if (rc != GPCA_OK) throw Error(rc, gpca_last_error(h_)); }
@@ -114,6 +116,27 @@ public:
         return out;
     }
 
+    /* f3: the stages of EigenSNPCoreAlgorithm (gpca.h) */
+    int device() const { return device_; }
+    int precision() const { return precision_; }
+    int storage() const { return storage_; }
+    int digit_planes() const { return digit_planes_; }
+    void copy_rows_from(const Engine& src, int64_t row0, int64_t rows) { check(gpca_copy_rows(h_, src.h_, row0, rows)); }
+    void set_sample_mask(const std::vector<uint8_t>* mask) {
+        if (mask && (int64_t)mask->size() != dims().second) throw std::invalid_argument("set_sample_mask: one entry per sample");
+        check(gpca_set_sample_mask(h_, mask ? mask->data() : nullptr));
+    }
+    void set_condensed_basis(const std::vector<float>& W, const std::vector<int32_t>& feat0, int cmax, int64_t R) {
+        const size_t M = (size_t)dims().first;
+        if (feat0.size() != M || W.size() != M * (size_t)cmax) throw std::invalid_argument("set_condensed_basis: W is [SNPs][cmax], feat0 [SNPs]");
+        check(gpca_set_condensed_basis(h_, W.data(), feat0.data(), cmax, R));
+    }
+    void rsvd_condensed(int k, int oversample, int power_iters, uint64_t seed) { check(gpca_rsvd_condensed(h_, k, oversample, power_iters, seed)); k_ = k; }
+    void refine(const std::vector<double>& scores, int k) {
+        if ((int64_t)scores.size() != dims().second * (int64_t)k) throw std::invalid_argument("refine: scores are [samples][k]");
+        check(gpca_refine(h_, scores.data(), k)); k_ = k;
+    }
+
     /* a5/a6 */
     void rsvd(int k, int oversample, int power_iters, uint64_t seed) { check(gpca_rsvd(h_, k, oversample, power_iters, seed)); k_ = k; }
     int components() const { return k_; }
@@ -126,6 +149,7 @@ public:
 private:
     gpca_handle* h_ = nullptr;
     int k_ = 0;
+    int device_ = -1, precision_ = GPCA_PREC_I8_EXACT, storage_ = GPCA_STORE_INT8, digit_planes_ = 0;
 };
 
 struct LdBlockSpecification {                       // prepare.rs:1540-1543
@@ -176,14 +200,46 @@ struct EigenSNPCoreOutput {
     int num_principal_components_computed = 0;
 };
 
-/* EigenSNPCoreAlgorithm::new(cfg).compute_pca(&accessor, &blocks) (main.rs:359-365): the GLOBAL randomized PCA of the
- * standardised matrix restricted to the SNPs the blocks name (a PCA SNP in no block leaves the PCA, prepare.rs:1465-1469).
- * Acting fields: target_num_global_pcs, global_pca_sketch_oversampling, global_pca_num_power_iterations, random_seed; the
- * local-stage / refinement fields are accepted and ignored (defined only in the un-vendored efficient_pca crate). */
+/* EigenSNPCoreAlgorithm::new(cfg).compute_pca(&accessor, &blocks) (main.rs:359-365): top-K PCA of the standardised matrix
+ * restricted to the SNPs the blocks name (a PCA SNP in no block leaves the PCA, prepare.rs:1465-1469).
+ *   local_stage = false (default): ONE global randomized PCA over the union of the blocks (target_num_global_pcs,
+ *     global_pca_sketch_oversampling, global_pca_num_power_iterations, random_seed act).
+ *   local_stage = true: the multi-stage algorithm the 14 config fields parameterise, as published for the un-vendored
+ *     efficient_pca crate (parity UNPINNED): sample subset -> per-block local bases -> condensed features of all samples, row
+ *     standardised -> initial global randomized PCA of the condensed features -> refine_pass_count refinement passes on the full
+ *     matrix.  Same stages, same calls, same seeds as genomic_pca_amd.engine.EigenSNPCoreAlgorithm._multi_stage. */
 class EigenSNPCoreAlgorithm {
 public:
     explicit EigenSNPCoreAlgorithm(const EigenSNPCoreAlgorithmConfig& cfg) : cfg_(cfg) {}
-    EigenSNPCoreOutput compute_pca(const MicroarrayGenotypeAccessor& accessor, const std::vector<LdBlockSpecification>& ld_blocks) const {
+
+    static int64_t subset_size(const EigenSNPCoreAlgorithmConfig& cfg, int64_t n_samples) {
+        int64_t want = (int64_t)std::nearbyint(cfg.subset_factor_for_local_basis_learning * (double)n_samples);
+        want = std::max(cfg.min_subset_size_for_local_basis_learning, std::min(cfg.max_subset_size_for_local_basis_learning, want));
+        return std::max<int64_t>(2, std::min(n_samples, want));
+    }
+    /* the first ns entries of a Fisher-Yates shuffle driven by SplitMix64(seed); empty = every sample */
+    static std::vector<uint8_t> subset_mask(const EigenSNPCoreAlgorithmConfig& cfg, int64_t n_samples) {
+        const int64_t ns = subset_size(cfg, n_samples);
+        if (ns >= n_samples) return {};
+        std::vector<int64_t> idx((size_t)n_samples);
+        for (int64_t i = 0; i < n_samples; ++i) idx[(size_t)i] = i;
+        uint64_t state = cfg.random_seed;
+        for (int64_t i = 0; i < ns; ++i) {
+            state += 0x9E3779B97F4A7C15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            const int64_t j = i + (int64_t)(z % (uint64_t)(n_samples - i));
+            std::swap(idx[(size_t)i], idx[(size_t)j]);
+        }
+        std::vector<uint8_t> mask((size_t)n_samples, 0);
+        for (int64_t i = 0; i < ns; ++i) mask[(size_t)idx[(size_t)i]] = 1;
+        return mask;
+    }
+
+    EigenSNPCoreOutput compute_pca(const MicroarrayGenotypeAccessor& accessor, const std::vector<LdBlockSpecification>& ld_blocks,
+                                   bool local_stage = false) const {
         Engine& eng = accessor.engine();
         const int64_t n_pca = accessor.num_pca_snps();
         if (ld_blocks.empty()) throw std::invalid_argument("compute_pca: ld_block_specifications is empty");
@@ -196,17 +252,18 @@ public:
             throw std::invalid_argument("compute_pca: PcaSnpId " + std::to_string(ids.front() < 0 ? ids.front() : ids.back()) + " out of range [0, " +
                                         std::to_string(n_pca) + ")");
         SnpStats saved;
+        std::vector<int64_t> rows;
         const bool restrict_rows = (int64_t)ids.size() < n_pca;
+        if (restrict_rows || local_stage) { saved = eng.get_standardization(); rows = eng.pca_snp_rows(); }
         if (restrict_rows) {   // keep mask = union of the blocks (same mu / sigma); the accessor's numbering is restored afterwards
-            saved = eng.get_standardization();
-            const std::vector<int64_t> rows = eng.pca_snp_rows();
             std::vector<uint8_t> keep2(saved.keep.size(), 0);
             for (PcaSnpId id : ids) keep2[(size_t)rows[(size_t)id]] = 1;
             eng.set_standardization(saved.mu, saved.sigma, keep2);
         }
         EigenSNPCoreOutput out;
         try {
-            eng.rsvd(cfg_.target_num_global_pcs, cfg_.global_pca_sketch_oversampling, cfg_.global_pca_num_power_iterations, cfg_.random_seed);
+            if (local_stage) multi_stage(eng, ld_blocks, saved, rows);
+            else eng.rsvd(cfg_.target_num_global_pcs, cfg_.global_pca_sketch_oversampling, cfg_.global_pca_num_power_iterations, cfg_.random_seed);
             out.final_sample_principal_component_scores = eng.scores();
             out.final_principal_component_eigenvalues = eng.eigenvalues();
             out.final_snp_principal_component_loadings = eng.loadings();
@@ -220,7 +277,73 @@ public:
         if (restrict_rows) eng.set_standardization(saved.mu, saved.sigma, saved.keep);
         return out;
     }
+
 private:
+    void multi_stage(Engine& eng, const std::vector<LdBlockSpecification>& ld_blocks, const SnpStats& st, const std::vector<int64_t>& pca_rows) const {
+        const auto dm = eng.dims();
+        const int64_t M = dm.first, N = dm.second;
+        const int K = cfg_.target_num_global_pcs;
+        const std::vector<uint8_t> mask = subset_mask(cfg_, N);
+        int64_t n_sub = N;
+        if (!mask.empty()) { n_sub = 0; for (uint8_t m : mask) n_sub += m; }
+        std::vector<std::vector<int64_t>> blocks;
+        int64_t longest = 0;
+        for (const auto& b : ld_blocks) {
+            if (b.pca_snp_ids_in_block.empty()) continue;
+            std::vector<int64_t> r;
+            for (PcaSnpId id : b.pca_snp_ids_in_block) r.push_back(pca_rows[(size_t)id]);
+            std::sort(r.begin(), r.end());
+            longest = std::max<int64_t>(longest, (int64_t)r.size());
+            blocks.push_back(std::move(r));
+        }
+        const int64_t cp = std::max(1, cfg_.components_per_ld_block);
+        const int cmax = (int)std::min<int64_t>({cp, longest, n_sub});
+        std::vector<float> W((size_t)M * (size_t)cmax, 0.f);
+        std::vector<int32_t> feat0((size_t)M, -1);
+        int64_t R = 0;
+        {
+            Engine sub(eng.device(), eng.precision(), eng.storage(), eng.digit_planes());
+            for (size_t bi = 0; bi < blocks.size(); ++bi) {
+                const std::vector<int64_t>& rows = blocks[bi];
+                const int64_t r0 = rows.front(), r1 = rows.back() + 1, D = (int64_t)rows.size();
+                sub.copy_rows_from(eng, r0, r1 - r0);
+                std::vector<uint8_t> keep((size_t)(r1 - r0), 0);
+                for (int64_t r : rows) keep[(size_t)(r - r0)] = 1;
+                sub.set_standardization(std::vector<float>(st.mu.begin() + r0, st.mu.begin() + r1), std::vector<float>(st.sigma.begin() + r0, st.sigma.begin() + r1), keep);
+                sub.set_sample_mask(mask.empty() ? nullptr : &mask);
+                int c = (int)std::min<int64_t>({cp, D, n_sub});
+                const int lo = (int)std::max<int64_t>(0, std::min<int64_t>(cfg_.local_rsvd_sketch_oversampling, std::min(D, n_sub) - c));
+                sub.rsvd(c, lo, cfg_.local_rsvd_num_power_iterations, cfg_.random_seed + 1 + (uint64_t)bi);
+                const std::vector<float> U = sub.loadings();          // [D][c]
+                const std::vector<double> feats = sub.transform();    // [N][c]
+                int kept_cols = 0;
+                for (int j = 0; j < c; ++j) {
+                    double mean = 0.0;
+                    for (int64_t n = 0; n < N; ++n) mean += feats[(size_t)n * c + j];
+                    mean /= (double)N;
+                    double ss = 0.0;
+                    for (int64_t n = 0; n < N; ++n) { const double d = feats[(size_t)n * c + j] - mean; ss += d * d; }
+                    const double sd = std::sqrt(ss / (double)(N - 1));
+                    if (!(sd > 1e-12)) continue;
+                    const float sdf = (float)sd;
+                    for (int64_t a = 0; a < D; ++a) W[(size_t)rows[(size_t)a] * cmax + kept_cols] = U[(size_t)a * c + j] / sdf;
+                    ++kept_cols;
+                }
+                if (kept_cols == 0) continue;
+                for (int64_t r : rows) feat0[(size_t)r] = (int32_t)R;
+                R += kept_cols;
+            }
+        }
+        if (R < 1) throw std::invalid_argument("compute_pca: no condensed features (every local component is constant)");
+        eng.set_sample_mask(nullptr);
+        eng.set_condensed_basis(W, feat0, cmax, R);
+        const int k0 = (int)std::min<int64_t>(K, R);
+        const int go = (int)std::max<int64_t>(0, std::min<int64_t>(cfg_.global_pca_sketch_oversampling, std::min(R, N) - k0));
+        eng.rsvd_condensed(k0, go, cfg_.global_pca_num_power_iterations, cfg_.random_seed);
+        std::vector<double> scores = eng.scores_f64();
+        for (int pass = 0; pass < std::max(1, cfg_.refine_pass_count); ++pass) { eng.refine(scores, k0); scores = eng.scores_f64(); }
+    }
+
     EigenSNPCoreAlgorithmConfig cfg_;
 };
 

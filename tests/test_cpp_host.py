@@ -225,6 +225,37 @@ def test_both_clis_go_out_of_core_when_the_device_is_too_small(tmp_path, host_bi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("subset", [False, True])
+def test_both_clis_multi_stage_eigensnp(tmp_path, host_bin, subset):
+    """--gpca-eigensnp-local-stage through both command lines on the reference's chr22_subset50 genotypes with 9 LD blocks (the
+    --eigensnp-* local / refine flags acting): the same stages, seeds and -- with a sample subset -- the same drawn samples in
+    the C++ and the Python host, so the files agree to the TSV rounding; and they sit close to the one-stage default."""
+    from genomic_pca_amd.cli import main
+    pre, z = _chr22_fileset(tmp_path)
+    ld = tmp_path / "ld.txt"
+    edges = np.linspace(16_050_000, 16_050_000 + 25 * 120_000, 10).astype(int)
+    ld.write_text("".join(f"22 {a} {b - 1}\n" for a, b in zip(edges[:-1], edges[1:])))
+    common = ["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--eigensnp-k-global", "5", "--eigensnp-seed", "3",
+              "--eigensnp-components-per-block", "6", "--eigensnp-refine-passes", "2"]
+    if subset:
+        common += ["--eigensnp-subset-factor", "0.5", "--eigensnp-min-subset-size", "20", "--eigensnp-max-subset-size", "40"]
+    ref = str(tmp_path / "ref" / "run")
+    assert main(["--out", ref] + common) == 0                       # the one-stage default
+    out_c, out_p = str(tmp_path / "c" / "run"), str(tmp_path / "p" / "run")
+    r = subprocess.run([host_bin, "--out", out_c, "--gpca-eigensnp-local-stage"] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert main(["--out", out_p, "--gpca-eigensnp-local-stage"] + common) == 0
+    num = lambda path, c: np.array([[float(x) for x in ln.split("\t")[c:]] for ln in open(path).read().strip().split("\n")[1:]])
+    for sfx, c in ((".eigensnp.pca.tsv", 1), (".eigenvalues.tsv", 1), (".eigensnp.loadings.tsv", 3)):
+        a, b, g0 = num(out_c + sfx, c), num(out_p + sfx, c), num(ref + sfx, c)
+        assert a.shape == b.shape == g0.shape
+        assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, np.max(np.abs(b))), sfx          # two hosts, one algorithm
+    ev_m, ev_g = num(out_p + ".eigenvalues.tsv", 1)[:, 0], num(ref + ".eigenvalues.tsv", 1)[:, 0]
+    # N = 64 real samples, a flat spectrum, local bases from as few as 32 samples: both runs approximate the same PCs
+    assert np.all(np.abs(ev_m - ev_g)[:2] / ev_g[:2] < 0.05) and np.all(np.abs(ev_m - ev_g) / ev_g < 0.2)
+
+
+@pytest.mark.gpu
 def test_cpp_vcf_workflow_equals_python_cli(tmp_path, host_bin, gpca, oracle):
     from genomic_pca_amd.cli import main
     M, N = 600, 48
