@@ -136,18 +136,20 @@ def test_compute_pca_multi_stage_end_to_end(gpca, oracle, prec, store):
         D = acc.num_pca_snps()
         edges = np.linspace(0, D - 400, 13).astype(int)             # the last 400 PCA SNPs are in no block
         blocks = [gpca.LdBlockSpecification(f"b{i}", list(range(edges[i], edges[i + 1]))) for i in range(12)]
+        blocks += [gpca.LdBlockSpecification("one_snp", [D - 300]), gpca.LdBlockSpecification("three_snps", [D - 200, D - 190, D - 180]),
+                   gpca.LdBlockSpecification("empty", [])]   # blocks smaller than components_per_ld_block, and an empty one
         cfg = gpca.EigenSNPCoreAlgorithmConfig(target_num_global_pcs=K, components_per_ld_block=5, subset_factor_for_local_basis_learning=0.4,
                                                min_subset_size_for_local_basis_learning=50, max_subset_size_for_local_basis_learning=200,
                                                random_seed=77, refine_pass_count=1, collect_diagnostics=True)
         assert gpca.EigenSNPCoreAlgorithm.subset_size(cfg, N) == 160
         out, diag = gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, blocks, local_stage=True)
-        assert diag["stage"] == "multi-stage" and diag["subset_size"] == 160 and diag["num_condensed_features"] == 60
+        assert diag["stage"] == "multi-stage" and diag["subset_size"] == 160 and diag["num_condensed_features"] == 60 + 1 + 3
         assert acc.num_pca_snps() == D                               # the accessor is as it was
         one, _ = gpca.EigenSNPCoreAlgorithm(cfg).compute_pca(acc, blocks)
         cfg2 = gpca.EigenSNPCoreAlgorithmConfig(**{**cfg.__dict__, "refine_pass_count": 2})
         two, _ = gpca.EigenSNPCoreAlgorithm(cfg2).compute_pca(acc, blocks, local_stage=True)
         rows = e.pca_snp_rows()
-    used = rows[:edges[-1]]
+    used = np.concatenate([rows[:edges[-1]], rows[[D - 300, D - 200, D - 190, D - 180]]])
     keep = np.zeros(M, np.uint8); keep[used] = 1
     r, b = oracle.scale_shift(st["mu"], st["sigma"], keep)
     E = oracle.exact_pca(G, N, r, b, K)
