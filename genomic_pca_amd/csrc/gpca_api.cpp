@@ -134,7 +134,9 @@ extern "C" int gpca_synchronize(gpca_handle* h) {
 // ---- a1 ---------------------------------------------------------------------------------------------------
 static int alloc_stats(gpca_handle* h) {
     const size_t M = (size_t)h->Mpad;   // pad rows: r = b = 0
-    if (h->d_mu) return GPCA_OK;
+    if (h->d_mu && h->cap_stats_pad >= h->Mpad) return GPCA_OK;
+    if (h->d_mu) free_stats(h);         // (arrays of an earlier, smaller matrix on a reused buffer: gpca_copy_rows)
+    h->cap_stats_pad = h->Mpad;
     HIPCHK(hipMalloc((void**)&h->d_mu, M * 4)); HIPCHK(hipMalloc((void**)&h->d_sigma, M * 4));
     HIPCHK(hipMalloc((void**)&h->d_r, M * 4)); HIPCHK(hipMalloc((void**)&h->d_b, M * 4));
     HIPCHK(hipMalloc((void**)&h->d_keep, M)); HIPCHK(hipMalloc((void**)&h->d_reason, M));

@@ -111,6 +111,8 @@ struct gpca_handle {
     // genotypes
     int64_t M = 0, N = 0, ldg = 0, Mpad = 0;   // ldg = samples padded to the kernels' tiles; Mpad = round_up(M, 128): zero rows, so the GEMM loops carry no predicates
     int64_t ld8 = 0;           // byte pitch of the int8 rows: ldg, plus 256 when ldg / 256 is even (see alloc_genotypes)
+    int64_t cap_rows_pad = 0;  // rows the resident genotype buffer was allocated for (gpca_copy_rows reuses it for a smaller block)
+    int64_t cap_stats_pad = 0; // rows the per-row statistics arrays (d_mu .. d_counts) were allocated for
     int8_t* dG = nullptr;      // GPCA_STORE_INT8: [Mpad][ldg]
     uint8_t* dG2 = nullptr;    // GPCA_STORE_2BIT: [Mpad][ld2], ld2 = ldg / 4, dosage codes (3 = missing)
     int64_t ld2 = 0;

@@ -6,7 +6,7 @@ using namespace gpca;
 void free_stats(gpca_handle* h) {
     dfree(h->d_mu); dfree(h->d_sigma); dfree(h->d_r); dfree(h->d_b); dfree(h->d_keep); dfree(h->d_reason);
     dfree(h->d_counts); dfree(h->d_flags); dfree(h->d_pca_rows);
-    h->have_stats = false; h->n_pca = 0; h->pca_rows.clear();
+    h->have_stats = false; h->n_pca = 0; h->pca_rows.clear(); h->cap_stats_pad = 0;
 }
 void free_eigensnp(gpca_handle* h) {
     dfree(h->d_smask); dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0);
@@ -58,6 +58,7 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     stream_close(h);
     free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
     h->M = M; h->N = N; h->Mpad = round_up(M, kGQRowsPerWave); h->pack_flags = 0;
+    h->cap_rows_pad = resident ? h->Mpad : 0;
     if (h->storage == GPCA_STORE_2BIT) {
         h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4; h->ld8 = h->ldg;
         // row pitch an odd multiple of 256 B, like the int8 rows below: 1.9 % on the packed K1 (in-process A/B, both engine orders:
@@ -408,8 +409,28 @@ extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, 
     if (row0 < 0 || rows <= 0 || row0 + rows > src->M) return fail(h, GPCA_ERR_BAD_ARG, "gpca_copy_rows: row range outside the source matrix");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(src->st));
-    CHK(alloc_genotypes(dst, rows, src->N));
-    if (dst->storage == GPCA_STORE_2BIT) HIPCHK(hipMemcpyAsync(dst->dG2, src->dG2 + (size_t)row0 * src->ld2, (size_t)rows * src->ld2, hipMemcpyDeviceToDevice, dst->st));
+    const int64_t new_pad = round_up(rows, kGQRowsPerWave);
+    const bool packed = dst->storage == GPCA_STORE_2BIT;
+    const int64_t pitch = packed ? src->ld2 : src->ld8;
+    if (!dst->sm.on && (packed ? dst->dG2 != nullptr : dst->dG != nullptr) && dst->N == src->N && new_pad <= dst->cap_rows_pad) {
+        // the block fits what an earlier, larger block allocated: keep the genotype buffer, the statistics arrays and the
+        // workspace (a per-LD-block loop would otherwise spend a third of its time in hipMalloc / hipFree); everything that
+        // depends on the rows is marked stale, the rows past the block are zeroed (pad rows: zero genotypes, r = b = 0)
+        HIPCHK(hipStreamSynchronize(dst->st));
+        dst->M = rows; dst->Mpad = new_pad;
+        dst->have_stats = false; dst->have_rsvd = false; dst->n_pca = 0; dst->pca_rows.clear(); dst->flags = 0; dst->apart_valid = false;
+        free_eigensnp(dst);
+        if (dst->d_r && dst->cap_stats_pad < new_pad) free_stats(dst);      // (allocated for a smaller block: the next stats pass re-makes them)
+        if (dst->d_r) {
+            const size_t n = (size_t)dst->cap_stats_pad;
+            HIPCHK(hipMemsetAsync(dst->d_r, 0, n * 4, dst->st)); HIPCHK(hipMemsetAsync(dst->d_b, 0, n * 4, dst->st));
+            HIPCHK(hipMemsetAsync(dst->d_keep, 0, n, dst->st)); HIPCHK(hipMemsetAsync(dst->d_counts, 0, n * 16, dst->st));
+        }
+        if (new_pad > rows) HIPCHK(hipMemsetAsync((packed ? (char*)dst->dG2 : (char*)dst->dG) + (size_t)rows * pitch, 0, (size_t)(new_pad - rows) * pitch, dst->st));
+    } else {
+        CHK(alloc_genotypes(dst, rows, src->N));
+    }
+    if (packed) HIPCHK(hipMemcpyAsync(dst->dG2, src->dG2 + (size_t)row0 * src->ld2, (size_t)rows * src->ld2, hipMemcpyDeviceToDevice, dst->st));
     else HIPCHK(hipMemcpyAsync(dst->dG, src->dG + (size_t)row0 * src->ld8, (size_t)rows * src->ld8, hipMemcpyDeviceToDevice, dst->st));
     dst->pack_flags = src->pack_flags;
     HIPCHK(hipStreamSynchronize(dst->st));

@@ -25,9 +25,24 @@ def test_copy_rows_makes_a_block_a_matrix_of_its_own(gpca, oracle, store):
     G = _data(gpca, oracle, 3000, 333)
     with gpca.GpcaEngine(**_modes("i8", store)) as e, gpca.GpcaEngine(**_modes("i8", store)) as sub:
         e.upload_genotypes_i8(G)
-        for r0, n in ((0, 1), (17, 500), (2999, 1), (1000, 2000)):
+        st = e.snp_stats(gpca.QcConfig(0.9, 0.01, 1e-6))
+        # growing, shrinking and growing again: a smaller block reuses the buffers of a larger one (no hipMalloc per LD block);
+        # every block must give the bits a fresh handle gives for the same rows
+        for r0, n in ((0, 1), (17, 500), (2999, 1), (1000, 2000), (40, 130), (0, 3000), (2000, 900), (5, 129)):
             sub.copy_rows_from(e, r0, n)
             assert sub.dims() == (n, 333) and np.array_equal(sub.download_genotypes_i8(), G[r0:r0 + n])
+            if n < 100:
+                continue
+            sub.set_standardization(st["mu"][r0:r0 + n], st["sigma"][r0:r0 + n], st["keep"][r0:r0 + n])
+            sub.rsvd(5, 8, 2, seed=r0 + 1)
+            got = (sub.eigenvalues(), sub.scores(f64=True), sub.loadings(), sub.transform())
+            with gpca.GpcaEngine(**_modes("i8", store)) as fresh:
+                fresh.upload_genotypes_i8(G[r0:r0 + n])
+                fresh.set_standardization(st["mu"][r0:r0 + n], st["sigma"][r0:r0 + n], st["keep"][r0:r0 + n])
+                fresh.rsvd(5, 8, 2, seed=r0 + 1)
+                want = (fresh.eigenvalues(), fresh.scores(f64=True), fresh.loadings(), fresh.transform())
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (r0, n)
         with pytest.raises(gpca.GpcaError):
             sub.copy_rows_from(e, 2990, 20)                        # past the end
         with pytest.raises(gpca.GpcaError):
