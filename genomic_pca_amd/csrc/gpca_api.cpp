@@ -132,7 +132,7 @@ extern "C" int gpca_synchronize(gpca_handle* h) {
 }
 
 // ---- a1 ---------------------------------------------------------------------------------------------------
-static int alloc_stats(gpca_handle* h) {
+int alloc_stats(gpca_handle* h) {
     const size_t M = (size_t)h->Mpad;   // pad rows: r = b = 0
     if (h->d_mu && h->cap_stats_pad >= h->Mpad) return GPCA_OK;
     if (h->d_mu) free_stats(h);         // (arrays of an earlier, smaller matrix on a reused buffer: gpca_copy_rows)
@@ -146,7 +146,7 @@ static int alloc_stats(gpca_handle* h) {
     return GPCA_OK;
 }
 
-static int refresh_pca_rows(gpca_handle* h) {
+int refresh_pca_rows(gpca_handle* h) {
     std::vector<uint8_t> keep((size_t)h->M);
     HIPCHK(hipMemcpy(keep.data(), h->d_keep, (size_t)h->M, hipMemcpyDeviceToHost));
     h->pca_rows.clear();

@@ -240,6 +240,8 @@ inline bool multi_rank(const gpca_handle* h) { return h->world > 1 || h->hook !=
 constexpr size_t kPlaneBytesPerBlock = (size_t)gpca::kDigits * 1024;   // digit planes of one 32-row (or 32-sample) block
 // gpca_residency.cpp
 void free_stats(gpca_handle* h);
+int alloc_stats(gpca_handle* h);
+int refresh_pca_rows(gpca_handle* h);
 void free_eigensnp(gpca_handle* h);
 void free_ws(gpca_handle* h);
 void stream_close(gpca_handle* h);

@@ -433,6 +433,30 @@ extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, 
     if (packed) HIPCHK(hipMemcpyAsync(dst->dG2, src->dG2 + (size_t)row0 * src->ld2, (size_t)rows * src->ld2, hipMemcpyDeviceToDevice, dst->st));
     else HIPCHK(hipMemcpyAsync(dst->dG, src->dG + (size_t)row0 * src->ld8, (size_t)rows * src->ld8, hipMemcpyDeviceToDevice, dst->st));
     dst->pack_flags = src->pack_flags;
+    if (src->have_stats) {
+        // the rows come with their statistics (mu, sigma, scale / shift, QC decision, genotype counts): the block needs no stats
+        // pass of its own, gpca_set_standardization on dst only narrows the keep set
+        CHK(alloc_stats(dst));
+        const size_t o = (size_t)row0, n = (size_t)rows;
+        HIPCHK(hipMemcpyAsync(dst->d_mu, src->d_mu + o, n * 4, hipMemcpyDeviceToDevice, dst->st));
+        HIPCHK(hipMemcpyAsync(dst->d_sigma, src->d_sigma + o, n * 4, hipMemcpyDeviceToDevice, dst->st));
+        HIPCHK(hipMemcpyAsync(dst->d_r, src->d_r + o, n * 4, hipMemcpyDeviceToDevice, dst->st));
+        HIPCHK(hipMemcpyAsync(dst->d_b, src->d_b + o, n * 4, hipMemcpyDeviceToDevice, dst->st));
+        HIPCHK(hipMemcpyAsync(dst->d_keep, src->d_keep + o, n, hipMemcpyDeviceToDevice, dst->st));
+        HIPCHK(hipMemcpyAsync(dst->d_reason, src->d_reason + o, n, hipMemcpyDeviceToDevice, dst->st));
+        HIPCHK(hipMemcpyAsync(dst->d_counts, src->d_counts + 4 * o, n * 16, hipMemcpyDeviceToDevice, dst->st));
+        HIPCHK(hipStreamSynchronize(dst->st));
+        CHK(refresh_pca_rows(dst));
+        std::vector<uint32_t> counts(n * 4);
+        HIPCHK(hipMemcpy(counts.data(), dst->d_counts, n * 16, hipMemcpyDeviceToHost));
+        dst->flags = 0;                    // missing / invalid genotypes among the rows the block keeps (as gpca_set_standardization does)
+        for (int64_t i : dst->pca_rows) {
+            const uint32_t* c = &counts[(size_t)i * 4];
+            if ((int64_t)c[0] != dst->N) dst->flags |= 1u;
+            if ((uint64_t)c[1] + c[2] + c[3] != c[0]) dst->flags |= 2u;
+        }
+        dst->have_stats = true;
+    }
     HIPCHK(hipStreamSynchronize(dst->st));
     return GPCA_OK;
 }
