@@ -151,7 +151,7 @@ struct gpca_handle {
     // EigenSNP stages (gpca_set_sample_mask / gpca_set_condensed_basis / gpca_rsvd_condensed / gpca_refine, gpca_rsvd.cpp)
     uint8_t* d_smask = nullptr;      // [N] 1 = the sample takes part in learning the basis (nullptr: all samples)
     float* d_cw = nullptr; int32_t* d_cfeat0 = nullptr; int c_cmax = 0; int64_t c_R = 0; int c_B = 0;   // block-diagonal W = U_blk Lambda^-1
-    int64_t *d_cblk_row0 = nullptr, *d_cblk_row1 = nullptr; int32_t* d_cblk_feat0 = nullptr;
+    int64_t *d_cblk_row0 = nullptr, *d_cblk_row1 = nullptr; int32_t *d_cblk_feat0 = nullptr, *d_cblk_c = nullptr;
     double* dP = nullptr; size_t cap_P = 0;         // [(R + 16)][L] condensed-side factor
     float* d_lqr = nullptr; size_t cap_lqr = 0;     // [Mpad][L] orthonormal SNP-side factor of a refinement pass
     float *d_ones = nullptr, *d_zeros = nullptr; size_t cap_ones = 0, cap_zeros = 0;

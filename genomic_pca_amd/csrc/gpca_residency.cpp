@@ -9,7 +9,7 @@ void free_stats(gpca_handle* h) {
     h->have_stats = false; h->n_pca = 0; h->pca_rows.clear(); h->cap_stats_pad = 0;
 }
 void free_eigensnp(gpca_handle* h) {
-    dfree(h->d_smask); dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0);
+    dfree(h->d_smask); dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0); dfree(h->d_cblk_c);
     dfree(h->dP); dfree(h->d_lqr); dfree(h->d_ones); dfree(h->d_zeros);
     h->cap_P = h->cap_lqr = h->cap_ones = h->cap_zeros = 0; h->c_cmax = 0; h->c_R = 0; h->c_B = 0; h->loadings_valid = true;
 }

@@ -628,13 +628,24 @@ extern "C" int gpca_set_condensed_basis(gpca_handle* h, const float* W, const in
         if (it == range.end()) range[f] = {i, i + 1}; else it->second.second = i + 1;
     }
     if (range.empty()) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_condensed_basis: no SNP belongs to a block");
-    std::vector<int64_t> r0, r1; std::vector<int32_t> bf;
+    if (R > M) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_condensed_basis: more condensed features than SNP rows");
+    std::vector<int64_t> r0, r1; std::vector<int32_t> bf, bc;
     for (const auto& kv : range) { bf.push_back(kv.first); r0.push_back(kv.second.first); r1.push_back(kv.second.second); }
+    // a block's feature count = distance to the next block's first feature (the map is ordered by feat0), at most cmax: features
+    // bf + c_b .. belong to the next block and must not be written by this one
+    for (size_t b = 0; b < bf.size(); ++b) {
+        const int64_t next = b + 1 < bf.size() ? (int64_t)bf[b + 1] : R;
+        const int64_t cb = next - bf[b];
+        if (cb < 1) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_condensed_basis: feat0 values of different blocks overlap");
+        bc.push_back((int32_t)std::min<int64_t>(cb, cmax));
+    }
     HIPCHK(hipStreamSynchronize(h->st));
-    dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0);
+    dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0); dfree(h->d_cblk_c);
     const size_t B = bf.size();
     HIPCHK(hipMalloc((void**)&h->d_cw, (size_t)M * cmax * 4)); HIPCHK(hipMalloc((void**)&h->d_cfeat0, (size_t)M * 4));
     HIPCHK(hipMalloc((void**)&h->d_cblk_row0, B * 8)); HIPCHK(hipMalloc((void**)&h->d_cblk_row1, B * 8)); HIPCHK(hipMalloc((void**)&h->d_cblk_feat0, B * 4));
+    HIPCHK(hipMalloc((void**)&h->d_cblk_c, B * 4));
+    HIPCHK(hipMemcpy(h->d_cblk_c, bc.data(), B * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_cw, W, (size_t)M * cmax * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_cfeat0, feat0, (size_t)M * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_cblk_row0, r0.data(), B * 8, hipMemcpyHostToDevice));
@@ -700,7 +711,7 @@ extern "C" int gpca_rsvd_condensed(gpca_handle* h, int32_t k, int32_t oversample
     };
     auto through_W_forward = [&]() -> int {         // dT = A Q ; dP = W^T dT
         CHK(stage_AQ(h, 0));
-        launch_bd_reduce(h->st, h->d_cw, h->d_cfeat0, cmax, h->dT, L, h->d_cblk_row0, h->d_cblk_row1, h->d_cblk_feat0, h->c_B, h->dP);
+        launch_bd_reduce(h->st, h->d_cw, h->d_cfeat0, cmax, h->dT, L, h->d_cblk_row0, h->d_cblk_row1, h->d_cblk_feat0, h->d_cblk_c, h->c_B, h->dP);
         HIPCHK(hipGetLastError());
         return GPCA_OK;
     };

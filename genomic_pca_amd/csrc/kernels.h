@@ -131,7 +131,7 @@ void launch_scale_rows(hipStream_t st, const float* X, int64_t M, int64_t Mpad, 
 // EigenSNP stages: block-diagonal condensed basis W (kernels.hip)
 void launch_bd_expand(hipStream_t st, const float* W, const int32_t* feat0, int cmax, const double* P, int64_t M, int L, float* out);
 void launch_bd_reduce(hipStream_t st, const float* W, const int32_t* feat0, int cmax, const float* T, int L, const int64_t* blk_row0,
-                      const int64_t* blk_row1, const int32_t* blk_feat0, int B, double* P);
+                      const int64_t* blk_row1, const int32_t* blk_feat0, const int32_t* blk_c, int B, double* P);
 void launch_rightmul_inplace_f32(hipStream_t st, float* X, int64_t rows, int L, const double* Z);
 void launch_mask_rows(hipStream_t st, double* Y, int64_t N, int L, const uint8_t* mask);
 void launch_f32_to_f64(hipStream_t st, const float* in, double* out, int64_t n);

@@ -1114,12 +1114,13 @@ void launch_bd_expand(hipStream_t st, const float* W, const int32_t* feat0, int 
 __global__ __launch_bounds__(256) void k_bd_reduce(const float* __restrict__ W, const int32_t* __restrict__ feat0, int cmax,
                                                    const float* __restrict__ T, int L, const int64_t* __restrict__ blk_row0,
                                                    const int64_t* __restrict__ blk_row1, const int32_t* __restrict__ blk_feat0,
-                                                   double* __restrict__ P) {
+                                                   const int32_t* __restrict__ blk_c, double* __restrict__ P) {
     const int b = blockIdx.x;
     const int64_t r0 = blk_row0[b], r1 = blk_row1[b];
     const int32_t bf = blk_feat0[b];
+    const int cb = blk_c[b];        // the block's own feature count (<= cmax): rows bf + cb .. of P belong to the next block
     const int cg = threadIdx.x >> 5, jl = threadIdx.x & 31;
-    for (int c = cg; c < cmax; c += 8)
+    for (int c = cg; c < cb; c += 8)
         for (int j = jl; j < L; j += 32) {
             double a = 0.0;
             for (int64_t i = r0; i < r1; ++i)
@@ -1128,9 +1129,9 @@ __global__ __launch_bounds__(256) void k_bd_reduce(const float* __restrict__ W, 
         }
 }
 void launch_bd_reduce(hipStream_t st, const float* W, const int32_t* feat0, int cmax, const float* T, int L, const int64_t* blk_row0,
-                      const int64_t* blk_row1, const int32_t* blk_feat0, int B, double* P) {
+                      const int64_t* blk_row1, const int32_t* blk_feat0, const int32_t* blk_c, int B, double* P) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(k_bd_reduce, dim3((unsigned)B), dim3(256), 0, st, W, feat0, cmax, T, L, blk_row0, blk_row1, blk_feat0, P);
+    hipLaunchKernelGGL(k_bd_reduce, dim3((unsigned)B), dim3(256), 0, st, W, feat0, cmax, T, L, blk_row0, blk_row1, blk_feat0, blk_c, P);
 }
 // X[i][:] <- X[i][:] Z   (X: rows x L f32 in place, Z: L x L f64 row-major): the triangular factor of a CholeskyQR of a tall f32 matrix
 template <int L>

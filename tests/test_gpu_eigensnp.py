@@ -113,6 +113,9 @@ def test_condensed_global_pca_and_refinement(gpca, oracle, prec, store):
         e.set_condensed_basis(W, feat0, R)
         e.rsvd_condensed(K, 10, 2, seed=5)
         s0, ev0 = e.scores(f64=True), e.eigenvalues()
+        for _ in range(4):                                         # (blocks with fewer features than cmax sit before larger ones:
+            e.rsvd_condensed(K, 10, 2, seed=5)                     #  every block writes its own features only -- same bits every time)
+            assert np.array_equal(e.scores(f64=True), s0)
         with pytest.raises(gpca.GpcaError):
             e.loadings()                                           # scores only
         e.refine(s0)
