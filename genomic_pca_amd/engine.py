@@ -609,6 +609,8 @@ class EigenSNPCoreAlgorithm:
         R = 0
         kw = dict(device=eng._device, precision=eng.precision, storage=eng.storage, digit_planes=eng.digit_planes)
         with GpcaEngine(**kw) as sub:
+            big = max(blocks, key=lambda b: int(b[1][-1]) - int(b[1][0]))[1]
+            sub.copy_rows_from(eng, int(big[0]), int(big[-1]) + 1 - int(big[0]))     # sized once for the widest block: every block reuses its buffers
             for bi, (_, rows) in enumerate(blocks):
                 r0, r1 = int(rows[0]), int(rows[-1]) + 1
                 sub.copy_rows_from(eng, r0, r1 - r0)

@@ -303,6 +303,12 @@ private:
         int64_t R = 0;
         {
             Engine sub(eng.device(), eng.precision(), eng.storage(), eng.digit_planes());
+            {   // sized once for the widest block: every block reuses its buffers
+                size_t big = 0;
+                for (size_t bi = 1; bi < blocks.size(); ++bi)
+                    if (blocks[bi].back() - blocks[bi].front() > blocks[big].back() - blocks[big].front()) big = bi;
+                sub.copy_rows_from(eng, blocks[big].front(), blocks[big].back() + 1 - blocks[big].front());
+            }
             for (size_t bi = 0; bi < blocks.size(); ++bi) {
                 const std::vector<int64_t>& rows = blocks[bi];
                 const int64_t r0 = rows.front(), r1 = rows.back() + 1, D = (int64_t)rows.size();
