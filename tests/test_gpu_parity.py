@@ -819,6 +819,54 @@ def test_rsvd_bitwise_repeatable(gpca, prec, store, M, N, k):
 # ------------------------------------------------------------------------------------------------
 # the alternative kernels behind the diagnostic switches stay correct ("Diagnostic switches")
 # ------------------------------------------------------------------------------------------------
+def _fuzz_cases():
+    rng = np.random.default_rng(20261004)
+    cases = []
+    for i in range(28):
+        k = int(rng.integers(1, 9))
+        N = int(rng.choice([rng.integers(k + 14, 90), rng.integers(90, 700), rng.integers(700, 2600)]))
+        M = int(rng.choice([rng.integers(k + 14, 200), rng.integers(200, 3000), rng.integers(3000, 9000)]))
+        cases.append((i, M, N, k, int(rng.integers(0, 13)), int(rng.integers(0, 4)), ["i8", "f32"][i % 2 if i % 5 else 0],
+                      ["int8", "2bit"][(i // 2) % 2], float(rng.choice([0.0, 0.0, 0.01])), int(rng.integers(1, 10**6))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-k{c[3]}+{c[4]}-q{c[5]}-{c[6]}-{c[7]}-miss{c[8]}")
+def test_random_shapes_against_the_oracle(gpca, oracle, case):
+    """Seeded random shapes, sketch widths, power-iteration counts, residencies, precisions and missing rates (rows with missing
+    genotypes leave through the call-rate filter): QC decisions bit-exact, eigenvalues / unit-norm PCs / loadings within the
+    1e-4 bar of the oracle with the same sketch.  Population structure with more groups than components keeps the requested
+    eigenvalues apart, so that the comparison is not one of rotations inside a degenerate subspace."""
+    from genomic_pca_amd import _lib
+    _, M, N, k, ov, q, prec, store, miss, seed = case
+    ov = min(ov, min(M, N) - k - 1)
+    th = gpca.synth_thresholds(M, k + 3, seed=seed, fst=0.35)
+    G = oracle.synth_genotypes(M, N, seed, th)
+    if miss:
+        rng = np.random.default_rng(seed)
+        rows = rng.choice(M, max(1, int(miss * M)), replace=False)
+        G[rows, rng.integers(0, N, len(rows))] = -127
+    qc = (1.0 if miss else 0.0, 0.0, 1.0)                              # missing rows fail a call rate of 1.0
+    ref = oracle.snp_stats(G, N, *qc)
+    if int(ref["keep"].sum()) < k + ov + 1:
+        pytest.skip("too few SNPs pass QC for this draw")
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA,
+                         storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8) as e:
+        e.upload_genotypes_i8(G)
+        st = e.snp_stats(gpca.QcConfig(*qc))
+        assert np.array_equal(st["keep"], ref["keep"]) and np.array_equal(st["mu"], ref["mu"])
+        e.rsvd(k, ov, q, seed=seed)
+        ev, sc, ld = e.eigenvalues(), e.scores(f64=True), e.loadings().astype(np.float64)
+    r, b = oracle.scale_shift(ref["mu"], ref["sigma"], ref["keep"])
+    R = oracle.rsvd(G, N, r, b, k, ov, q, seed=seed)
+    assert np.max(np.abs(ev - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
+    gaps = np.abs(np.diff(np.append(R["singular_values"][:k], R["singular_values"][k] if k < len(R["singular_values"]) else 0.0))) / R["singular_values"][:k]
+    sep = gaps > 1e-2                                                  # (a PC whose singular value sits within 1 % of the next is compared by its eigenvalue only)
+    if sep.any():
+        assert oracle.max_abs_dpc(sc[:, sep], R["scores"][:, sep]) < 1e-4
+        assert oracle.max_abs_dpc(ld[:, sep], R["loadings"][ref["keep"].astype(bool)][:, sep]) < 1e-4
+
+
 @pytest.mark.parametrize("env", [{"GPCA_GQ_DMA": "0"}, {"GPCA_GTT_DMA": "0"}, {"GPCA_GQ_DMA": "0", "GPCA_GTT_DMA": "0"},
                                  {"GPCA_LDS_PLANES": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GTT_WAVES": "64"},
                                  {"GPCA_GQ_SLOTS": "7", "GPCA_GQ_WAVES": "8"}, {"GPCA_GTT_XCD": "0"}, {"GPCA_GQ_DMA_NT": "0"},
