@@ -282,6 +282,58 @@ def test_panel_cache_reads_the_source_once(gpca, store, fused):
             e.stream_set_cache(-1)                               # no stream open
 
 
+def _stream_fuzz_cases():
+    rng = np.random.default_rng(777)
+    out = []
+    for i in range(14):
+        M = int(rng.integers(300, 12_000)); N = int(rng.integers(40, 1800)); k = int(rng.integers(1, 8))
+        out.append((i, M, N, k, int(rng.integers(1, 9)) * 128 * int(rng.integers(1, 5)), int(rng.integers(2, 6)), int(rng.integers(0, 4)),
+                    ["int8", "2bit"][i % 2], ["synth", "synth16", "host_i8", "host_bed"][i % 4], int(rng.integers(1, 10**6))))
+    return out
+
+
+@pytest.mark.parametrize("case", _stream_fuzz_cases(), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-k{c[3]}-p{c[4]}-r{c[5]}-c{c[6]}-{c[7]}-{c[8]}")
+def test_random_streams_equal_the_resident_engine(gpca, oracle, case):
+    """Seeded random matrix shapes, panel sizes, ring depths, cache sizes and source kinds: the six-pass stream gives the
+    resident engine's bits (QC statistics, eigenvalues, scores, loadings, transform), the four-pass stream stays within the
+    per-panel fixed-point grid of it, and both repeat bit for bit."""
+    _, M, N, k, pr, ring, ncache, store, kind, seed = case
+    P = k + 3
+    th = gpca.synth_thresholds(M, P, seed=seed, fst=0.3)
+    th16 = gpca.synth_thresholds16(M, P, seed=seed, fst=0.3)
+    G = oracle.synth16_genotypes(M, N, seed, th16) if kind == "synth16" else oracle.synth_genotypes(M, N, seed, th)
+    bed = _encode_bed(G)
+    src = {"synth": lambda: gpca.PanelSource.synth(th, seed), "synth16": lambda: gpca.PanelSource.synth16(th16, seed),
+           "host_i8": lambda: gpca.PanelSource.host_i8(lambda r0, r: G[r0:r0 + r]),
+           "host_bed": lambda: gpca.PanelSource.host_bed(lambda r0, r: bed[r0:r0 + r])}[kind]
+    ov = min(10, min(M, N) - k - 1)
+
+    def run(e):
+        st = e.snp_stats(gpca.QcConfig(0.9, 0.01, 1e-6))
+        e.rsvd(k, ov, 2, seed=seed)
+        return dict(mu=st["mu"], keep=st["keep"], ev=e.eigenvalues(), sc=e.scores(f64=True), ld=e.loadings(), tr=e.transform())
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.upload_genotypes_i8(G)
+        res = run(e)
+    if res["keep"].sum() < k + ov + 1:
+        pytest.skip("too few SNPs pass QC for this draw")
+    row_bytes = (-(-N // 256) * 256 + 256) if store == "int8" else (-(-N // 1024) * 1024 // 4 + 512)   # (an upper bound of the pitch)
+    for fused in (False, True):
+        with gpca.GpcaEngine(**_modes(store)) as e:
+            e.stream_open(src(), M, N, panel_rows=pr, ring_slots=ring, fused=fused, cache_bytes=ncache * pr * row_bytes)
+            a = run(e); b = run(e)
+        _same(a, b)
+        if not fused:
+            _same(res, a)
+        else:
+            assert np.array_equal(a["mu"], res["mu"]) and np.array_equal(a["keep"], res["keep"])
+            assert np.max(np.abs(a["ev"] - res["ev"]) / res["ev"]) < 1e-7
+            gaps = np.abs(np.diff(np.append(res["ev"], 0.0))) / res["ev"]
+            sep = gaps > 1e-2
+            if sep.any():
+                assert oracle.max_abs_dpc(a["sc"][:, sep], res["sc"][:, sep]) < 1e-5
+
+
 def test_stream_open_argument_errors(gpca):
     from genomic_pca_amd import _lib
     th = gpca.synth_thresholds(256, 3, seed=1)
