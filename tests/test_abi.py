@@ -155,3 +155,13 @@ def test_rccl_constants_match_the_installed_header():
     init = re.search(r"ncclResult_t\s+ncclCommInitRank\(([^;]*?)\);", txt, re.S).group(1)
     assert [a.split()[-1].lstrip("*") for a in init.replace("\n", " ").split(",")] == ["comm", "nranks", "commId", "rank"]
     assert "ncclUniqueId commId" in init                       # by value
+
+
+def test_integration_md_names_every_exported_symbol():
+    """INTEGRATION.md shows the binding a maintainer of the reference would add: it has to name every entry point of include/gpca.h."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "gpca.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = re.findall(r"GPCA_API\s+[\w\s\*]+?\b(gpca_\w+)\s*\(", hdr)
+    assert len(names) > 40
+    assert [n for n in names if n not in doc] == []
