@@ -37,7 +37,7 @@ struct Args {
     uint64_t seed = 2025;
     // extensions
     int device = -1;
-    std::string precision = "i8", storage = "int8", stream = "auto";
+    std::string precision = "i8", storage = "auto", stream = "auto";
     int64_t panel_rows = 0;
     bool local_stage = false;
 };
@@ -84,7 +84,7 @@ void print_help() {
         "      --device <N>                     HIP device ordinal\n"
         "      --write-eigenvalues              VCF workflow: fill P.eigenvalues.tsv (the reference leaves it header-only)\n"
         "      --gpca-precision <i8|f32>        i8 = exact-integer GEMMs (default); f32 = f32 matrix cores\n"
-        "      --gpca-storage <int8|2bit>       HBM residency of the genotypes\n"
+        "      --gpca-storage <auto|int8|2bit>  HBM residency of the genotypes (auto = 2bit for a .bed of >= 1024 samples, else int8)\n"
         "      --gpca-stream <auto|on|off>      walk the .bed out of core (auto = when it does not fit the device)\n"
         "      --gpca-panel-rows <N>            SNP rows per panel for --gpca-stream (0 = engine default)\n"
         "      --gpca-eigensnp-local-stage      run the multi-stage algorithm of the --eigensnp-* local / refine flags instead of\n"
@@ -147,7 +147,7 @@ Args parse(int argc, char** argv) {
         else if (f == "--device") a.device = (int)to_i64(f, val());
         else if (f == "--write-eigenvalues") a.write_eigenvalues = true;
         else if (f == "--gpca-precision") { a.precision = val(); if (a.precision != "i8" && a.precision != "f32") usage_error("invalid value '" + a.precision + "' for '--gpca-precision' (i8, f32)"); }
-        else if (f == "--gpca-storage") { a.storage = val(); if (a.storage != "int8" && a.storage != "2bit") usage_error("invalid value '" + a.storage + "' for '--gpca-storage' (int8, 2bit)"); }
+        else if (f == "--gpca-storage") { a.storage = val(); if (a.storage != "auto" && a.storage != "int8" && a.storage != "2bit") usage_error("invalid value '" + a.storage + "' for '--gpca-storage' (auto, int8, 2bit)"); }
         else if (f == "--gpca-stream") { a.stream = val(); if (a.stream != "auto" && a.stream != "on" && a.stream != "off") usage_error("invalid value '" + a.stream + "' for '--gpca-stream' (auto, on, off)"); }
         else if (f == "--gpca-panel-rows") a.panel_rows = to_i64(f, val());
         else if (f == "--gpca-eigensnp-local-stage") a.local_stage = true;
@@ -164,10 +164,15 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
 }
 
 int engine_precision(const Args& a) { return a.precision == "i8" ? GPCA_PREC_I8_EXACT : GPCA_PREC_F32_MFMA; }
-int engine_storage(const Args& a) { return a.storage == "2bit" ? GPCA_STORE_2BIT : GPCA_STORE_INT8; }
+// storage "auto": a .bed of >= 1 024 samples stays in its own 2-bit form (a quarter of the HBM, faster packed kernels there);
+// narrower matrices and VCF input are int8 (cli.py:_engine_modes)
+int engine_storage(Args& a, int64_t bed_samples = 0) {
+    if (a.storage == "auto") a.storage = bed_samples >= 1024 ? "2bit" : "int8";
+    return a.storage == "2bit" ? GPCA_STORE_2BIT : GPCA_STORE_INT8;
+}
 
 // ------------------------------------------------------------------------------------------------ VCF workflow
-int run_vcf_workflow(const Args& a) {
+int run_vcf_workflow(Args a) {
     if (a.vcf_dir.empty() || !a.have_components) {
         std::fprintf(stderr, "error: --vcf-dir and --components are required unless --eigensnp is given\n");
         return 2;
@@ -260,7 +265,7 @@ void load_bed(gpca::Engine& eng, const Args& a, const gpca_host::PlinkFileset& f
     eng.stream_open(src, fs.n_snps, n_samples, a.panel_rows, 3, true, -1);
 }
 
-int run_eigensnp_workflow(const Args& a) {
+int run_eigensnp_workflow(Args a) {
     if (a.bed_file.empty() || a.ld_block_file.empty()) {
         std::fprintf(stderr, "error: --bed-file and --ld-block-file are required when --eigensnp is used\n");           // main.rs:296-301
         return 2;
@@ -268,7 +273,8 @@ int run_eigensnp_workflow(const Args& a) {
     const auto t0 = std::chrono::steady_clock::now();
     gpca_host::PlinkFileset fs;
     gpca_host::read_plink(a.bed_file, fs);
-    gpca::Engine eng(a.device, engine_precision(a), engine_storage(a));
+    const int store = engine_storage(a, fs.n_samples);
+    gpca::Engine eng(a.device, engine_precision(a), store);
     std::vector<std::string> sample_ids = fs.sample_ids;
     KeptColumns kept{&fs, {}};
     bool use_kept = false;

@@ -256,6 +256,31 @@ def test_both_clis_multi_stage_eigensnp(tmp_path, host_bin, subset):
 
 
 @pytest.mark.gpu
+def test_both_clis_pick_2bit_residency_for_a_wide_bed(tmp_path, host_bin, gpca, oracle):
+    """--gpca-storage auto (the default): a .bed of >= 1 024 samples stays in its own 2-bit form on the device, a narrower one is
+    decoded to int8 -- both hosts make the same choice (byte-identical files, and identical to the explicit setting)."""
+    from genomic_pca_amd.cli import main
+    M, N = 2500, 1100
+    G = oracle.synth_genotypes(M, N, 6, gpca.synth_thresholds(M, 5, seed=6, fst=0.3))
+    pre = str(tmp_path / "wide")
+    gio.write_plink(pre, G, [f"s{i}" for i in range(N)], [f"rs{i}" for i in range(M)], ["7"] * M, list(range(1, M + 1)))
+    ld = tmp_path / "ld.txt"
+    ld.write_text("7 1 100000\n")
+    common = ["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--eigensnp-k-global", "4"]
+    outs = {}
+    for name, extra in (("auto", []), ("two", ["--gpca-storage", "2bit"]), ("eight", ["--gpca-storage", "int8"])):
+        out = str(tmp_path / name / "run")
+        assert main(["--out", out] + common + extra) == 0
+        outs[name] = [open(out + sfx).read() for sfx in (".eigensnp.pca.tsv", ".eigenvalues.tsv", ".eigensnp.loadings.tsv")]
+    out_c = str(tmp_path / "c" / "run")
+    r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert [open(out_c + sfx).read() for sfx in (".eigensnp.pca.tsv", ".eigenvalues.tsv", ".eigensnp.loadings.tsv")] == outs["auto"]
+    assert outs["auto"] == outs["two"]                                # 1 100 samples: 2-bit
+    assert outs["two"] == outs["eight"]                               # (and the exact path gives the same bits on either residency)
+
+
+@pytest.mark.gpu
 def test_cpp_vcf_workflow_equals_python_cli(tmp_path, host_bin, gpca, oracle):
     from genomic_pca_amd.cli import main
     M, N = 600, 48
