@@ -40,6 +40,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc8(const void* p) {
 // streamed-panel runs agree on c exactly
 #define GPCA_STORE_CUNIT(UNIT) { const float co_ = ct + __shfl_xor(ct, 32); if (h == 0) cunit[(int64_t)(UNIT) * 32 + c] = co_; }
 
+// Shapes the hand-counted DMA pipelines were derived for: sample pitch a multiple of `npad_mult`, row count a multiple of `rows_mult`.
+// The launchers refuse anything else (hipErrorInvalidValue -> GPCA_ERR_HIP with the kernel's name) rather than compute garbage.
+static inline bool dma_shape_ok(int64_t Npad, int64_t npad_mult, int64_t rows, int64_t rows_mult) {
+    return Npad > 0 && Npad % npad_mult == 0 && rows > 0 && rows % rows_mult == 0;
+}
+
 template <int BITS = 7>
 __device__ __forceinline__ double combine_digits(const i32x16 (&a)[kDigits], int e) {
     // exact: each |a| < 2^31, weights are powers of two, total < 2^53
@@ -900,13 +906,15 @@ __global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, i
     if (h == 0) apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am;
 }
 
-void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+int launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                  int scale_out, int64_t ldt, const KernelOpts& ko) {
+    if (!dma_shape_ok(Npad, 256, plan.units * 32, 32)) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
-    const int64_t nstage = Npad / 128;    // Npad is a multiple of 256 -> even
+    const int64_t nstage = Npad / 128;    // even (checked above): the plane slots alternate per stage
     const int rmax = ko.gq_r;
     hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, rmax, ldt);
+    return 0;
 }
 
 // ================================================================================================
@@ -1148,6 +1156,9 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                 int scale_out, int64_t ldt, const KernelOpts& ko) {
+    // the hand-counted vmcnt pipeline is only correct for an EVEN number of 128-sample stages (9 stages gave wrong eigenvalues,
+    // profiles/r1_kbench_summary.md section 9): refuse any other pitch instead of answering wrongly
+    if (!dma_shape_ok(Npad, 256, plan.units * 32, 32) || ldg < Npad) return (int)hipErrorInvalidValue;
     const int slots = ko.gq_slots;
     const bool g_dma_nt = ko.dma_nt != 0;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
@@ -1608,6 +1619,8 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
 
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, int nd, const KernelOpts& ko) {
+    // stages of 128 SNP rows, 1 024-sample row padding of the packed store (its DMA pieces are whole 128-byte lines of codes)
+    if (!dma_shape_ok(Npad, kSamplePad2bit, Mpad, kGQRowsPerWave) || ld2 * 4 < Npad) return (int)hipErrorInvalidValue;
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     const int remap = ko.gtt_xcd;
     if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
@@ -1619,6 +1632,7 @@ int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, i
 
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, const KernelOpts& ko) {
+    if (!dma_shape_ok(Npad, 256, Mpad, kGQRowsPerWave) || ldg < Npad) return (int)hipErrorInvalidValue;   // 128-row stages, 256-sample pitch
     const int64_t ngroups = (plan.nblocks_n + 3) / 4;
     const dim3 grid((unsigned)plan.grid), blk(256);
     const int remap = ko.gtt_xcd;   // measured 5.10 -> 5.00 ms per step

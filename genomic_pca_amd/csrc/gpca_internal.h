@@ -136,6 +136,7 @@ struct gpca_handle {
     int spin_sync = 1;           // busy-poll the stream at the two syncs of gpca_rsvd (GPCA_SPIN_SYNC=0: hipStreamSynchronize)
     int* d_cholflag = nullptr;   // first failed CholeskyQR pivot + 1 (0 = ok), written by k_chol_inv
     double *d_scratch64 = nullptr, *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
+    double* d_tr64 = nullptr; size_t cap_tr64 = 0;   // [N][k] compacted output of gpca_transform
     double* d_scores64 = nullptr; float* d_scores32 = nullptr; float* d_load32 = nullptr; int* d_sign = nullptr;
     size_t cap_Q = 0, cap_T = 0, cap_Tb = 0, cap_Ypart = 0, cap_cpart = 0, cap_Y = 0, cap_part64 = 0, cap_scores = 0, cap_load = 0;
     std::vector<double> eig, sv;
@@ -150,6 +151,7 @@ struct gpca_handle {
     double* d_yint = nullptr; size_t cap_yint = 0;   // [halves][N][32] integer partial sums of a streamed K2 sweep
     // EigenSNP stages (gpca_set_sample_mask / gpca_set_condensed_basis / gpca_rsvd_condensed / gpca_refine, gpca_rsvd.cpp)
     uint8_t* d_smask = nullptr;      // [N] 1 = the sample takes part in learning the basis (nullptr: all samples)
+    int64_t n_smask = 0;             // samples in the subset (eigenvalues of a masked gpca_rsvd are variances over these: / (n_smask - 1))
     float* d_cw = nullptr; int32_t* d_cfeat0 = nullptr; int c_cmax = 0; int64_t c_R = 0; int c_B = 0;   // block-diagonal W = U_blk Lambda^-1
     int64_t *d_cblk_row0 = nullptr, *d_cblk_row1 = nullptr; int32_t *d_cblk_feat0 = nullptr, *d_cblk_c = nullptr;
     double* dP = nullptr; size_t cap_P = 0;         // [(R + 16)][L] condensed-side factor
@@ -179,6 +181,7 @@ struct gpca_handle {
 
     // timings (off by default; bounded: pending records are folded into `agg` once kMaxTimingRecs are outstanding)
     bool timing_on = false;
+    int open_timers = 0;         // ScopedTimers alive (their records must not be folded away under them)
     std::vector<TimingRec> recs;
     std::vector<hipEvent_t> ev_pool;
     std::vector<gpca_kernel_timing> agg;
@@ -221,16 +224,18 @@ struct ScopedTimer {
     ScopedTimer(gpca_handle* h_, const char* name, double flops, double bytes, hipStream_t st_ = nullptr, bool enable = true)
         : h(h_), on(h_->timing_on && enable), st(st_ ? st_ : h_->st) {
         if (!on) return;
-        if (h->recs.size() >= kMaxTimingRecs) fold_timings(h);
+        // (never while another timer is open: a fold clears recs and recycles the open record's events -- nested timers are the
+        //  sweep timers of the streamed passes around their panel_fill / per-launch records)
+        if (h->recs.size() >= kMaxTimingRecs && h->open_timers == 0) fold_timings(h);
         TimingRec r; r.name = name; r.flops = flops; r.bytes = bytes; r.a = r.b = nullptr;
         for (hipEvent_t* e : {&r.a, &r.b}) {
             if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
             else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
         }
         (void)hipEventRecord(r.a, st);
-        h->recs.push_back(r); idx = h->recs.size() - 1;
+        h->recs.push_back(r); idx = h->recs.size() - 1; h->open_timers++;
     }
-    ~ScopedTimer() { if (on) (void)hipEventRecord(h->recs[idx].b, st); }
+    ~ScopedTimer() { if (on) { (void)hipEventRecord(h->recs[idx].b, st); h->open_timers--; } }
 };
 
 

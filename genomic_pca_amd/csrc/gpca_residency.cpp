@@ -9,7 +9,7 @@ void free_stats(gpca_handle* h) {
     h->have_stats = false; h->n_pca = 0; h->pca_rows.clear(); h->cap_stats_pad = 0;
 }
 void free_eigensnp(gpca_handle* h) {
-    dfree(h->d_smask); dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0); dfree(h->d_cblk_c);
+    dfree(h->d_smask); h->n_smask = 0; dfree(h->d_cw); dfree(h->d_cfeat0); dfree(h->d_cblk_row0); dfree(h->d_cblk_row1); dfree(h->d_cblk_feat0); dfree(h->d_cblk_c);
     dfree(h->dP); dfree(h->d_lqr); dfree(h->d_ones); dfree(h->d_zeros);
     h->cap_P = h->cap_lqr = h->cap_ones = h->cap_zeros = 0; h->c_cmax = 0; h->c_R = 0; h->c_B = 0; h->loadings_valid = true;
 }
@@ -17,7 +17,7 @@ void free_ws(gpca_handle* h) {
     free_eigensnp(h);
     dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
-    dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64);
+    dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64); dfree(h->d_tr64); h->cap_tr64 = 0;
     dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_cholflag); if (h->h_pin) { (void)hipHostFree(h->h_pin); h->h_pin = nullptr; } dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
     dfree(h->d_amax_run); dfree(h->d_yint); h->cap_yint = 0;
     h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
@@ -364,6 +364,9 @@ extern "C" int gpca_stream_set_cache(gpca_handle* h, int64_t max_bytes, int32_t*
     while (sm.cache.size() < want) {
         void* p = nullptr; hipEvent_t e = nullptr;
         hipError_t err = hipMalloc(&p, panel_bytes);
+        // zeroed like the ring slots: a HOST_I8 source writes N bytes per row, and the kernels' vector loads assume the bytes between
+        // N and the row pitch are 0 (recycled device memory need not be)
+        if (err == hipSuccess) err = hipMemsetAsync(p, 0, panel_bytes, sm.st_fill);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
         if (err != hipSuccess) {
             if (p) (void)hipFree(p);

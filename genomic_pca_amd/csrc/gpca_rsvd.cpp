@@ -232,7 +232,10 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                         const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
                         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
                     }
-                    else if (h->lds_planes) launch_gq_x(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
+                    else if (h->lds_planes) {
+                        const int e = launch_gq_x(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
+                        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_x launch failed (hip error " + std::to_string(e) + ")");
+                    }
                     else launch_gq_i8(h->st, pv.g8, h->ld8, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, scale_out, L, h->ko);
                     HIPCHK(hipGetLastError());
                     if (streamed && scale_out && (packed || h->lds_planes)) {   // (streamed: the per-launch timer above is disabled) fold this panel's column abs-max before the next launch reuses ap
@@ -293,7 +296,10 @@ static int stage_power_fused(gpca_handle* h) {
                 else if (h->gq_dma) {
                     const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
                     if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
-                } else launch_gq_x(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
+                } else {
+                    const int e = launch_gq_x(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
+                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_x launch failed (hip error " + std::to_string(e) + ")");
+                }
                 HIPCHK(hipGetLastError());
                 // this panel's rows of T' -> digit planes against this panel's column maxima
                 launch_quantize_f32_premax(h->st, Th, pv.rows_pad, pv.rows_pad, ap, plan1.waves, h->d_tscale + 32 * hf, h->d_tinv + 32 * hf,
@@ -498,7 +504,9 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     host_eigh_desc(C, V, w, l);
     h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
     for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
-    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
+    // variance over the samples that took part: all N, or the subset of gpca_set_sample_mask (the other rows of the sketch are zero)
+    const double n_eff = h->d_smask ? (double)h->n_smask : (double)h->N;
+    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (n_eff - 1.0);
     // 4. scores = Q V_k diag(s) ; sign ; loadings = B V_k diag(sign/s)   (the sign is applied to the loadings' Z on the device)
     const size_t zk = (size_t)L * k;
     for (size_t e = 0; e < 2 * zk; ++e) Zpin[e] = 0.0;
@@ -580,10 +588,16 @@ extern "C" int gpca_transform(gpca_handle* h, double* out) {
     lrc = agree_status(h, lrc, "gpca_transform");
     if (lrc != GPCA_OK) return lrc;
 #undef LOCAL
-    std::vector<double> Y((size_t)h->N * L);
-    HIPCHK(hipMemcpyAsync(Y.data(), h->dY, (size_t)h->N * L * 8, hipMemcpyDeviceToHost, h->st));
+    // only the k columns asked for leave the device (the whole N x L block was 256 MB at N = 500k, L = 64): compacted on the device
+    // by a right-multiplication with the L x k selection matrix, then one contiguous copy into the caller's buffer
+    CHK(ensure(h, h->d_tr64, h->cap_tr64, (size_t)h->N * k));
+    double* Zsel = h->h_pin + 64 * 64;
+    for (int j = 0; j < L; ++j) for (int c = 0; c < k; ++c) Zsel[(size_t)j * k + c] = j == c ? 1.0 : 0.0;
+    HIPCHK(hipMemcpyAsync(h->dZ, Zsel, sizeof(double) * (size_t)L * k, hipMemcpyHostToDevice, h->st));
+    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_tr64, (float*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->d_tr64, (size_t)h->N * k * 8, hipMemcpyDeviceToHost, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
-    for (int64_t n = 0; n < h->N; ++n) for (int c = 0; c < k; ++c) out[n * k + c] = Y[(size_t)n * L + c];
     h->have_rsvd = true;  // dT (=B) is consumed, but scores/loadings/eigenvalues stay valid
     return GPCA_OK;
 }
@@ -599,12 +613,13 @@ extern "C" int gpca_set_sample_mask(gpca_handle* h, const uint8_t* mask) {
     LOCK(h);
     if (!have_genotypes(h)) return fail(h, GPCA_ERR_STATE, "gpca_set_sample_mask: no genotypes resident and no panel stream open");
     HIPCHK(hipStreamSynchronize(h->st));
-    if (!mask) { dfree(h->d_smask); return GPCA_OK; }
+    if (!mask) { dfree(h->d_smask); h->n_smask = 0; return GPCA_OK; }
     int64_t n_in = 0;
     for (int64_t n = 0; n < h->N; ++n) n_in += mask[n] != 0;
     if (n_in < 2) return fail(h, GPCA_ERR_BAD_ARG, "gpca_set_sample_mask: fewer than 2 samples in the subset");
     if (!h->d_smask) HIPCHK(hipMalloc((void**)&h->d_smask, (size_t)h->N));
     HIPCHK(hipMemcpy(h->d_smask, mask, (size_t)h->N, hipMemcpyHostToDevice));
+    h->n_smask = n_in;
     h->have_rsvd = false;
     return GPCA_OK;
 }

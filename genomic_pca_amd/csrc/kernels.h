@@ -189,7 +189,7 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                 int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
 // K1 with the digit planes of Q shared through LDS (int8-resident genotypes)
-void launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
+int launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                  int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
 // K2 with the digit planes shared through LDS (packed = 0: int8 rows of pitch ldr, 1: 2-bit rows of pitch ldr)

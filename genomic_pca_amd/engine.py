@@ -417,6 +417,10 @@ class PCA:
                 g[:, s0:s0 + step] = r.T.astype(np.int8)
         self._eng.upload_genotypes_i8(g)
         self._eng.snp_stats(QcConfig.none(), fetch=False)
+        # zero-variance rows leave the PCA even without QC thresholds: the reference's clamp (main.rs:621-628), applied to what is left
+        if self._eng.num_pca_snps() == 0:
+            raise ValueError("PCA requires at least 1 variant (feature), found 0.")
+        k = min(k, self._eng.num_pca_snps())
         l = min(k + n_oversamples, n_samples, self._eng.num_pca_snps())
         self._eng.rsvd(k, l - k, power_iters, 0 if seed is None else int(seed))
         self._fitted = True
@@ -552,8 +556,9 @@ class EigenSNPCoreAlgorithm:
             else:
                 eng.rsvd(cfg.target_num_global_pcs, cfg.global_pca_sketch_oversampling, cfg.global_pca_num_power_iterations,
                          cfg.random_seed)
-            out = EigenSNPCoreOutput(eng.scores(), eng.eigenvalues(), eng.loadings(), accessor.num_qc_samples(),
-                                     int(ids.size), cfg.target_num_global_pcs)
+            sc = eng.scores()     # (the local stage may leave fewer components than target_num_global_pcs: min(K, condensed features))
+            out = EigenSNPCoreOutput(sc, eng.eigenvalues(), eng.loadings(), accessor.num_qc_samples(),
+                                     int(ids.size), int(sc.shape[1]))
         finally:
             if restore is not None:
                 eng.set_standardization(restore["mu"], restore["sigma"], restore["keep"])

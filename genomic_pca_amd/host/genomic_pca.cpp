@@ -324,14 +324,16 @@ int run_eigensnp_workflow(Args a) {
     cfg.random_seed = a.seed; cfg.snp_processing_strip_size = a.strip_size; cfg.refine_pass_count = (int)a.refine_passes;
     cfg.collect_diagnostics = a.collect_diagnostics;
     const gpca::EigenSNPCoreOutput out = gpca::EigenSNPCoreAlgorithm(cfg).compute_pca(acc, specs, a.local_stage);
+    // the column count comes from the result: the local stage may leave fewer than k components (min(k, condensed features))
+    const int kc = (int)out.num_principal_components_computed;
     gpca_host::ensure_parent(a.output_prefix);
     gpca_host::write_principal_components(a.output_prefix, "eigensnp.pca.tsv", sample_ids, out.final_sample_principal_component_scores.data(),
-                                          out.num_qc_samples_used, (int)k);
+                                          out.num_qc_samples_used, kc);
     gpca_host::write_eigenvalues(a.output_prefix, out.final_principal_component_eigenvalues);
     std::vector<std::string> vids, chroms; std::vector<int64_t> pos;
     vids.reserve(rows.size()); chroms.reserve(rows.size()); pos.reserve(rows.size());
     for (int64_t r : rows) { vids.push_back(fs.variant_ids[(size_t)r]); chroms.push_back(fs.chromosomes[(size_t)r]); pos.push_back(fs.positions[(size_t)r]); }
-    gpca_host::write_loadings(a.output_prefix, vids, chroms, pos, out.final_snp_principal_component_loadings.data(), (int64_t)rows.size(), (int)k);
+    gpca_host::write_loadings(a.output_prefix, vids, chroms, pos, out.final_snp_principal_component_loadings.data(), (int64_t)rows.size(), kc);
     std::snprintf(buf, sizeof buf, "EigenSNP workflow done in %.2fs", seconds_since(t0));
     logmsg(buf);
     return 0;

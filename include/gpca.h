@@ -222,7 +222,8 @@ GPCA_API int gpca_transform(gpca_handle* h, double* out);
  * gpca_copy_rows: dst (same device and storage mode) receives rows [row0, row0 + rows) of src's RESIDENT matrix, device to device:
  *   an LD block as a matrix of its own (follow with gpca_set_standardization on dst).
  * gpca_set_sample_mask: mask[n] != 0 = sample n takes part in learning the basis; gpca_rsvd then learns scores / loadings from
- *   those columns only, gpca_transform still projects every sample.  NULL clears.
+ *   those columns only (its eigenvalues are variances over the subset: / (subset size - 1)), gpca_transform still projects every
+ *   sample.  NULL clears.
  * gpca_set_condensed_basis: W[i][0..cmax) = SNP row i's coefficients (local loading / feature s.d.) on the condensed features
  *   [feat0[i], feat0[i] + cmax) of its block, zero-padded; feat0[i] < 0 = in no block; R = number of condensed features.
  * gpca_rsvd_condensed: randomized PCA of the row-standardised condensed feature matrix C* = W^T A (R x N, never formed: its

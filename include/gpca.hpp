@@ -269,7 +269,7 @@ public:
             out.final_snp_principal_component_loadings = eng.loadings();
             out.num_qc_samples_used = accessor.num_qc_samples();
             out.num_pca_snps_used = (int64_t)ids.size();
-            out.num_principal_components_computed = cfg_.target_num_global_pcs;
+            out.num_principal_components_computed = eng.components();   // (the local stage may leave fewer: min(K, condensed features))
         } catch (...) {
             if (restrict_rows) eng.set_standardization(saved.mu, saved.sigma, saved.keep);
             throw;
@@ -367,6 +367,9 @@ public:
         k = (int)std::min<int64_t>({(int64_t)k, n_samples, n_features});                                                          // main.rs:621-628
         eng_.upload_genotypes_i8(variants_by_samples, n_features, n_samples, n_samples);
         eng_.snp_stats(QcConfig::none(), false);
+        // zero-variance rows leave the PCA even without QC thresholds: the reference's clamp (main.rs:621-628), applied to what is left
+        if (eng_.num_pca_snps() == 0) throw std::invalid_argument("PCA requires at least 1 variant (feature), found 0.");
+        k = (int)std::min<int64_t>((int64_t)k, eng_.num_pca_snps());
         const int64_t l = std::min<int64_t>({(int64_t)k + n_oversamples, n_samples, eng_.num_pca_snps()});
         eng_.rsvd(k, (int)(l - k), power_iters, seed);
         fitted_ = true;

@@ -256,6 +256,30 @@ def test_both_clis_multi_stage_eigensnp(tmp_path, host_bin, subset):
 
 
 @pytest.mark.gpu
+def test_both_clis_local_stage_with_fewer_components_than_k_global(tmp_path, host_bin):
+    """One LD block and components_per_block (3) < k_global (5): the local stage leaves 3 condensed features, so 3 PCs come back.
+    Both hosts must take the column count from the result -- the C++ host once wrote k_global columns from 3-column arrays (wrong
+    stride, reads past the end) -- and produce the same 3-column files."""
+    from genomic_pca_amd.cli import main
+    pre, z = _chr22_fileset(tmp_path)
+    ld = tmp_path / "ld.txt"
+    ld.write_text("22 1 500000000\n")
+    common = ["--eigensnp", "--bed-file", pre + ".bed", "--ld-block-file", str(ld), "--eigensnp-k-global", "5", "--eigensnp-seed", "3",
+              "--eigensnp-components-per-block", "3", "--gpca-eigensnp-local-stage"]
+    out_c, out_p = str(tmp_path / "c" / "run"), str(tmp_path / "p" / "run")
+    r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert main(["--out", out_p] + common) == 0
+    num = lambda path, c: np.array([[float(x) for x in ln.split("\t")[c:]] for ln in open(path).read().strip().split("\n")[1:]])
+    for sfx, c, cols in ((".eigensnp.pca.tsv", 1, 3), (".eigenvalues.tsv", 1, 1), (".eigensnp.loadings.tsv", 3, 3)):
+        a, b = num(out_c + sfx, c), num(out_p + sfx, c)
+        assert a.shape == b.shape and a.shape[1] == cols, (sfx, a.shape, b.shape)
+        assert open(out_c + sfx).readline() == open(out_p + sfx).readline()           # same header (PC1..PC3)
+        assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, np.max(np.abs(b))), sfx
+    assert num(out_p + ".eigenvalues.tsv", 1).shape[0] == 3
+
+
+@pytest.mark.gpu
 def test_both_clis_pick_2bit_residency_for_a_wide_bed(tmp_path, host_bin, gpca, oracle):
     """--gpca-storage auto (the default): a .bed of >= 1 024 samples stays in its own 2-bit form on the device, a narrower one is
     decoded to int8 -- both hosts make the same choice (byte-identical files, and identical to the explicit setting)."""

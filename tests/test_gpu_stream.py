@@ -231,6 +231,31 @@ def test_streamed_fused_power_iteration(gpca, oracle, store, planes, k):
     assert oracle.max_abs_dpc(stm["sc"][:, :kk], R["scores"][:, :kk]) < 1e-4
 
 
+def test_panel_cache_pad_columns_on_recycled_device_memory(gpca, oracle):
+    """A cached panel of a HOST_I8 source on int8 storage receives N bytes per row; the bytes between N and the row pitch must read as
+    zero (k_snp_stats' vector loads count them otherwise).  The cache buffers are therefore zeroed at allocation -- checked here on
+    device memory that was first filled with 1s and freed, with N % 16 != 0."""
+    M, N, pr = 6000, 1003, 2048
+    G = oracle.synth_genotypes(M, N, 4, gpca.synth_thresholds(M, 3, seed=4, fst=0.1))
+    G[np.random.default_rng(1).random(G.shape) < 0.02] = -127
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        e.upload_genotypes_i8(G)
+        ref = e.snp_stats(gpca.QcConfig())
+        ref_counts, ref_reason = e.snp_qc_detail()
+    for attempt in range(2):
+        with gpca.GpcaEngine(**_modes("int8")) as d:       # dirty what the cache will be carved from: the same byte sizes, all 1s
+            d.upload_genotypes_i8(np.ones((3 * pr, 1280), np.int8))
+            d.snp_stats(gpca.QcConfig.none())
+        with gpca.GpcaEngine(**_modes("int8")) as e:
+            e.stream_open(gpca.PanelSource.host_i8(lambda r0, r: G[r0:r0 + r]), M, N, panel_rows=pr, ring_slots=2, fused=False)
+            assert e.stream_set_cache(-1) == 3
+            st = e.snp_stats(gpca.QcConfig())
+            counts, reason = e.snp_qc_detail()
+            assert np.array_equal(counts, ref_counts) and np.array_equal(reason, ref_reason)
+            for key in ("mu", "sigma", "keep"):
+                assert np.array_equal(st[key], ref[key]), key
+
+
 @pytest.mark.parametrize("store,fused", [("int8", False), ("2bit", False), ("2bit", True)])
 def test_panel_cache_reads_the_source_once(gpca, store, fused):
     """gpca_stream_set_cache: the leading panels keep an HBM buffer of their own -- the source is asked for them once (during
