@@ -58,11 +58,20 @@ PANEL_HOST_I8 = 0
 PANEL_HOST_BED = 1
 PANEL_SYNTH = 2
 PANEL_SYNTH16 = 3
+PANEL_MAPPED_I8 = 4
+PANEL_MAPPED_BED = 5
+SOURCE_REGISTER = 1
 
 
 class gpca_panel_source(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_pop", C.c_int32), ("fill", PANEL_FN), ("user", C.c_void_p),
-                ("thresh", C.c_void_p), ("seed", C.c_uint64), ("snp_offset", C.c_int64), ("reserved", C.c_int64 * 2)]
+                ("thresh", C.c_void_p), ("seed", C.c_uint64), ("snp_offset", C.c_int64), ("host_ld", C.c_int64), ("flags", C.c_int64)]
+
+
+class gpca_stream_info(C.Structure):
+    _fields_ = [("panel_rows", C.c_int64), ("n_panels", C.c_int32), ("ring_slots", C.c_int32), ("n_cached", C.c_int32),
+                ("staging_buffers", C.c_int32), ("zero_staging", C.c_int32), ("copy_threads", C.c_int32), ("fills", C.c_int64),
+                ("fill_host_ms", C.c_double), ("fill_wait_ms", C.c_double), ("register_ms", C.c_double), ("reserved", C.c_int64 * 4)]
 
 
 # name -> (restype, argtypes); the "not gpu" test checks every one of these is exported
@@ -81,6 +90,7 @@ PROTOTYPES = {
     "gpca_stream_open": (C.c_int, [_H, C.POINTER(gpca_panel_source), C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "gpca_stream_set_fused": (C.c_int, [_H, C.c_int32]),
     "gpca_stream_set_cache": (C.c_int, [_H, C.c_int64, C.POINTER(C.c_int32)]),
+    "gpca_stream_get_info": (C.c_int, [_H, C.POINTER(gpca_stream_info)]),
     "gpca_get_device_memory": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gpca_copy_rows": (C.c_int, [_H, _H, C.c_int64, C.c_int64]),
     "gpca_set_sample_mask": (C.c_int, [_H, C.c_void_p]),

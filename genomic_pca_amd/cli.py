@@ -162,7 +162,8 @@ def _load_bed(eng, a, fs, cols):
             if a.gpca_stream == "off" or e.status != _lib.GPCA_ERR_OOM:
                 raise
             _log("the genotype matrix does not fit the device: walking it out of core")
-    src = PanelSource.host_bed(lambda r0, n: rows[r0:r0 + n]) if cols is None else PanelSource.host_i8(subset)
+    # the memory-mapped payload itself is the source (GPCA_PANEL_MAPPED_BED): the library's copy threads stage its panels, no callback
+    src = PanelSource.mapped_bed(rows) if cols is None else PanelSource.host_i8(subset)
     eng.stream_open(src, rows.shape[0], n_samples, panel_rows=a.gpca_panel_rows, cache_bytes=-1)
 
 

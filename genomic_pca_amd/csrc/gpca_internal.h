@@ -16,6 +16,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -63,21 +68,36 @@ struct TimingRec { std::string name; hipEvent_t a, b; double flops, bytes; };
 // One view of genotype rows in HBM: the whole resident matrix, or the panel currently in a ring slot (streamed mode).
 struct PanelView { const int8_t* g8; const uint8_t* g2; int64_t row0, rows, rows_pad; int index; };
 
-// Turns a gpca_panel_source into rows in device memory: device generators run on `st`; host callbacks fill one of two
-// pinned staging buffers, which is then copied (and, for .bed bytes / 2-bit storage, recoded) on `st`.
+// Turns a gpca_panel_source into rows in device memory: device generators run on `st`; host sources go through a ring of pinned
+// staging panels that a library-owned worker thread fills (callback, or the library's copy threads for MAPPED_* sources) up to
+// n_stage - 1 panels ahead of the one being copied to the device (and, for .bed bytes / 2-bit storage, recoded) on `st`; a MAPPED_*
+// source that could be page-locked in place is DMA-ed straight from the caller's memory (no staging, no worker).
 struct Filler {
     gpca_panel_source src{};
     int64_t chunk_rows = 0;          // most rows one fill() call may ask for
-    int64_t stage_ld = 0;            // bytes per row of the host staging buffers
+    int64_t stage_ld = 0;            // bytes per row of the host staging buffers (= bytes per row that travel)
     uint32_t* d_thresh = nullptr;    // SYNTH*: [M][n_pop]
     int8_t* d_scratch8 = nullptr;    // int8 rows on their way to 2-bit storage: [chunk_rows][ldg]
     uint8_t* d_raw = nullptr;        // .bed bytes on the device: [chunk_rows][bpr]
     unsigned* d_flags = nullptr;     // invalid-genotype flag of the pack kernel
-    void* h_stage[2] = {nullptr, nullptr};
-    hipEvent_t ev_stage[2] = {nullptr, nullptr};
-    char stage_pending[2] = {0, 0};
-    int stage_idx = 0;
     bool open = false;
+    // host sources
+    bool host = false, mapped = false, registered = false;
+    const uint8_t* map_base = nullptr; int64_t map_ld = 0; size_t reg_bytes = 0;
+    int device = 0, copy_threads = 1;
+    int n_stage = 0;
+    std::vector<void*> h_stage;
+    std::vector<hipEvent_t> ev_stage;
+    // staging ring state, guarded by m.  Both sides walk the buffers round-robin from a common origin: job #i uses buffer i % n_stage.
+    enum { kFree = 0, kReady = 1, kInFlight = 2 };
+    std::vector<int> st_state, st_rc;
+    std::vector<int64_t> st_row0;
+    std::deque<std::pair<int64_t, int64_t>> jobs;    // posted (row0, rows), not yet started
+    uint64_t posted = 0, produced = 0, consumed = 0;
+    bool busy = false, quit = false;
+    std::mutex m; std::condition_variable cv; std::thread worker;
+    // host-side accounting (gpca_stream_get_info)
+    int64_t fills = 0; double fill_host_ms = 0.0, fill_wait_ms = 0.0, register_ms = 0.0;
 };
 
 struct StreamState {
@@ -252,15 +272,16 @@ void free_ws(gpca_handle* h);
 void stream_close(gpca_handle* h);
 int finish_pack_flags(gpca_handle* h, unsigned* d_flags, hipStream_t st);
 int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst, hipStream_t st);
+void filler_post(Filler& f, int64_t row0, int64_t rows);   // tell the worker which rows filler_fill will ask for next (in this order)
+void filler_cancel(Filler& f);                              // drop what was posted and not consumed (a pass that ended early)
 // gpca_api.cpp
 int allreduce_f64(gpca_handle* h, double* dbuf, int64_t count);   // in-place sum across the ranks that share the sharded matrix
 hipError_t stream_wait(gpca_handle* h);
 int agree_status(gpca_handle* h, int local_rc, const char* where);
 
-// fn(view) once for the resident matrix, or once per panel (generated / copied one panel ahead on the fill stream)
+// fn(view) once for the resident matrix, or once per panel (generated / copied ahead on the fill stream)
 template <class F>
-inline int for_each_panel(gpca_handle* h, F&& fn) {
-    if (!h->sm.on) { const PanelView pv{h->dG, h->dG2, 0, h->M, h->Mpad, 0}; return fn(pv); }
+inline int for_each_panel_walk(gpca_handle* h, F&& fn) {
     StreamState& sm = h->sm;
     const bool packed = h->storage == GPCA_STORE_2BIT;
     const int64_t row_bytes = packed ? h->ld2 : h->ld8;
@@ -298,5 +319,20 @@ inline int for_each_panel(gpca_handle* h, F&& fn) {
         HIPCHK(hipEventRecord(sm.ev_free[s], h->st)); sm.free_pending[s] = 1;
     }
     return GPCA_OK;
+}
+template <class F>
+inline int for_each_panel(gpca_handle* h, F&& fn) {
+    if (!h->sm.on) { const PanelView pv{h->dG, h->dG2, 0, h->M, h->Mpad, 0}; return fn(pv); }
+    StreamState& sm = h->sm;
+    // the worker of a host source learns the whole sweep up front (every panel that will be asked of the source, in order) and
+    // stages ahead of the walk below
+    for (int p = 0; p < sm.n_panels; ++p) {
+        if (p < (int)sm.cache.size() && sm.cache_filled[p]) continue;
+        const int64_t row0 = (int64_t)p * sm.panel_rows;
+        filler_post(sm.fl, row0, std::min(sm.panel_rows, h->M - row0));
+    }
+    const int rc = for_each_panel_walk(h, fn);
+    if (rc != GPCA_OK) filler_cancel(sm.fl);    // a sweep that ended early leaves nothing posted behind
+    return rc;
 }
 

@@ -24,13 +24,95 @@ void free_ws(gpca_handle* h) {
     h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
     h->have_rsvd = false;
 }
-static void filler_close(Filler& f) {
-    dfree(f.d_thresh); dfree(f.d_scratch8); dfree(f.d_raw); dfree(f.d_flags);
-    for (int i = 0; i < 2; ++i) {
-        if (f.ev_stage[i]) { (void)hipEventSynchronize(f.ev_stage[i]); (void)hipEventDestroy(f.ev_stage[i]); f.ev_stage[i] = nullptr; }
-        if (f.h_stage[i]) { (void)hipHostFree(f.h_stage[i]); f.h_stage[i] = nullptr; }
-        f.stage_pending[i] = 0;
+static inline bool host_kind(int kind) { return kind == GPCA_PANEL_HOST_I8 || kind == GPCA_PANEL_HOST_BED || kind == GPCA_PANEL_MAPPED_I8 || kind == GPCA_PANEL_MAPPED_BED; }
+static inline bool bed_kind(int kind) { return kind == GPCA_PANEL_HOST_BED || kind == GPCA_PANEL_MAPPED_BED; }
+static inline bool mapped_kind(int kind) { return kind == GPCA_PANEL_MAPPED_I8 || kind == GPCA_PANEL_MAPPED_BED; }
+static inline double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// rows [row0, row0 + rows) of a MAPPED_* source -> staging, by f.copy_threads threads (one memcpy stream runs at 10-15 GB/s on
+// this class of host; the link wants > 50)
+static void copy_mapped_rows(const Filler& f, int64_t row0, int64_t rows, void* dst) {
+    const int64_t w = f.stage_ld;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(f.copy_threads, rows * w / (4 << 20)));   // >= 4 MiB per thread
+    auto part = [&](int t) {
+        const int64_t a = rows * t / T, b = rows * (t + 1) / T;
+        const uint8_t* src = f.map_base + (size_t)(row0 + a) * (size_t)f.map_ld;
+        uint8_t* d = (uint8_t*)dst + (size_t)a * (size_t)w;
+        if (f.map_ld == w) memcpy(d, src, (size_t)(b - a) * (size_t)w);
+        else for (int64_t r = a; r < b; ++r, src += f.map_ld, d += w) memcpy(d, src, (size_t)w);
+    };
+    if (T == 1) { part(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(part, t);
+    part(0);
+    for (auto& x : th) x.join();
+}
+
+// The worker of a host source: stages posted panels in order, up to n_stage - 1 ahead of the pass thread.
+static void filler_worker(Filler* f) {
+    (void)hipSetDevice(f->device);
+    std::unique_lock<std::mutex> lk(f->m);
+    for (;;) {
+        // next job when its buffer is not holding a staged panel the pass thread has yet to take
+        f->cv.wait(lk, [&] { return f->quit || (!f->jobs.empty() && f->st_state[(size_t)(f->produced % (uint64_t)f->n_stage)] != Filler::kReady); });
+        if (f->quit) return;
+        const size_t b = (size_t)(f->produced % (uint64_t)f->n_stage);
+        const std::pair<int64_t, int64_t> job = f->jobs.front();
+        f->jobs.pop_front();
+        f->busy = true;
+        const bool in_flight = f->st_state[b] == Filler::kInFlight;
+        lk.unlock();
+        if (in_flight) (void)hipEventSynchronize(f->ev_stage[b]);      // its last H2D copy has left the buffer
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = 0;
+        if (f->mapped) copy_mapped_rows(*f, job.first, job.second, f->h_stage[b]);
+        else rc = f->src.fill(f->src.user, job.first, job.second, f->h_stage[b], f->stage_ld);
+        const double ms = ms_since(t0);
+        lk.lock();
+        f->fill_host_ms += ms;
+        f->st_state[b] = Filler::kReady; f->st_rc[b] = rc; f->st_row0[b] = job.first;
+        f->produced++; f->busy = false;
+        if (rc != 0) f->jobs.clear();          // no further panel is asked after a failure
+        f->cv.notify_all();
     }
+}
+
+void filler_post(Filler& f, int64_t row0, int64_t rows) {
+    if (!f.worker.joinable()) return;          // device generator or zero-staging: nothing to stage
+    std::lock_guard<std::mutex> lk(f.m);
+    f.jobs.emplace_back(row0, rows); f.posted++;
+    f.cv.notify_all();
+}
+
+void filler_cancel(Filler& f) {
+    if (!f.worker.joinable()) return;
+    std::unique_lock<std::mutex> lk(f.m);
+    f.jobs.clear();
+    f.cv.wait(lk, [&] { return !f.busy; });
+    for (size_t b = 0; b < f.st_state.size(); ++b) {
+        if (f.st_state[b] == Filler::kInFlight) (void)hipEventSynchronize(f.ev_stage[b]);
+        f.st_state[b] = Filler::kFree;
+    }
+    f.posted = f.produced = f.consumed = 0;
+}
+
+static void filler_close(Filler& f) {
+    if (f.worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(f.m); f.quit = true; f.jobs.clear(); }
+        f.cv.notify_all();
+        f.worker.join();
+    }
+    f.quit = false; f.busy = false; f.jobs.clear(); f.posted = f.produced = f.consumed = 0;
+    dfree(f.d_thresh); dfree(f.d_scratch8); dfree(f.d_raw); dfree(f.d_flags);
+    for (size_t i = 0; i < f.h_stage.size(); ++i) {
+        if (f.ev_stage[i]) { (void)hipEventSynchronize(f.ev_stage[i]); (void)hipEventDestroy(f.ev_stage[i]); }
+        if (f.h_stage[i]) (void)hipHostFree(f.h_stage[i]);
+    }
+    f.h_stage.clear(); f.ev_stage.clear(); f.st_state.clear(); f.st_rc.clear(); f.st_row0.clear(); f.n_stage = 0;
+    if (f.registered) { (void)hipHostUnregister((void*)f.map_base); f.registered = false; }
+    f.host = f.mapped = false; f.map_base = nullptr;
     f.open = false;
 }
 void stream_close(gpca_handle* h) {
@@ -165,6 +247,9 @@ static int check_source(gpca_handle* h, const gpca_panel_source* src, const char
         case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED:
             if (!src->fill) return fail(h, GPCA_ERR_BAD_ARG, std::string(who) + ": host panel source without a fill callback");
             return GPCA_OK;
+        case GPCA_PANEL_MAPPED_I8: case GPCA_PANEL_MAPPED_BED:
+            if (!src->user || src->host_ld < 0) return fail(h, GPCA_ERR_BAD_ARG, std::string(who) + ": mapped source needs user = address of row 0 and host_ld >= 0");
+            return GPCA_OK;
         case GPCA_PANEL_SYNTH: case GPCA_PANEL_SYNTH16:
             if (!src->thresh || src->n_pop <= 0 || src->snp_offset < 0) return fail(h, GPCA_ERR_BAD_ARG, std::string(who) + ": generator source needs thresh, n_pop > 0, snp_offset >= 0");
             return GPCA_OK;
@@ -172,11 +257,15 @@ static int check_source(gpca_handle* h, const gpca_panel_source* src, const char
     }
 }
 
+static int env_int_r(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 // staging of one source for chunks of up to chunk_rows rows of the handle's current M x N matrix
 static int filler_open(gpca_handle* h, Filler& f, const gpca_panel_source& src, int64_t chunk_rows, hipStream_t st) {
     filler_close(f);
-    f.src = src; f.chunk_rows = chunk_rows; f.stage_idx = 0;
+    f.src = src; f.chunk_rows = chunk_rows;
     f.open = true;
+    f.device = h->device;
+    f.fills = 0; f.fill_host_ms = f.fill_wait_ms = f.register_ms = 0.0;
     const bool packed = h->storage == GPCA_STORE_2BIT;
     if (src.kind == GPCA_PANEL_SYNTH || src.kind == GPCA_PANEL_SYNTH16) {
         const size_t tb = (size_t)h->M * (size_t)src.n_pop * sizeof(uint32_t);
@@ -184,22 +273,63 @@ static int filler_open(gpca_handle* h, Filler& f, const gpca_panel_source& src, 
         HIPCHK(hipMemcpyAsync(f.d_thresh, src.thresh, tb, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));   // the caller's table may be freed after open
     }
-    if (packed && (src.kind == GPCA_PANEL_SYNTH || src.kind == GPCA_PANEL_HOST_I8)) {
+    const bool i8_rows = src.kind == GPCA_PANEL_SYNTH || src.kind == GPCA_PANEL_HOST_I8 || src.kind == GPCA_PANEL_MAPPED_I8;
+    if (packed && i8_rows) {
         HIPCHK(hipMalloc((void**)&f.d_scratch8, (size_t)chunk_rows * (size_t)h->ldg));
         HIPCHK(hipMemsetAsync(f.d_scratch8, 0, (size_t)chunk_rows * (size_t)h->ldg, st));   // pad columns stay 0
         HIPCHK(hipMalloc((void**)&f.d_flags, 16));
         HIPCHK(hipMemsetAsync(f.d_flags, 0, 16, st));
     }
-    if (src.kind == GPCA_PANEL_HOST_BED) {
-        f.stage_ld = (h->N + 3) / 4;
-        HIPCHK(hipMalloc((void**)&f.d_raw, (size_t)chunk_rows * (size_t)f.stage_ld));
-    }
-    if (src.kind == GPCA_PANEL_HOST_I8) f.stage_ld = h->N;
-    if (src.kind == GPCA_PANEL_HOST_I8 || src.kind == GPCA_PANEL_HOST_BED) {
-        for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipHostMalloc(&f.h_stage[i], (size_t)chunk_rows * (size_t)f.stage_ld, hipHostMallocDefault));
-            HIPCHK(hipEventCreateWithFlags(&f.ev_stage[i], hipEventDisableTiming));
+    if (!host_kind(src.kind)) return GPCA_OK;
+    f.host = true;
+    f.stage_ld = bed_kind(src.kind) ? (h->N + 3) / 4 : h->N;
+    if (bed_kind(src.kind)) HIPCHK(hipMalloc((void**)&f.d_raw, (size_t)chunk_rows * (size_t)f.stage_ld));
+    if (mapped_kind(src.kind)) {
+        f.mapped = true;
+        f.map_base = (const uint8_t*)src.user;
+        f.map_ld = src.host_ld > 0 ? src.host_ld : f.stage_ld;
+        if (f.map_ld < f.stage_ld) return fail(h, GPCA_ERR_BAD_ARG, "mapped panel source: host_ld is smaller than a row");
+        f.copy_threads = std::max(1, std::min({env_int_r("GPCA_COPY_THREADS", 8), 64, (int)std::max(1u, std::thread::hardware_concurrency())}));
+        if ((src.flags & GPCA_SOURCE_REGISTER) && env_int_r("GPCA_SOURCE_REGISTER", 1) != 0) {
+            // zero staging: lock the caller's pages once, DMA every panel straight out of them.  A mapping that cannot be locked
+            // (a file larger than RAM, RLIMIT_MEMLOCK, a read-only mapping the driver refuses) falls back to the staging ring.
+            const size_t bytes = (size_t)(h->M - 1) * (size_t)f.map_ld + (size_t)f.stage_ld;
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t e = hipHostRegister((void*)f.map_base, bytes, hipHostRegisterDefault);
+            if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister((void*)f.map_base, bytes, hipHostRegisterReadOnly); }
+            if (e == hipSuccess) { f.registered = true; f.reg_bytes = bytes; f.register_ms = ms_since(t0); return GPCA_OK; }
+            (void)hipGetLastError();
         }
+    }
+    f.n_stage = std::max(2, std::min(8, env_int_r("GPCA_STAGE_BUFFERS", 3)));
+    for (int i = 0; i < f.n_stage; ++i) {
+        void* p = nullptr; hipEvent_t e = nullptr;
+        HIPCHK(hipHostMalloc(&p, (size_t)chunk_rows * (size_t)f.stage_ld, hipHostMallocDefault));
+        f.h_stage.push_back(p); f.ev_stage.push_back(nullptr);
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        f.ev_stage.back() = e;
+    }
+    f.st_state.assign((size_t)f.n_stage, Filler::kFree); f.st_rc.assign((size_t)f.n_stage, 0); f.st_row0.assign((size_t)f.n_stage, -1);
+    f.posted = f.produced = f.consumed = 0; f.quit = false; f.busy = false;
+    f.worker = std::thread(filler_worker, &f);
+    return GPCA_OK;
+}
+
+// host rows (pinned staging, or the caller's page-locked mapping) of pitch src_ld -> dst on the device, enqueued on st
+static int host_rows_to_device(gpca_handle* h, Filler& f, const void* src, int64_t src_ld, int64_t rows, void* dst, hipStream_t st) {
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    if (bed_kind(f.src.kind)) {
+        if (src_ld == f.stage_ld) HIPCHK(hipMemcpyAsync(f.d_raw, src, (size_t)rows * (size_t)f.stage_ld, hipMemcpyHostToDevice, st));
+        else HIPCHK(hipMemcpy2DAsync(f.d_raw, (size_t)f.stage_ld, src, (size_t)src_ld, (size_t)f.stage_ld, (size_t)rows, hipMemcpyHostToDevice, st));
+        if (packed) launch_bed_to_codes(st, f.d_raw, f.stage_ld, (uint8_t*)dst, rows, h->N, h->ld2);
+        else launch_bed_decode(st, f.d_raw, f.stage_ld, (int8_t*)dst, rows, h->N, h->ld8);
+        HIPCHK(hipGetLastError());
+    } else if (packed) {
+        HIPCHK(hipMemcpy2DAsync(f.d_scratch8, (size_t)h->ldg, src, (size_t)src_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
+        launch_pack_i8(st, f.d_scratch8, h->ldg, (uint8_t*)dst, rows, h->N, h->ld2, f.d_flags);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)h->ld8, src, (size_t)src_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
     }
     return GPCA_OK;
 }
@@ -220,27 +350,41 @@ int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst
             launch_synth16(st, dst, packed ? 1 : 0, rows, h->N, packed ? h->ld2 : h->ld8, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
             HIPCHK(hipGetLastError());
             return GPCA_OK;
-        case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED: {
-            const int b = f.stage_idx; f.stage_idx ^= 1;
-            if (f.stage_pending[b]) { HIPCHK(hipEventSynchronize(f.ev_stage[b])); f.stage_pending[b] = 0; }   // its last copy has left the buffer
-            if (s.fill(s.user, row0, rows, f.h_stage[b], f.stage_ld) != 0) {
-                char buf[160];
-                snprintf(buf, sizeof buf, "panel source callback failed for rows [%lld, %lld)", (long long)row0, (long long)(row0 + rows));
+        case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED: case GPCA_PANEL_MAPPED_I8: case GPCA_PANEL_MAPPED_BED: {
+            if (rows > f.chunk_rows) return fail(h, GPCA_ERR_BAD_ARG, "panel source: more rows asked than the staging holds");
+            f.fills++;
+            if (f.registered)      // zero staging: straight out of the caller's page-locked mapping
+                return host_rows_to_device(h, f, f.map_base + (size_t)row0 * (size_t)f.map_ld, f.map_ld, rows, dst, st);
+            size_t b;
+            int rc;
+            {
+                std::unique_lock<std::mutex> lk(f.m);
+                if (f.consumed == f.posted) { f.jobs.emplace_back(row0, rows); f.posted++; f.cv.notify_all(); }   // (not announced by filler_post)
+                b = (size_t)(f.consumed % (uint64_t)f.n_stage);
+                const auto t0 = std::chrono::steady_clock::now();
+                const bool waited = !(f.st_state[b] == Filler::kReady && f.produced > f.consumed);
+                f.cv.wait(lk, [&] { return f.st_state[b] == Filler::kReady && f.produced > f.consumed; });
+                if (waited) f.fill_wait_ms += ms_since(t0);
+                rc = f.st_rc[b];
+                if (rc == 0 && f.st_row0[b] != row0) rc = -1;      // (the walk asked for rows other than the ones it posted)
+            }
+            if (rc != 0) {
+                filler_cancel(f);
+                char buf[200];
+                if (rc == -1) snprintf(buf, sizeof buf, "panel source: internal order mismatch at rows [%lld, %lld)", (long long)row0, (long long)(row0 + rows));
+                else snprintf(buf, sizeof buf, "panel source callback failed for rows [%lld, %lld)", (long long)row0, (long long)(row0 + rows));
                 return fail(h, GPCA_ERR_BAD_ARG, buf);
             }
-            if (s.kind == GPCA_PANEL_HOST_BED) {
-                HIPCHK(hipMemcpyAsync(f.d_raw, f.h_stage[b], (size_t)rows * (size_t)f.stage_ld, hipMemcpyHostToDevice, st));
-                if (packed) launch_bed_to_codes(st, f.d_raw, f.stage_ld, (uint8_t*)dst, rows, h->N, h->ld2);
-                else launch_bed_decode(st, f.d_raw, f.stage_ld, (int8_t*)dst, rows, h->N, h->ld8);
-                HIPCHK(hipGetLastError());
-            } else if (packed) {
-                HIPCHK(hipMemcpy2DAsync(f.d_scratch8, (size_t)h->ldg, f.h_stage[b], (size_t)f.stage_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
-                launch_pack_i8(st, f.d_scratch8, h->ldg, (uint8_t*)dst, rows, h->N, h->ld2, f.d_flags);
-                HIPCHK(hipGetLastError());
-            } else {
-                HIPCHK(hipMemcpy2DAsync(dst, (size_t)h->ld8, f.h_stage[b], (size_t)f.stage_ld, (size_t)h->N, (size_t)rows, hipMemcpyHostToDevice, st));
+            int erc = host_rows_to_device(h, f, f.h_stage[b], f.stage_ld, rows, dst, st);
+            hipError_t ee = erc == GPCA_OK ? hipEventRecord(f.ev_stage[b], st) : hipSuccess;
+            {
+                std::lock_guard<std::mutex> lk(f.m);
+                // (on failure the buffer goes back as "in flight" too: its event is whatever was recorded last, long complete)
+                f.st_state[b] = Filler::kInFlight; f.consumed++;
+                f.cv.notify_all();
             }
-            HIPCHK(hipEventRecord(f.ev_stage[b], st)); f.stage_pending[b] = 1;
+            if (erc != GPCA_OK) return erc;
+            HIPCHK(ee);
             return GPCA_OK;
         }
         default: return fail(h, GPCA_ERR_BAD_ARG, "unknown panel kind");
@@ -257,6 +401,7 @@ extern "C" int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* sr
     const int64_t cr = pack_chunk_rows(h);
     Filler f;
     int rc = filler_open(h, f, *src, cr, h->st);
+    if (rc == GPCA_OK) for (int64_t r0 = 0; r0 < M; r0 += cr) filler_post(f, r0, std::min(cr, M - r0));   // the worker stages ahead of the loop below
     for (int64_t r0 = 0; r0 < M && rc == GPCA_OK; r0 += cr) {
         const int64_t rows = std::min(cr, M - r0);
         void* dst = packed ? (void*)(h->dG2 + (size_t)r0 * h->ld2) : (void*)(h->dG + (size_t)r0 * h->ld8);
@@ -290,10 +435,10 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
         int64_t rows = (int64_t)h->gq_waves_target * kGQRowsPerWave;
         const int64_t fit = (int64_t)(budget / ((double)ring_slots * (double)row_bytes));
         if (rows > fit) rows = fit;
-        if (src->kind == GPCA_PANEL_HOST_I8 || src->kind == GPCA_PANEL_HOST_BED) {
-            // callback sources also need two pinned host staging panels: keep each within 2 GiB (such a source is bound by the
-            // host link, ~55 GB/s, long before the row-parallel K1 runs out of rows)
-            const int64_t host_ld = src->kind == GPCA_PANEL_HOST_BED ? (N + 3) / 4 : N;
+        if (host_kind(src->kind)) {
+            // host sources also need pinned host staging panels (three by default): keep each within 2 GiB (such a source is bound by
+            // the host link, ~55 GB/s, long before the row-parallel K1 runs out of rows)
+            const int64_t host_ld = bed_kind(src->kind) ? (N + 3) / 4 : N;
             const int64_t cap = ((int64_t)2 << 30) / host_ld;
             if (rows > cap) rows = cap;
         }
@@ -379,6 +524,20 @@ extern "C" int gpca_stream_set_cache(gpca_handle* h, int64_t max_bytes, int32_t*
     }
     if (n_cached) *n_cached = (int32_t)sm.cache.size();
     return rc;
+}
+
+extern "C" int gpca_stream_get_info(gpca_handle* h, gpca_stream_info* out) {
+    if (!h || !out) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    StreamState& sm = h->sm;
+    if (!sm.on) return fail(h, GPCA_ERR_STATE, "gpca_stream_get_info: no panel stream open");
+    memset(out, 0, sizeof *out);
+    out->panel_rows = sm.panel_rows; out->n_panels = sm.n_panels; out->ring_slots = sm.ring; out->n_cached = (int32_t)sm.cache.size();
+    Filler& f = sm.fl;
+    std::lock_guard<std::mutex> lk(f.m);
+    out->staging_buffers = f.n_stage; out->zero_staging = f.registered ? 1 : 0; out->copy_threads = f.mapped && !f.registered ? f.copy_threads : 0;
+    out->fills = f.fills; out->fill_host_ms = f.fill_host_ms; out->fill_wait_ms = f.fill_wait_ms; out->register_ms = f.register_ms;
+    return GPCA_OK;
 }
 
 extern "C" int gpca_download_genotypes_i8(gpca_handle* h, int8_t* out, int64_t ld) {

@@ -55,8 +55,10 @@ class PanelSource:
     (``GpcaEngine.stream_open``; BASELINE.json configs[4]).  The reference's analogue is the accessor's strip pull loop
     (main.rs:322,584; prepare.rs:1839-2022)."""
 
-    def __init__(self, kind: int, fill=None, thresh: Optional[np.ndarray] = None, seed: int = 0, snp_offset: int = 0):
+    def __init__(self, kind: int, fill=None, thresh: Optional[np.ndarray] = None, seed: int = 0, snp_offset: int = 0,
+                 mapped: Optional[np.ndarray] = None, flags: int = 0):
         self.kind = kind
+        self.mapped, self.flags = mapped, int(flags)
         self.thresh = None if thresh is None else np.ascontiguousarray(thresh, np.uint32)
         self.seed, self.snp_offset = int(seed), int(snp_offset)
         self._fill = fill
@@ -84,6 +86,10 @@ class PanelSource:
         if self.thresh is not None:
             st.n_pop = self.thresh.shape[1]
             st.thresh = self.thresh.ctypes.data_as(C.c_void_p)
+        if self.mapped is not None:
+            st.user = self.mapped.ctypes.data_as(C.c_void_p)
+            st.host_ld = self.mapped.strides[0]
+            st.flags = self.flags
         return st
 
     @staticmethod
@@ -93,6 +99,24 @@ class PanelSource:
     @staticmethod
     def host_bed(fn):
         return PanelSource(_lib.PANEL_HOST_BED, fill=fn)
+
+    @staticmethod
+    def _mapped(kind, a, want, register):
+        a = np.asarray(a)
+        if a.dtype != want or a.ndim != 2 or (a.shape[1] > 1 and a.strides[1] != 1) or a.strides[0] < a.shape[1]:
+            raise ValueError(f"mapped panel source: a 2-D {np.dtype(want).name} array with contiguous rows is required")
+        return PanelSource(kind, mapped=a, flags=_lib.SOURCE_REGISTER if register else 0)
+
+    @staticmethod
+    def mapped_i8(a, register=False):
+        """The whole int8 matrix [M, N] in host memory (an ndarray or np.memmap; rows contiguous, any row pitch): no callback, the
+        library's copy threads stage the panels -- or, register=True, the pages are locked once and DMA-ed in place."""
+        return PanelSource._mapped(_lib.PANEL_MAPPED_I8, a, np.int8, register)
+
+    @staticmethod
+    def mapped_bed(a, register=False):
+        """The .bed payload [M, ceil(N/4)] uint8 in host memory (e.g. np.memmap of the file past its 3-byte magic)."""
+        return PanelSource._mapped(_lib.PANEL_MAPPED_BED, a, np.uint8, register)
 
     @staticmethod
     def synth(thresh, seed, snp_offset=0):
@@ -193,6 +217,12 @@ class GpcaEngine:
         self._chk(self._lib.gpca_stream_set_fused(self._h, int(fused)))
         if cache_bytes:
             self.stream_set_cache(cache_bytes)
+
+    def stream_info(self) -> dict:
+        """gpca_stream_get_info: shape of the open panel stream and where its host-side time went."""
+        info = _lib.gpca_stream_info()
+        self._chk(self._lib.gpca_stream_get_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
 
     def stream_set_cache(self, max_bytes: int = -1) -> int:
         """Keep the leading panels in spare HBM (asked of the source once, read in place afterwards); returns how many."""

@@ -222,12 +222,6 @@ extern "C" int fill_kept_columns(void* user, int64_t row0, int64_t rows, void* d
     }
     return 0;
 }
-extern "C" int fill_bed_rows(void* user, int64_t row0, int64_t rows, void* dst, int64_t ld) {
-    const gpca_host::PlinkFileset* fs = static_cast<const gpca_host::PlinkFileset*>(user);
-    for (int64_t r = 0; r < rows; ++r) std::memcpy(static_cast<uint8_t*>(dst) + r * ld, fs->bed_rows + (row0 + r) * fs->bytes_per_row, (size_t)fs->bytes_per_row);
-    return 0;
-}
-
 // The .bed payload into the engine: resident, or -- when it does not fit the device, or on request -- out of core with the
 // HBM panel cache on (cli.py:_load_bed; the reference pulls strips through the accessor on every pass, main.rs:322).
 void load_bed(gpca::Engine& eng, const Args& a, const gpca_host::PlinkFileset& fs, KeptColumns* kept) {
@@ -235,7 +229,9 @@ void load_bed(gpca::Engine& eng, const Args& a, const gpca_host::PlinkFileset& f
     std::memset(&src, 0, sizeof src);
     const int64_t n_samples = kept ? (int64_t)kept->cols.size() : fs.n_samples;
     if (kept) { src.kind = GPCA_PANEL_HOST_I8; src.fill = fill_kept_columns; src.user = kept; }
-    else { src.kind = GPCA_PANEL_HOST_BED; src.fill = fill_bed_rows; src.user = const_cast<gpca_host::PlinkFileset*>(&fs); }
+    else {   // the memory-mapped payload itself is the source: the library's copy threads stage its panels, no callback
+        src.kind = GPCA_PANEL_MAPPED_BED; src.user = const_cast<uint8_t*>(fs.bed_rows); src.host_ld = fs.bytes_per_row;
+    }
     std::string mode = a.stream;
     if (mode == "auto") {
         // resident needs the matrix (1 B or 0.25 B per genotype, rows padded) plus the solver's workspace (gpca.h,

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GPCA_VERSION 220 /* 0.2.2: + gpca_stream_set_cache, gpca_get_device_memory, the EigenSNP stage calls */
+#define GPCA_VERSION 230 /* 0.2.3: + mapped host sources (zero-staging), staging ring filled by a worker thread, gpca_stream_get_info */
 #define GPCA_MISSING_I8 (-127) /* bed_reader i8 missing code, prepare.rs:1224 */
 
 typedef struct gpca_handle gpca_handle;
@@ -121,31 +121,47 @@ typedef enum gpca_panel_kind {
     GPCA_PANEL_HOST_I8 = 0,  /* `fill` writes int8 SNP-major rows (0/1/2, -127 missing), row pitch ld = N */
     GPCA_PANEL_HOST_BED = 1, /* `fill` writes PLINK .bed rows (2 bits/sample, count_a1 decode), row pitch ld = ceil(N/4) */
     GPCA_PANEL_SYNTH = 2,    /* device generator of gpca_synth_genotypes: thresh = uint32 [M][n_pop] = floor(p * 2^32) */
-    GPCA_PANEL_SYNTH16 = 3   /* fast device generator, one 16-bit uniform per genotype (SplitMix64 in counter mode): thresh = uint32 [M][n_pop],
+    GPCA_PANEL_SYNTH16 = 3,  /* fast device generator, one 16-bit uniform per genotype (SplitMix64 in counter mode): thresh = uint32 [M][n_pop],
                                 high half = floor(P(g >= 1) * 65536), low half = floor(P(g = 2) * 65536); sample n belongs to
                                 population (n / 16) % n_pop */
+    /* The whole matrix sits in the caller's address space (malloc'ed, or a memory-mapped .bed payload: what bed_reader opens at
+     * prepare.rs:622-629): `user` = address of row 0, `host_ld` = row pitch in bytes (0 = tight: N, or ceil(N/4)).  No callback:
+     * the library's own copy threads move the rows of a panel into its pinned staging ring, or -- GPCA_SOURCE_REGISTER -- the
+     * mapping is page-locked once at open and every panel is DMA-ed straight out of it (no staging copy at all).  The memory must
+     * stay valid and unchanged until the stream is closed (gpca_stream_open) or the call returns (gpca_load_from_source). */
+    GPCA_PANEL_MAPPED_I8 = 4,
+    GPCA_PANEL_MAPPED_BED = 5
 } gpca_panel_kind;
+/* gpca_panel_source.flags */
+#define GPCA_SOURCE_REGISTER 1 /* MAPPED_*: hipHostRegister the mapping at open (zero staging); if the pages cannot be locked the
+                                  staged path is used instead -- gpca_stream_get_info reports which */
 /* Write rows [row0, row0 + rows) of the matrix into dst (pinned host memory owned by the library).  Return 0, or
- * non-zero to abort the pass (reported as GPCA_ERR_BAD_ARG with the row range in the message).  Called on the thread that runs
- * the pass, with the handle's lock held: it may block on I/O, it must not wait for another thread that calls into the same handle. */
+ * non-zero to abort the pass (reported as GPCA_ERR_BAD_ARG with the row range in the message).
+ * Threading: called from ONE library-owned worker thread per source (never concurrently with itself), rows ascending within a
+ * pass, up to staging_buffers - 1 panels ahead of the panel being copied to the device -- so the host copy of panel p + 2
+ * overlaps the H2D copy of p + 1 and the GEMMs of p.  It runs while a pass (gpca_snp_stats / gpca_rsvd / gpca_transform /
+ * gpca_load_from_source) is in progress on another thread, which holds the handle's lock: it may block on I/O, it must not
+ * call into the same handle.  Every panel is asked exactly once per pass (cached panels once in all); after a failure no
+ * further panel is asked in that pass. */
 typedef int (*gpca_panel_fn)(void* user, int64_t row0, int64_t rows, void* dst, int64_t ld);
 typedef struct gpca_panel_source {
     int32_t kind;           /* gpca_panel_kind */
     int32_t n_pop;          /* SYNTH*: populations (columns of thresh) */
-    gpca_panel_fn fill;     /* HOST_*: called from the thread that runs the pass, once per panel per pass, rows ascending */
-    void* user;
+    gpca_panel_fn fill;     /* HOST_*: the callback above */
+    void* user;             /* HOST_*: passed to fill; MAPPED_*: address of row 0 */
     const uint32_t* thresh; /* SYNTH*: host table, copied to the device at open */
     uint64_t seed;          /* SYNTH* */
     int64_t snp_offset;     /* SYNTH*: global index of row 0 (row shards of one matrix draw the rows they would unsharded) */
-    int64_t reserved[2];
+    int64_t host_ld;        /* MAPPED_*: row pitch in bytes (0 = tight) */
+    int64_t flags;          /* GPCA_SOURCE_* */
 } gpca_panel_source;
 /* Resident load through a panel source (chunked through bounded staging: a 250 GB .bed needs no second device copy). */
 GPCA_API int gpca_load_from_source(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N);
 /* Out-of-core mode: the matrix is never resident.  Every pass of gpca_snp_stats / gpca_rsvd / gpca_transform walks
  * ceil(M / panel_rows) panels through a ring of `ring_slots` (>= 2) HBM panel buffers; panel p + 1 is generated or
  * copied on a second stream while panel p is multiplied.  panel_rows is rounded up to a multiple of 128; 0 picks
- * 131 072 rows (a full grid of the row-parallel GEMM) or as many as fit the ring in half of the free HBM (callback sources: at most
- * 2 GiB of pinned host staging per panel).  Requires GPCA_PREC_I8_EXACT (either storage).  With gpca_stream_set_fused(h, 0) the
+ * 131 072 rows (a full grid of the row-parallel GEMM) or as many as fit the ring in half of the free HBM (host sources: at most
+ * 2 GiB of pinned host staging per panel, three staging panels -- GPCA_STAGE_BUFFERS=2..8).  Requires GPCA_PREC_I8_EXACT (either storage).  With gpca_stream_set_fused(h, 0) the
  * results are bit-identical to the resident engine on the same matrix; the default (fused) form is described below.  The pull API
  * (gpca_standardize_block) and gpca_download_genotypes_i8 need a resident matrix. */
 GPCA_API int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, int64_t M, int64_t N, int64_t panel_rows,
@@ -163,6 +179,20 @@ GPCA_API int gpca_stream_set_fused(gpca_handle* h, int32_t fused);
  * return the same rows every time it is asked (it must anyway: every pass re-reads it).  Results do not change.
  * *n_cached (may be NULL) receives the number of cached panels.  GPCA_ERR_OOM keeps the panels allocated so far. */
 GPCA_API int gpca_stream_set_cache(gpca_handle* h, int64_t max_bytes, int32_t* n_cached);
+/* What the open panel stream looks like, and where its time went since gpca_stream_open (host-side, always collected). */
+typedef struct gpca_stream_info {
+    int64_t panel_rows;
+    int32_t n_panels, ring_slots, n_cached;
+    int32_t staging_buffers; /* pinned host staging panels (0: device generator, or zero-staging) */
+    int32_t zero_staging;    /* 1 = MAPPED_* source page-locked in place, panels DMA-ed straight from the caller's memory */
+    int32_t copy_threads;    /* MAPPED_* staged: threads that copy a panel into staging */
+    int64_t fills;           /* panels asked of the source so far */
+    double fill_host_ms;     /* host time spent producing panels into staging (callback / copy threads), summed over the worker's jobs */
+    double fill_wait_ms;     /* time the pass thread waited for a staged panel that was not ready yet: > 0 = the source is the bottleneck */
+    double register_ms;      /* hipHostRegister at open (zero-staging) */
+    int64_t reserved[4];
+} gpca_stream_info;
+GPCA_API int gpca_stream_get_info(gpca_handle* h, gpca_stream_info* out);
 GPCA_API int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N);
 /* Free and total memory of the handle's device in bytes (hipMemGetInfo): what a host needs to choose between a resident load
  * (M x N bytes int8, M x N / 4 packed, plus about 1 KiB per SNP row and 8 KiB per sample of workspace) and gpca_stream_open. */

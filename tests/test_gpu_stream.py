@@ -161,6 +161,85 @@ def test_streamed_equals_resident_bitwise(gpca, oracle, store, kind):
     assert oracle.max_abs_dpc(stm["ld"].astype(np.float64), R["loadings"][ref["keep"].astype(bool)]) < 1e-4
 
 
+@pytest.mark.parametrize("store", ["int8", "2bit"])
+@pytest.mark.parametrize("kind,register", [("mapped_i8", False), ("mapped_i8", True), ("mapped_bed", False), ("mapped_bed", True)])
+def test_mapped_sources_equal_resident_bitwise(gpca, oracle, store, kind, register, monkeypatch):
+    """GPCA_PANEL_MAPPED_*: the whole matrix sits in host memory (here with a row pitch wider than a row, as a padded mapping has);
+    no callback -- the library's copy threads stage the panels, or (register) the pages are locked once and every panel is DMA-ed
+    in place.  Same bits as the resident engine, for the resident load and for the out-of-core walk."""
+    M, N, k, seed = 20_000, 1003, 8, 2
+    G = oracle.synth_genotypes(M, N, seed, gpca.synth_thresholds(M, 6, seed=seed, fst=0.2))
+    G[np.random.default_rng(5).random(G.shape) < 0.003] = -127
+    if kind == "mapped_i8":
+        wide = np.zeros((M, N + 37), np.int8); wide[:, :N] = G; view = wide[:, :N]
+        src = lambda: gpca.PanelSource.mapped_i8(view, register=register)
+    else:
+        bed = _encode_bed(G)
+        wide = np.zeros((M, bed.shape[1] + 5), np.uint8); wide[:, :bed.shape[1]] = bed; view = wide[:, :bed.shape[1]]
+        src = lambda: gpca.PanelSource.mapped_bed(view, register=register)
+    monkeypatch.setenv("GPCA_COPY_THREADS", "3")
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.upload_genotypes_i8(G)
+        res = _run(e, k, seed, gpca.QcConfig())
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.load_from_source(src(), M, N)
+        assert np.array_equal(e.download_genotypes_i8(), G)
+        _same(res, _run(e, k, seed, gpca.QcConfig()))
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.stream_open(src(), M, N, panel_rows=4096, ring_slots=2, fused=False)
+        stm = _run(e, k, seed, gpca.QcConfig())
+        info = e.stream_info()
+        assert info["n_panels"] == 5 and info["panel_rows"] == 4096 and info["ring_slots"] == 2
+        assert info["fills"] == 5 * 8                                   # stats + 6 sweeps + transform
+        if info["zero_staging"]:
+            assert register and info["staging_buffers"] == 0 and info["copy_threads"] == 0
+        else:                                                           # (register may be refused by the driver: the staged path then)
+            assert info["staging_buffers"] == 3 and info["copy_threads"] == 3 and info["fill_host_ms"] > 0
+        if not register:
+            assert not info["zero_staging"]
+    _same(res, stm)
+    with pytest.raises(ValueError):
+        gpca.PanelSource.mapped_i8(np.zeros((4, 4), np.uint8))
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        with pytest.raises(gpca.GpcaError) as err:                      # a pitch smaller than a row is refused
+            bad = gpca.PanelSource.mapped_i8(view); cs = bad.c_struct(); cs.host_ld = 7
+            e._chk(e._lib.gpca_stream_open(e._h, __import__("ctypes").byref(cs), M, N, 4096, 2))
+        assert err.value.status == -1
+
+
+def test_host_callback_runs_ahead_on_the_worker_and_recovers_from_a_failure(gpca, oracle):
+    """The fill callback runs on a library-owned worker thread, in row order, every panel once per pass, up to two panels ahead;
+    a failing panel aborts the pass with its row range (no further panel is asked in that pass) and the next pass works."""
+    M, N, pr, k, seed = 12_000, 500, 2048, 5, 3
+    G = oracle.synth_genotypes(M, N, seed, gpca.synth_thresholds(M, 4, seed=seed, fst=0.2))
+    calls, threads, fail_at = [], set(), [None]
+
+    def rows_i8(row0, rows):
+        threads.add(threading.get_ident()); calls.append(row0)
+        if fail_at[0] is not None and row0 == fail_at[0]:
+            raise RuntimeError("disk on fire")
+        return G[row0:row0 + rows]
+    npanels = -(-M // pr)
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        e.upload_genotypes_i8(G)
+        res = _run(e, k, seed)
+    with gpca.GpcaEngine(**_modes("int8")) as e:
+        e.stream_open(gpca.PanelSource.host_i8(rows_i8), M, N, panel_rows=pr, ring_slots=2, fused=False)
+        assert e.stream_info()["staging_buffers"] == 3
+        e.snp_stats()
+        assert calls == [p * pr for p in range(npanels)]
+        assert threads and threading.get_ident() not in threads        # not the thread that runs the pass
+        del calls[:]
+        fail_at[0] = 2 * pr
+        with pytest.raises(RuntimeError, match="disk on fire"):
+            e.rsvd(k, 10, 2, seed=seed)
+        assert calls == [0, pr, 2 * pr]                                 # nothing asked after the failure
+        fail_at[0] = None; del calls[:]
+        stm = _run(e, k, seed)
+        assert calls == [p * pr for p in range(npanels)] * 8
+    _same(res, stm)
+
+
 @pytest.mark.parametrize("store,planes", [("int8", 0), ("2bit", 0), ("2bit", 3)])
 def test_streamed_wide_sketch_k40(gpca, oracle, store, planes):
     """BASELINE.json configs[4]'s sketch width: k = 40 -> l = 50 -> two 32-column halves per panel; ring of 3."""
