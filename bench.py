@@ -95,11 +95,19 @@ def timed_run(eng, a, k, barrier, dist, torch):
         eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
     barrier()
     dt = time.perf_counter() - t0
+    timings = eng.timings()
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    return dt, eng.timings()
+        mine = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        dt = max(per_rank)                         # the contract's max over ranks
+        ar = timings.get("allreduce")
+        timings["_ranks"] = {"per_rank_ms_per_step_min": min(per_rank) / a.steps * 1e3, "per_rank_ms_per_step_max": max(per_rank) / a.steps * 1e3,
+                             "allreduce_ms_per_step_rank0": (ar["total_ms"] / a.steps) if ar else None,
+                             "allreduce_launches_per_step": (ar["launches"] / a.steps) if ar else None,
+                             "allreduce_bytes_per_step": (ar["bytes"] / a.steps) if ar else None}
+    return dt, timings
 
 
 def pmc_traffic(kernel):
@@ -151,6 +159,76 @@ def roofline_of(timings, precision, steps, storage="int8"):
                 "traffic": traffic, "algorithmic_TFLOPs_equivalent": tflops, **common}
     return {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "hbm_GBs_algorithmic": gbs, **common}
+
+
+def kernel_rooflines(timings, precision, storage):
+    """Per-kernel roofline of one run: both GEMMs, each against the resource that bounds it on this path."""
+    out = {}
+    for name in ("gemm_GQ", "gemm_GtT"):
+        t = timings.get(name)
+        if not t or not t["launches"]:
+            continue
+        ms = t["total_ms"] / t["launches"]
+        tf = t["flops"] / t["launches"] / (ms * 1e-3) / 1e12
+        gbs = t["bytes"] / t["launches"] / (ms * 1e-3) / 1e9
+        d = {"avg_launch_ms": ms, "launches": t["launches"], "algorithmic_TFLOPs": tf, "algorithmic_GBs": gbs}
+        if precision == "f32":
+            d.update(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F32_PEAK_TFLOPS)
+        elif storage == "2bit":
+            tops = 2.0 * 32 * 4 * (t["bytes"] / t["launches"] * 4) / (ms * 1e-3) / 1e12
+            d.update(bound="mfma", achieved=tops, peak=5000.0, unit="TOP/s (int8, executed digit-plane MFMAs)", frac=tops / 5000.0)
+        else:
+            d.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+        out[name] = d
+    return out
+
+
+def extra_resident_line(g, a, name, M, N, k, precision, storage, steps, warmup, device):
+    """One more resident workload of BASELINE.json, timed by THIS process (so the driver's run carries it): generated on the
+    device (GPCA_PANEL_SYNTH16: 3 populations, Hardy-Weinberg proportions), stats, `warmup` + `steps` gpca_rsvd calls, HIP-event
+    rooflines of both GEMMs, and the size-independent properties of the result (there is no oracle at this size)."""
+    PREC = {"f32": g._lib.PREC_F32_MFMA, "i8": g._lib.PREC_I8_EXACT}
+    t0 = time.perf_counter()
+    th16 = g.synth_thresholds16(M, 3, seed=a.rfit_seed)
+    eng = g.GpcaEngine(device=device, precision=PREC[precision], storage=g._lib.STORE_2BIT if storage == "2bit" else g._lib.STORE_INT8)
+    try:
+        eng.load_from_source(g.PanelSource.synth16(th16, a.rfit_seed), M, N)
+        del th16
+        eng.synchronize()
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng.snp_stats(g.QcConfig.none(), fetch=False)
+        t_stats = time.perf_counter() - t0
+        for _ in range(warmup):
+            eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+        eng.enable_timings(True); eng.reset_timings()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+        eng.synchronize()
+        per_step = (time.perf_counter() - t0) / steps
+        tim = eng.timings()
+        sc, ev, sv = eng.scores(f64=True), eng.eigenvalues(), eng.singular_values()
+        gram = sc.T @ sc
+        off = gram - np.diag(np.diag(gram))
+        props = {"scores_orthogonality_max_offdiag_rel": float(np.max(np.abs(off)) / sv[0] ** 2),
+                 "scores_norms_vs_singular_values_max_rel": float(np.max(np.abs(np.diag(gram) - sv[:k] ** 2) / sv[:k] ** 2)),
+                 "centring_max_abs_colsum_rel": float(np.max(np.abs(sc.sum(axis=0))) / np.abs(sc).sum(axis=0).max()),
+                 "structured_eigenvalues_found": int(np.sum(ev > 20 * ev[-1])), "structured_eigenvalues_expected": 2,
+                 "eigenvalues_descending": bool(np.all(np.diff(ev) <= 0))}
+        tr = eng.transform()
+        a_, b_ = tr[:, :2] / np.linalg.norm(tr[:, :2], axis=0), sc[:, :2] / np.linalg.norm(sc[:, :2], axis=0)
+        a_ = a_ * np.sign(np.sum(a_ * b_, axis=0))      # sign-aligned unit-norm PCs: PCA::transform against the scores of the fit
+        props["transform_vs_scores_max_abs_dPC_structured"] = float(np.max(np.abs(a_ - b_)))
+        l = k + a.oversample
+        return {"workload": name, "snps": M, "samples": N, "k": k, "l": l, "q": a.power_iters, "gemm_path": precision, "residency": storage,
+                "steps": steps, "warmup": warmup, "ms_per_step": per_step * 1e3, "value": M * N / per_step, "unit": "SNPs*samples/s",
+                "generate_s": t_gen, "snp_stats_s": t_stats, "roofline": kernel_rooflines(tim, precision, storage),
+                "all_kernels_ms_per_step": {n_: t_["total_ms"] / steps for n_, t_ in tim.items()},
+                "top_eigenvalues": [float(x) for x in ev[:3]], "properties": props}
+    finally:
+        eng.close()
 
 
 def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn=None, steps=None, warmup=None, cache_gb=0.0):
@@ -269,6 +347,10 @@ def main():
     ap.add_argument("--rfit-seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-path", action="store_true", help="skip the extra f32-MFMA measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra BASELINE.json workloads of the default one-GPU run (configs[3]'s per-GPU shard 1.25M x 100k int8 and "
+                         "north_star's literal 10M x 100k MFMA-fp32 job on 2-bit rows): use it under rocprofv3, whose per-kernel averages "
+                         "would otherwise mix three shapes")
     ap.add_argument("--storage", default="int8", choices=["int8", "2bit"],
                     help="HBM residency of the genotypes: int8 = 1 B/genotype (the BASELINE.json configs), 2bit = 0.25 B, decoded in the GEMM prologues")
     ap.add_argument("--digit-planes", type=int, default=0, choices=[0, 3, 4],
@@ -336,6 +418,7 @@ def main():
         order.append("i8_2bit_3p")
     th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
     t_stats = None
+    head_rank_info = None
     for prec in order:
         packed = prec in ("i8_2bit", "i8_2bit_3p")
         store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == a.precision) or packed) else g._lib.STORE_INT8
@@ -350,8 +433,14 @@ def main():
         if dist is not None:
             uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
             eng.comm_init(world, rank, uid, snp_offset)
+        ranks_seen = eng.comm_count_ranks() if dist is not None else 1   # a 1.0 per rank through libgpca's own RCCL communicator
         dt, timings = timed_run(eng, a, k, barrier, dist, torch)
+        rank_info = timings.pop("_ranks", None)
+        if rank_info is not None:
+            rank_info["ranks_seen_by_rccl"] = ranks_seen
         results[prec] = (dt, timings, eng.eigenvalues())
+        if prec == a.precision:
+            head_rank_info = rank_info
         eng.close()
     del th
 
@@ -375,6 +464,8 @@ def main():
             "snp_stats_s": t_stats,
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
+        if head_rank_info is not None:
+            out["multi_gpu"] = head_rank_info
         if "f32" in results and a.precision != "f32":
             dt2, tim2, ev2 = results["f32"]
             out["f32_mfma_path"] = {"value": M_total * N / (dt2 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt2 / a.steps * 1e3,
@@ -405,6 +496,14 @@ def main():
                                               "device generator (GPCA_PANEL_SYNTH16; a different synthetic draw than the resident matrix)",
                                       "value": M_local * N / (dts / min(a.steps, 3)), "unit": "SNPs*samples/s",
                                       "ms_per_step": dts / min(a.steps, 3) * 1e3, **streamed_summary(tims, min(a.steps, 3), M_local, N, l, a.storage)}
+        if world == 1 and DEFAULT_SHAPE and not a.no_extras and not a.no_second_path and a.precision == "i8" and a.storage == "int8":
+            # the other single-GPU workloads BASELINE.json names, timed inside this (the driver's) run
+            out["config3_per_gpu_shard"] = extra_resident_line(
+                g, a, "BASELINE.json configs[3] per-GPU shard: 1.25M SNPs x 100k samples int8 (125 GB resident), exact-integer GEMMs",
+                1_250_000, 100_000, k, "i8", "int8", steps=5, warmup=1, device=local_rank)
+            out["north_star_literal"] = extra_resident_line(
+                g, a, "north_star's literal target: 10M SNPs x 100k samples, k = 20, MFMA-fp32 GEMMs on ONE MI355X (2-bit resident rows, 250 GB)",
+                10_000_000, 100_000, k, "f32", "2bit", steps=2, warmup=1, device=local_rank)
         # bench lines of the other BASELINE.json configs, measured with this build by the scripts named in DESIGN.md (too large or too
         # long for the default run; each file holds one line in this same format)
         out["see_also"] = {k_: v_ for k_, v_ in {

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "gpca_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "gpca_comm_init": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "gpca_set_allreduce_hook": (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32, C.c_int64]),
+    "gpca_comm_count_ranks": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "gpca_get_timings": (C.c_int, [_H, C.POINTER(gpca_kernel_timing), C.c_int32, C.POINTER(C.c_int32)]),
     "gpca_reset_timings": (C.c_int, [_H]),
     "gpca_enable_timings": (C.c_int, [_H, C.c_int32]),

@@ -427,6 +427,21 @@ int agree_status(gpca_handle* h, int local_rc, const char* where) {
     return fail(h, agreed, buf);
 }
 
+extern "C" int gpca_comm_count_ranks(gpca_handle* h, int32_t* ranks) {
+    if (!h || !ranks) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    *ranks = 1;
+    if (!multi_rank(h)) return GPCA_OK;
+    if (!h->d_status || !h->h_status) return fail(h, GPCA_ERR_STATE, "gpca_comm_count_ranks: no status buffer");
+    for (int i = 0; i < 16; ++i) h->h_status[i] = i == 0 ? 1.0 : 0.0;
+    HIPCHK(hipMemcpyAsync(h->d_status, h->h_status, 16 * sizeof(double), hipMemcpyHostToDevice, h->st));
+    CHK(allreduce_f64(h, h->d_status, 16));
+    HIPCHK(hipMemcpyAsync(h->h_status + 16, h->d_status, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    *ranks = (int32_t)(h->h_status[16] + 0.5);
+    return GPCA_OK;
+}
+
 // ---- d: timings ------------------------------------------------------------------------------------------------
 extern "C" int gpca_enable_timings(gpca_handle* h, int32_t on) { if (!h) return GPCA_ERR_BAD_ARG; LOCK(h); h->timing_on = on != 0; return GPCA_OK; }
 extern "C" int gpca_reset_timings(gpca_handle* h) {

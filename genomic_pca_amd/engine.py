@@ -373,6 +373,12 @@ class GpcaEngine:
     def comm_init(self, world: int, rank: int, unique_id: bytes, snp_offset: int):
         self._chk(self._lib.gpca_comm_init(self._h, world, rank, C.c_char_p(unique_id), snp_offset))
 
+    def comm_count_ranks(self) -> int:
+        """Ranks the exchange actually reaches (collective: a 1.0 per rank summed through RCCL or the hook)."""
+        n = C.c_int32()
+        self._chk(self._lib.gpca_comm_count_ranks(self._h, C.byref(n)))
+        return n.value
+
     def set_allreduce_hook(self, fn, world: int, rank: int, snp_offset: int):
         """fn(np.ndarray f64 view) sums the buffer in place across ranks (any transport)."""
         def _tramp(_user, ptr, count):

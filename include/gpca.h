@@ -279,6 +279,10 @@ typedef int (*gpca_allreduce_fn)(void* user, double* host_buf, int64_t count);
 GPCA_API int gpca_set_allreduce_hook(gpca_handle* h, gpca_allreduce_fn fn, void* user, int32_t world,
                             int32_t rank, int64_t snp_offset);
 
+/* How many ranks the handle's exchange actually reaches: a 1.0 per rank summed through the same transport as the sketch (RCCL
+ * communicator or hook).  Collective: every rank of the sharded matrix must call it.  1 for an unsharded handle. */
+GPCA_API int gpca_comm_count_ranks(gpca_handle* h, int32_t* ranks);
+
 /* ---- d: measurement ------------------------------------------------------------------------- */
 typedef struct gpca_kernel_timing {
     char name[32];

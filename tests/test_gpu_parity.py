@@ -546,11 +546,12 @@ def test_full_size_properties(gpca, oracle, prec, store):
         assert np.array_equal(ev, evf) and np.array_equal(sc2, scf)
 
 
-@pytest.mark.parametrize("M,N", [(200_000, 100_000)])
-def test_c4_shape_class_i8_and_2bit(gpca, oracle, M, N):
-    """BASELINE.json configs[3]'s per-GPU shape class (100k samples) with enough rows for full LDS-DMA rounds: 20 GB of
-    int8 genotypes.  No oracle at this size: property checks, bitwise repeat, and int8-resident == 2-bit-resident (the
-    same exact integers), plus spot rows of the loadings against a direct f64 evaluation from the oracle's bytes."""
+@pytest.mark.parametrize("M,N", [(1_250_000, 100_000)])
+def test_c4_per_gpu_shard_i8_and_2bit(gpca, oracle, M, N):
+    """BASELINE.json configs[3]'s PER-GPU workload at full size: 1.25M SNPs x 100k samples (one of the eight row shards of
+    10M x 100k) = 125 GB of int8 genotypes resident, then the same rows as 2-bit codes.  No oracle at this size: property
+    checks, bitwise repeat, and int8-resident == 2-bit-resident (the same exact integers), plus spot rows of the loadings
+    against a direct f64 evaluation from the oracle's bytes."""
     from genomic_pca_amd import _lib
     k, seed = 20, 5
     th = gpca.synth_thresholds(M, 3, seed=seed)
@@ -571,7 +572,7 @@ def test_c4_shape_class_i8_and_2bit(gpca, oracle, M, N):
             assert np.max(np.abs(sc.sum(axis=0))) < 1e-6 * np.abs(sc).sum(axis=0).max()
             assert ev[1] > 20 * ev[2]
             V = sc[:, :2] / sv[:2]
-            for i in (0, 77_777, M - 1):
+            for i in (0, 77_777, 654_321, M - 1):
                 g_row = oracle.synth_genotypes(1, N, seed, th[i:i + 1], snp_offset=int(i)).astype(np.float64)[0]
                 a_i = (g_row - float(st["mu"][i])) / float(st["sigma"][i])
                 assert np.max(np.abs(a_i @ V / sv[:2] - ld[i, :2].astype(np.float64))) < 1e-5

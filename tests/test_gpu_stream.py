@@ -724,3 +724,48 @@ def test_config5_sample_count_k40(gpca, oracle):
         e.snp_stats(); e.rsvd(k, 10, 2, seed=seed)
         assert np.max(np.abs(e.eigenvalues() - out["2bit"][0]) / out["2bit"][0]) < 2e-8
         assert oracle.max_abs_dpc(e.scores(f64=True)[:, :2], out["2bit"][1][:, :2]) < 2e-7
+
+
+def test_config5_per_gpu_shard_streamed(gpca, oracle):
+    """BASELINE.json configs[4]'s PER-GPU workload at full size: 6.25M SNPs x 500k samples (one of the eight row shards of 50M x 500k),
+    k = 40, never resident -- 48 panels of 131 072 rows of 2-bit codes from the device generator through a ring of 3 (781 GB per pass).
+    One stats pass + one fused gpca_rsvd (4 passes), then the same with the HBM panel cache on: the cache must not change a bit.  No
+    oracle at this size: spot rows of the generator and of the QC statistics against the oracle, and the size-independent properties
+    of the result (orthogonality, centring, the two population PCs, PCA::transform == scores, loadings of spot rows re-derived in f64)."""
+    M, N, k, seed = 6_250_000, 500_000, 40, 1
+    th16 = gpca.synth_thresholds16(M, 3, seed=seed)
+    with gpca.GpcaEngine(**_modes("2bit")) as e:
+        e.stream_open(gpca.PanelSource.synth16(th16, seed), M, N)          # panel_rows = 0: the library's choice (131 072), fused
+        info = e.stream_info()
+        assert info["panel_rows"] == 131072 and info["n_panels"] == 48 and info["ring_slots"] == 3 and info["n_cached"] == 0
+        st = e.snp_stats(gpca.QcConfig.none())
+        counts, _ = e.snp_qc_detail()
+        rows = [0, 131071, 131072, 3_333_333, M - 1]
+        for i in rows:                                                     # generator + statistics of spot rows: the oracle's bytes
+            g_row = oracle.synth16_genotypes(1, N, seed, th16[i:i + 1], snp_offset=int(i))
+            o = oracle.snp_stats(g_row, N, 0.0, 0.0, 1.0)
+            assert np.array_equal(counts[i], o["counts"][0]) and st["mu"][i] == o["mu"][0]
+            assert abs(float(st["sigma"][i]) - float(o["sigma"][0])) <= np.spacing(o["sigma"][0])
+        assert int(st["keep"].sum()) == M and counts[:, 0].min() == N
+        e.rsvd(k, 10, 2, seed=seed)
+        sc = e.scores(f64=True); ev = e.eigenvalues(); sv = e.singular_values(); ld = e.loadings()
+        gram = sc.T @ sc
+        assert np.allclose(np.diag(gram), sv[:k] ** 2, rtol=1e-6)
+        assert np.max(np.abs(gram - np.diag(np.diag(gram)))) < 1e-6 * sv[0] ** 2
+        assert np.max(np.abs(sc.sum(axis=0))) < 1e-6 * np.abs(sc).sum(axis=0).max()
+        assert np.all(np.diff(ev) <= 0) and ev[1] > 20 * ev[2]             # 3 populations -> 2 structured PCs
+        V = sc[:, :2] / sv[:2]
+        for i in rows:
+            g_row = oracle.synth16_genotypes(1, N, seed, th16[i:i + 1], snp_offset=int(i)).astype(np.float64)[0]
+            a_i = (g_row - float(st["mu"][i])) / float(st["sigma"][i])
+            assert np.max(np.abs(a_i @ V / sv[:2] - ld[i, :2].astype(np.float64))) < 1e-5
+        tr = e.transform()
+        assert oracle.max_abs_dpc(tr[:, :2], sc[:, :2]) < 1e-4
+        # the panel cache: the leading panels stay in spare HBM, the others keep streaming -- same bits
+        n_cached = e.stream_set_cache(-1)
+        assert 1 <= n_cached < 48
+        e.snp_stats(gpca.QcConfig.none(), fetch=False)
+        f0 = e.stream_info()["fills"]
+        e.rsvd(k, 10, 2, seed=seed)
+        assert e.stream_info()["fills"] - f0 == 4 * (48 - n_cached)        # 4 passes, cached panels not asked again
+        assert np.array_equal(e.eigenvalues(), ev) and np.array_equal(e.scores(f64=True), sc) and np.array_equal(e.loadings(), ld)
