@@ -30,10 +30,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
 def cpu_baseline(N, k, oversample, q, seed, target_s=15.0):
-    """Oracle restatement (REAL=float, OpenMP) timed on a bounded sample of the same workload."""
+    """Oracle restatement (REAL=float, OpenMP) timed on a bounded sample of the same workload, on the CPUs this process really owns
+    (affinity mask, cgroup quota, physical cores: oracle.usable_cpus)."""
     from oracle import oracle as O   # cpu_baseline leg only
     import genomic_pca_amd as g
-    threads = O.num_threads("f32")
+    cpus = O.usable_cpus()
+    threads = cpus["threads"]
+    O.set_num_threads(threads, "f32")
+    l = k + oversample
 
     def run(Ms):
         th = g.synth_thresholds(Ms, 3, seed=seed)
@@ -46,12 +50,20 @@ def cpu_baseline(N, k, oversample, q, seed, target_s=15.0):
     Ms = 25000
     t = run(Ms)
     rate = Ms * N / t
+    half = None
+    if threads >= 2:      # the same sample on half the threads: the baseline must scale with the cores it is given
+        O.set_num_threads(threads // 2, "f32")
+        half = Ms * N / run(Ms)
+        O.set_num_threads(threads, "f32")
     Ms2 = int(min(max(rate * target_s / N, Ms), 1_000_000))   # ~target_s of CPU work, capped at 10 GB of genotypes
     if Ms2 > 1.5 * Ms:
         t = run(Ms2); Ms = Ms2
-    return {"value": Ms * N / t, "unit": "SNPs*samples/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/gpca_oracle.c REAL=float, {Ms} SNPs x {N} samples, k={k}, l={k + oversample}, q={q}, "
-                      f"{t:.1f} s on {threads} OpenMP threads (CPU restatement, not the Rust/faer binary)"}
+    flop = (2 + 4 * q + 2) * l * Ms * N
+    return {"value": Ms * N / t, "unit": "SNPs*samples/s", "cores": threads, "kind": "port", "gflops": flop / t / 1e9,
+            "value_on_half_the_threads": half, "cpus": cpus,
+            "sample": f"oracle/gpca_oracle.c REAL=float, {Ms} SNPs x {N} samples, k={k}, l={l}, q={q}, "
+                      f"{t:.1f} s on {threads} OpenMP threads = {flop / t / 1e9:.0f} GFLOP/s (CPU restatement, not the Rust/faer binary; "
+                      f"threads = min(affinity {cpus['affinity']}, cgroup quota {cpus['cgroup_quota_cpus']}, physical cores {cpus['physical_cores']}))"}
 
 
 def parity_check(g, precision, seed):

@@ -345,72 +345,118 @@ void orc_jacobi_eigh(double* A, double* V, double* w, int n) { jacobi_eigh(A, V,
  *   A[i][n] = g[i][n] * r[i] + b[i],  r = 1/sigma, b = -mu * r (both f32, prepare.rs:1948-1949).
  * A is never materialised:  (A Q)[i] = r_i (g_i . Q) + b_i (1^T Q);  A^T T = G^T (r o T) + 1 (b^T T).
  * ---------------------------------------------------------------------------------------- */
+/* Both products are tiled so that every thread owns its outputs outright (rows of T; a sample tile of Y): no per-thread copies of
+ * the N x l block and no reduction over threads, whose cost grew with the thread count (307 MB of partials at 256 threads).  The
+ * skinny operand is padded to LP = 32 or 64 columns so that the inner loops have a compile-time trip count (gcc vectorises them). */
+#define ORC_ROWS_PER_BLOCK 2
+#define ORC_SAMPLE_TILE 64
+static int padded_cols(int l) { return l <= 32 ? 32 : (l <= 64 ? 64 : ((l + 15) / 16) * 16); }
+
+#define ORC_DEFINE_AQ(NAME, LP)                                                                                         \
+static void NAME(const int8_t* G, int64_t M, int64_t N, int64_t ld, const float* r, const float* b, const real* Qp,      \
+                 const real* s, int l, real* T) {                                                                       \
+    _Pragma("omp parallel for schedule(static)")                                                                         \
+    for (int64_t i0 = 0; i0 < M; i0 += ORC_ROWS_PER_BLOCK) {                                                             \
+        real acc[ORC_ROWS_PER_BLOCK][LP];                                                                                \
+        const int nr = (int)(M - i0 < ORC_ROWS_PER_BLOCK ? M - i0 : ORC_ROWS_PER_BLOCK);                                 \
+        for (int a = 0; a < ORC_ROWS_PER_BLOCK; ++a) for (int j = 0; j < LP; ++j) acc[a][j] = 0;                         \
+        const int8_t* row0 = G + i0 * ld;                                                                                \
+        const int8_t* row1 = G + (i0 + (nr > 1 ? 1 : 0)) * ld;                                                           \
+        for (int64_t n = 0; n < N; ++n) {                                                                                \
+            const real* q = Qp + n * LP;                                                                                 \
+            const real g0 = (real)row0[n], g1 = (real)row1[n];                                                           \
+            for (int j = 0; j < LP; ++j) { acc[0][j] += g0 * q[j]; acc[1][j] += g1 * q[j]; }                              \
+        }                                                                                                                \
+        for (int a = 0; a < nr; ++a) {                                                                                   \
+            const real ri = (real)r[i0 + a], bi = (real)b[i0 + a];                                                       \
+            for (int j = 0; j < l; ++j) T[(i0 + a) * l + j] = ri * acc[a][j] + bi * s[j];                                \
+        }                                                                                                                \
+    }                                                                                                                    \
+}
+ORC_DEFINE_AQ(prod_AQ_32, 32)
+ORC_DEFINE_AQ(prod_AQ_64, 64)
+
 /* T[M][l] = A Q ; Q is [N][l] */
 static void prod_AQ(const int8_t* G, int64_t M, int64_t N, int64_t ld, const float* r,
                     const float* b, const real* Q, int l, real* T) {
+    const int LP = padded_cols(l);
     real* s = (real*)calloc(l, sizeof(real));
     for (int64_t n = 0; n < N; ++n) for (int j = 0; j < l; ++j) s[j] += Q[n * l + j];
-#pragma omp parallel
-    {
-        real* acc = (real*)malloc(sizeof(real) * l);
-#pragma omp for schedule(static)
+    if (LP > 64) {   /* wider than the engine ever runs: the plain loop */
+#pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < M; ++i) {
             const int8_t* row = G + i * ld;
-            for (int j = 0; j < l; ++j) acc[j] = 0;
-            for (int64_t n = 0; n < N; ++n) {
-                real g = (real)row[n];
-                const real* q = Q + n * l;
-                for (int j = 0; j < l; ++j) acc[j] += g * q[j];
-            }
             real ri = (real)r[i], bi = (real)b[i];
-            for (int j = 0; j < l; ++j) T[i * l + j] = ri * acc[j] + bi * s[j];
+            for (int j = 0; j < l; ++j) {
+                real acc = 0;
+                for (int64_t n = 0; n < N; ++n) acc += (real)row[n] * Q[n * l + j];
+                T[i * l + j] = ri * acc + bi * s[j];
+            }
         }
-        free(acc);
+        free(s);
+        return;
     }
-    free(s);
+    real* Qp = (real*)calloc((size_t)N * LP, sizeof(real));
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n) for (int j = 0; j < l; ++j) Qp[n * LP + j] = Q[n * l + j];
+    if (LP == 32) prod_AQ_32(G, M, N, ld, r, b, Qp, s, l, T); else prod_AQ_64(G, M, N, ld, r, b, Qp, s, l, T);
+    free(Qp); free(s);
 }
-/* Y[N][l] = A^T T ; T is [M][l].  Per-thread private Y, reduced in double. */
+
+#define ORC_DEFINE_ATT(NAME, LP)                                                                                         \
+static void NAME(const int8_t* G, int64_t M, int64_t N, int64_t ld, const real* TP, const double* c, int l, double* Y) {  \
+    const int64_t tiles = (N + ORC_SAMPLE_TILE - 1) / ORC_SAMPLE_TILE;                                                    \
+    _Pragma("omp parallel for schedule(dynamic, 1)")                                                                       \
+    for (int64_t t = 0; t < tiles; ++t) {                                                                                 \
+        const int64_t n0 = t * ORC_SAMPLE_TILE;                                                                           \
+        const int nn = (int)(N - n0 < ORC_SAMPLE_TILE ? N - n0 : ORC_SAMPLE_TILE);                                        \
+        real y[ORC_SAMPLE_TILE][LP];                                                                                      \
+        for (int a = 0; a < ORC_SAMPLE_TILE; ++a) for (int j = 0; j < LP; ++j) y[a][j] = 0;                               \
+        for (int64_t i = 0; i < M; ++i) {                                                                                 \
+            const int8_t* g = G + i * ld + n0;                                                                            \
+            const real* tp = TP + i * LP;                                                                                 \
+            for (int a = 0; a < nn; ++a) {                                                                                \
+                const real ga = (real)g[a];                                                                               \
+                for (int j = 0; j < LP; ++j) y[a][j] += ga * tp[j];                                                       \
+            }                                                                                                             \
+        }                                                                                                                 \
+        for (int a = 0; a < nn; ++a) for (int j = 0; j < l; ++j) Y[(n0 + a) * l + j] = c[j] + (double)y[a][j];            \
+    }                                                                                                                     \
+}
+ORC_DEFINE_ATT(prod_AtT_32, 32)
+ORC_DEFINE_ATT(prod_AtT_64, 64)
+
+/* Y[N][l] = A^T T ; T is [M][l].  T' = r o T is formed once (padded to LP columns), c = b^T T in double; every thread then owns a
+ * tile of 64 samples and sweeps all rows for it. */
 static void prod_AtT(const int8_t* G, int64_t M, int64_t N, int64_t ld, const float* r,
                      const float* b, const real* T, int l, double* Y) {
-    int nt = 1;
-#ifdef _OPENMP
-    nt = omp_get_max_threads();
-#endif
-    real* priv = (real*)calloc((size_t)nt * N * l, sizeof(real));
-    double* cpriv = (double*)calloc((size_t)nt * l, sizeof(double));
+    const int LP = padded_cols(l);
+    real* TP = (real*)calloc((size_t)M * LP, sizeof(real));
+    double* c = (double*)calloc(l, sizeof(double));
 #pragma omp parallel
     {
-        int tid = 0;
-#ifdef _OPENMP
-        tid = omp_get_thread_num();
-#endif
-        real* Yp = priv + (size_t)tid * N * l;
-        double* cp = cpriv + (size_t)tid * l;
-        real* tp = (real*)malloc(sizeof(real) * l);
+        double* cp = (double*)calloc(l, sizeof(double));
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < M; ++i) {
-            const int8_t* row = G + i * ld;
-            real ri = (real)r[i], bi = (real)b[i];
-            for (int j = 0; j < l; ++j) { tp[j] = ri * T[i * l + j]; cp[j] += (double)bi * (double)T[i * l + j]; }
-            for (int64_t n = 0; n < N; ++n) {
-                real g = (real)row[n];
-                if (g == 0) continue;
-                real* y = Yp + n * l;
-                for (int j = 0; j < l; ++j) y[j] += g * tp[j];
-            }
+            const real ri = (real)r[i]; const double bi = (double)b[i];
+            for (int j = 0; j < l; ++j) { TP[i * LP + j] = ri * T[i * l + j]; cp[j] += bi * (double)T[i * l + j]; }
         }
-        free(tp);
+#pragma omp critical
+        for (int j = 0; j < l; ++j) c[j] += cp[j];
+        free(cp);
     }
-    double* c = (double*)calloc(l, sizeof(double));
-    for (int t = 0; t < nt; ++t) for (int j = 0; j < l; ++j) c[j] += cpriv[(size_t)t * l + j];
+    if (LP == 32) prod_AtT_32(G, M, N, ld, TP, c, l, Y);
+    else if (LP == 64) prod_AtT_64(G, M, N, ld, TP, c, l, Y);
+    else {
 #pragma omp parallel for schedule(static)
-    for (int64_t n = 0; n < N; ++n)
-        for (int j = 0; j < l; ++j) {
-            double a = c[j];
-            for (int t = 0; t < nt; ++t) a += (double)priv[(size_t)t * N * l + n * l + j];
-            Y[n * l + j] = a;
-        }
-    free(priv); free(cpriv); free(c);
+        for (int64_t n = 0; n < N; ++n)
+            for (int j = 0; j < l; ++j) {
+                double a = c[j];
+                for (int64_t i = 0; i < M; ++i) a += (double)((real)G[i * ld + n] * TP[i * LP + j]);
+                Y[n * l + j] = a;
+            }
+    }
+    free(TP); free(c);
 }
 void orc_prod_AQ(const int8_t* G, int64_t M, int64_t N, int64_t ld, const float* r, const float* b,
                  const real* Q, int l, real* T) { prod_AQ(G, M, N, ld, r, b, Q, l, T); }
@@ -500,6 +546,13 @@ int orc_rsvd(const int8_t* G, int64_t M, int64_t N, int64_t ld, const float* r, 
 }
 
 int orc_sizeof_real(void) { return (int)sizeof(real); }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -342,3 +342,45 @@ def max_abs_dpc(X, ref):
 
 def num_threads(real="f64") -> int:
     return int(lib(real).orc_num_threads())
+
+
+def set_num_threads(n: int, real="f64") -> None:
+    lib(real).orc_set_num_threads(C.c_int(int(n)))
+
+
+def usable_cpus() -> dict:
+    """CPUs this process can really run on: the scheduler affinity mask, capped by the cgroup CPU quota (a container on a 256-thread
+    host may own 16 CPUs' worth of time: 256 OpenMP threads on it spend their time descheduled) and by the physical core count (SMT
+    siblings add nothing to an FMA-bound loop)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cores = set()
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    physical = len(cores) or aff
+    use = max(1, min(aff, physical, int(quota + 0.5) if quota else aff))
+    return {"threads": use, "affinity": aff, "cgroup_quota_cpus": quota, "physical_cores": physical}
