@@ -188,7 +188,8 @@ typedef struct gpca_stream_info {
     int32_t copy_threads;    /* MAPPED_* staged: threads that copy a panel into staging */
     int64_t fills;           /* panels asked of the source so far */
     double fill_host_ms;     /* host time spent producing panels into staging (callback / copy threads), summed over the worker's jobs */
-    double fill_wait_ms;     /* time the pass thread waited for a staged panel that was not ready yet: > 0 = the source is the bottleneck */
+    double fill_wait_ms;     /* time the pass thread was blocked on the staging ring (panel not staged yet, or every buffer still in flight on
+                                the link): compare with fill_host_ms to tell a slow source from a saturated link */
     double register_ms;      /* hipHostRegister at open (zero-staging) */
     int64_t reserved[4];
 } gpca_stream_info;
