@@ -202,7 +202,7 @@ def test_mapped_sources_equal_resident_bitwise(gpca, oracle, store, kind, regist
         gpca.PanelSource.mapped_i8(np.zeros((4, 4), np.uint8))
     with gpca.GpcaEngine(**_modes(store)) as e:
         with pytest.raises(gpca.GpcaError) as err:                      # a pitch smaller than a row is refused
-            bad = gpca.PanelSource.mapped_i8(view); cs = bad.c_struct(); cs.host_ld = 7
+            bad = src(); cs = bad.c_struct(); cs.host_ld = 7
             e._chk(e._lib.gpca_stream_open(e._h, __import__("ctypes").byref(cs), M, N, 4096, 2))
         assert err.value.status == -1
 
