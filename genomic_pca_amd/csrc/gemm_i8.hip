@@ -1704,14 +1704,34 @@ __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict_
 
 // layout 0: block = 32 consecutive rows, lane half hh, element j -> row 32*blk + 16*hh + j
 // layout 1 (packed K1): block = MFMA step (b, s) of a 128-row group -> row 128*(blk/4) + 64*hh + 16*(blk%4) + j
-template <typename T>
+// The 16 loads of a lane are unconditional (row index clamped, the value zeroed afterwards) and issued together: with a
+// predicated load per element the compiler waited for each one before asking for the next (16 serial latencies per lane,
+// 3.8 TB/s on the 256 MB of a T' pass); ND is a template parameter so that the digit loop carries no runtime branch.
+template <int ND>
+__device__ __forceinline__ void split_digits(int v, unsigned (&w)[kDigits][4], int j) {
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) {
+        int dg;
+        if (ND == 3) { if (d < 2) { dg = ((v + 128) & 255) - 128; v = (v - dg) >> 8; } else { dg = v; v = 0; } }    // base 256, plane 3 = 0
+        else if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
+        w[d][j >> 2] |= ((unsigned)(dg & 0xff)) << (8 * (j & 3));
+    }
+}
+template <typename T, int ND>
 __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64_t rows, int64_t rows_pad,
-                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int nd, int64_t ldx) {
+                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int64_t ldx) {
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk * 32 >= rows_pad) return;
     const int cc = lane & 31, hh = lane >> 5;
     const double sc = inv[cc];
+    const int64_t rbase = layout ? (blk >> 2) * 128 + 64 * hh + 16 * (blk & 3) : blk * 32 + 16 * hh;
+    T xv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t row = rbase + j;
+        xv[j] = X[(row < rows ? row : rows - 1) * ldx + cc];
+    }
     unsigned w[kDigits][4];
 #pragma unroll
     for (int d = 0; d < kDigits; ++d)
@@ -1719,20 +1739,19 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
         for (int q = 0; q < 4; ++q) w[d][q] = 0u;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int64_t row = layout ? (blk >> 2) * 128 + 64 * hh + 16 * (blk & 3) + j : blk * 32 + 16 * hh + j;
-        const double x = row < rows ? (double)X[row * ldx + cc] : 0.0;
-        int v = __double2int_rn(x * sc);          // |x * sc| <= 0.49 * 2^28 (2^24 in three-plane mode): 32-bit digit arithmetic
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d) {
-            int dg;
-            if (nd == 3) { if (d < 2) { dg = ((v + 128) & 255) - 128; v = (v - dg) >> 8; } else { dg = v; v = 0; } }    // base 256, plane 3 = 0
-            else if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
-            w[d][j >> 2] |= ((unsigned)(dg & 0xff)) << (8 * (j & 3));
-        }
+        const double x = rbase + j < rows ? (double)xv[j] : 0.0;
+        split_digits<ND>(__double2int_rn(x * sc), w, j);          // |x * sc| <= 0.49 * 2^28 (2^24 in three-plane mode): 32-bit digit arithmetic
     }
 #pragma unroll
     for (int d = 0; d < kDigits; ++d)
         *reinterpret_cast<uint4*>(Xd + ((blk * kDigits + d) * 64 + lane) * 16) = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
+}
+template <typename T>
+static void launch_k_quantize(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) {
+    const int64_t blocks = rows_pad / 32;
+    const dim3 grid((unsigned)((blocks + 3) / 4)), blk(256);
+    if (nd == 3) hipLaunchKernelGGL((k_quantize<T, 3>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx);
+    else hipLaunchKernelGGL((k_quantize<T, kDigits>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx);
 }
 
 template <typename T>
@@ -1741,21 +1760,18 @@ static void quantize_t(hipStream_t st, const T* X, int64_t rows, int64_t rows_pa
     const int64_t P = absmax_num_parts(rows);
     hipLaunchKernelGGL((k_col_absmax<T>), dim3((unsigned)P), dim3(256), 0, st, X, rows, part, ldx);
     hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv, digit_scale(nd));
-    const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
+    launch_k_quantize<T>(st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
 }
 // abs-max partials already produced by the kernel that wrote X (K1 epilogue): finish the scale and quantise
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
                                 double* scale, double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) {
     hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, apart, P, scale, inv, digit_scale(nd));
-    const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<float>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
+    launch_k_quantize<float>(st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
 }
 // quantise X (f64) with a column scale that is already on the device (k_finish_q)
 void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout,
                                    int nd, int64_t ldx) {
-    const int64_t blocks = rows_pad / 32;
-    hipLaunchKernelGGL((k_quantize<double>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, X, rows, rows_pad, inv, Xd, layout, nd, ldx);
+    launch_k_quantize<double>(st, X, rows, rows_pad, inv, Xd, layout, nd, ldx);
 }
 void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
                          double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd, ldx); }

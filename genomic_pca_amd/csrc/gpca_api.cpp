@@ -188,7 +188,7 @@ extern "C" int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* m
     if (h->sm.on && h->sm.fl.d_flags) CHK(finish_pack_flags(h, h->sm.fl.d_flags, h->sm.st_fill));   // int8 panels packed on the way in
     h->flags |= h->pack_flags;   // 2-bit mode: values outside {0,1,2,-127} were seen (and stored as missing) at upload
     CHK(refresh_pca_rows(h));
-    h->have_stats = true; h->have_rsvd = false;
+    h->have_stats = true; h->have_rsvd = false; h->rmax_valid = false;
     if (mu) HIPCHK(hipMemcpy(mu, h->d_mu, (size_t)h->M * 4, hipMemcpyDeviceToHost));
     if (sigma) HIPCHK(hipMemcpy(sigma, h->d_sigma, (size_t)h->M * 4, hipMemcpyDeviceToHost));
     if (keep) HIPCHK(hipMemcpy(keep, h->d_keep, (size_t)h->M, hipMemcpyDeviceToHost));
@@ -241,7 +241,7 @@ extern "C" int gpca_set_standardization(gpca_handle* h, const float* mu, const f
         if ((int64_t)c[0] != h->N) h->flags |= 1u;
         if ((uint64_t)c[1] + c[2] + c[3] != c[0]) h->flags |= 2u;
     }
-    h->have_rsvd = false;
+    h->have_rsvd = false; h->rmax_valid = false;
     return GPCA_OK;
 }
 

@@ -167,6 +167,7 @@ struct gpca_handle {
     int8_t *dQd = nullptr, *dTd = nullptr;
     double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false; int64_t apart_parts = 0;   // column abs-max partials of T' from the K1 epilogue
     const double* apart_src[2] = {nullptr, nullptr};   // where the partials of each 32-column half sit
+    float* d_rmax = nullptr; bool rmax_valid = false;   // max_i r[i]: the sketch's digit scale is 6.67 * rmax (k_omega); recomputed when r changes
     double* d_amax_run = nullptr;    // [2][32] running column abs-max over the panels of a streamed K1 sweep
     double* d_yint = nullptr; size_t cap_yint = 0;   // [halves][N][32] integer partial sums of a streamed K2 sweep
     // EigenSNP stages (gpca_set_sample_mask / gpca_set_condensed_basis / gpca_rsvd_condensed / gpca_refine, gpca_rsvd.cpp)

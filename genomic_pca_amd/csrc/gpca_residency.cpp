@@ -19,7 +19,7 @@ void free_ws(gpca_handle* h) {
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
     dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64); dfree(h->d_tr64); h->cap_tr64 = 0;
     dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_cholflag); if (h->h_pin) { (void)hipHostFree(h->h_pin); h->h_pin = nullptr; } dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
-    dfree(h->d_amax_run); dfree(h->d_yint); h->cap_yint = 0;
+    dfree(h->d_amax_run); dfree(h->d_rmax); h->rmax_valid = false; dfree(h->d_yint); h->cap_yint = 0;
     h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
     h->cap_Q = h->cap_T = h->cap_Tb = h->cap_Ypart = h->cap_cpart = h->cap_Y = h->cap_part64 = h->cap_scores = h->cap_load = 0;
     h->have_rsvd = false;
@@ -580,7 +580,7 @@ extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, 
         // depends on the rows is marked stale, the rows past the block are zeroed (pad rows: zero genotypes, r = b = 0)
         HIPCHK(hipStreamSynchronize(dst->st));
         dst->M = rows; dst->Mpad = new_pad;
-        dst->have_stats = false; dst->have_rsvd = false; dst->n_pca = 0; dst->pca_rows.clear(); dst->flags = 0; dst->apart_valid = false;
+        dst->have_stats = false; dst->have_rsvd = false; dst->n_pca = 0; dst->pca_rows.clear(); dst->flags = 0; dst->apart_valid = false; dst->rmax_valid = false;
         free_eigensnp(dst);
         if (dst->d_r && dst->cap_stats_pad < new_pad) free_stats(dst);      // (allocated for a smaller block: the next stats pass re-makes them)
         if (dst->d_r) {

@@ -150,14 +150,14 @@ static int k2_panel(gpca_handle* h, const PanelView& pv, const int8_t* Td_half, 
 }
 
 // Y = A^T T  (T' = r o T already in dT, c = b^T T in d_c); rank-local part, the exchange of Y follows in the caller
-static int stage_AtT_local(gpca_handle* h) {
+static int stage_AtT_local(gpca_handle* h, bool planes_ready = false) {
     const double elems = (double)h->M * (double)h->N;
     if (h->precision == GPCA_PREC_I8_EXACT) {
         // T' (f32 row-major in dT) -> digit planes; exact int8 product; integer partials summed exactly in f64.
         // The kernels are 32 columns wide: a 64-column sketch (32 < l <= 64) runs as two column halves over the same genotypes.
         const int L = h->L, halves = L / 32;
         const size_t td_half = (size_t)h->Mpad * 32 * kDigits;
-        for (int hf = 0; hf < halves; ++hf) {
+        for (int hf = 0; hf < halves && !planes_ready; ++hf) {      // (planes_ready: the sketch's digit planes came straight out of k_omega)
             const float* Th = h->dT + 32 * hf;
             double* tsc = h->d_tscale + 32 * hf; double* tin = h->d_tinv + 32 * hf;
             if (h->apart_valid) launch_quantize_f32_premax(h->st, Th, h->Mpad, h->Mpad, h->apart_src[hf], h->apart_parts, tsc, tin, h->dTd + hf * td_half, 0, h->nd, L);
@@ -335,9 +335,12 @@ static int stage_orth(gpca_handle* h) {
         const int64_t parts = gram_num_parts(h->N);
         launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
         HIPCHK(hipGetLastError());
-        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
-        HIPCHK(hipGetLastError());
-        launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
+        if (parts <= 64) launch_sum_chol_inv(h->st, h->d_part64, parts, l, L, h->dZ, h->d_cholflag);    // (always, for the sample-side Grams below 262 144 samples)
+        else {
+            launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
+            HIPCHK(hipGetLastError());
+            launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
+        }
         HIPCHK(hipGetLastError());
         if (round == 0) launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, nullptr, h->ldg);
         else launch_apply_right_tail(h->st, h->dY, h->N, L, h->dZ, h->dQ, h->ldg, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L);
@@ -395,6 +398,7 @@ static int ensure_workspace(gpca_handle* h) {
             HIPCHK(hipMalloc((void**)&h->d_qscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, 64 * 8));
             HIPCHK(hipMalloc((void**)&h->d_tscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, 64 * 8));
             HIPCHK(hipMalloc((void**)&h->d_amax_run, 64 * 8));
+            HIPCHK(hipMalloc((void**)&h->d_rmax, 4));
         }
     }
     size_t cap2 = h->cap_scores;
@@ -446,16 +450,22 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         // 1. sketch: T' = r o Omega, c = b^T Omega
         ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
         if (h->precision == GPCA_PREC_I8_EXACT) {
-            HIPCHK(hipMemsetAsync(h->d_apart, 0, 32 * 8, h->st));
-            launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dT, h->d_cpart, L == 32 ? h->d_apart : nullptr, 0);
-            h->apart_valid = L == 32; h->apart_parts = 1; h->apart_src[0] = h->d_apart; h->apart_src[1] = nullptr;
+            // the digit planes of T' leave k_omega directly, scaled by the analytic bound 6.67 * max r (no f32 T', no quantisation pass)
+            if (!h->rmax_valid) {
+                HIPCHK(hipMemsetAsync(h->d_rmax, 0, 4, h->st));
+                launch_max_f32(h->st, h->d_r, h->Mpad, h->d_rmax);
+                HIPCHK(hipGetLastError());
+                h->rmax_valid = true;
+            }
+            launch_omega_planes(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->d_cpart, h->dTd, h->d_rmax, h->d_tscale, h->d_tinv, h->nd);
+            h->apart_valid = false;
         } else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart, nullptr, 1);
         HIPCHK(hipGetLastError());
         return GPCA_OK;
     };
     LOCAL(omega());
     LOCAL(stage_sum_c(h, omega_num_parts(h->Mpad)));
-    LOCAL(stage_AtT_local(h));                       // Y = A^T Omega
+    LOCAL(stage_AtT_local(h, h->precision == GPCA_PREC_I8_EXACT));                       // Y = A^T Omega (exact path: planes already made)
     EXCHANGE(h->dY, h->N * (int64_t)L);
     LOCAL(stage_orth(h));
     // 2. power iterations

@@ -67,6 +67,12 @@ int64_t omega_num_parts(int64_t Mpad);
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
                   const float* r, const float* b, float* Tb, float* cpart, double* apart, int blocked = 1);
 
+// exact-integer path: the digit planes of T' = r o Omega directly (analytic column bound 6.67 * rmax[0]; no f32 T')
+void launch_omega_planes(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
+                         const float* b, float* cpart, int8_t* Td, const float* rmax, double* tscale, double* tinv, int nd);
+// out[0] = max_i r[i] for r >= 0 (the caller zeroes out first)
+void launch_max_f32(hipStream_t st, const float* r, int64_t n, float* out);
+
 // K1: T = r o (G Q) + b s^T.  Tb != NULL: write r o T blocked into Tb and cpart[wave][j] = sum_i b_i T_ij
 // (power iteration); Tb == NULL: write T row-major into Tout (projection B = A Q).  Qb is the blocked basis.
 struct GqPlan { int64_t units; int64_t waves; };   // 32-row units of the padded matrix; resident waves (multiple of 4)
@@ -105,6 +111,8 @@ void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax
                      double* scale, double* inv, int nd = 4);
 // W = R^T R (n x n, pitch ld <= 64), Z = R^-1; *flag = j + 1 on a non-positive pivot (first failure wins)
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag);
+// the same from the P <= 64 unsummed Gram partials [P][ld][ld] (sum + factorisation + inverse in one launch)
+void launch_sum_chol_inv(hipStream_t st, const double* part, int64_t P, int n, int ld, double* Z, int* flag);
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qb,
                                 int64_t rows_pad);
 // out[n][kc] = sum_j X[n][j] Z[j][kc]   (Z: [L][K] f64)

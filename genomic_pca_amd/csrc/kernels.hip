@@ -360,7 +360,8 @@ int64_t omega_num_parts(int64_t Mpad) { return (Mpad + 63) / 64; }
 __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
                                                const float* __restrict__ r, const float* __restrict__ b,
                                                float* __restrict__ Tb, float* __restrict__ cpart, double* __restrict__ apart,
-                                               int blocked) {
+                                               int blocked, int8_t* __restrict__ Td, const float* __restrict__ rmax,
+                                               double* __restrict__ tscale, double* __restrict__ tinv, int nd) {
     // Each lane draws the L normals of its own SNP row; the wave's 64 x L tile is staged in LDS (pitch L + 1) so that
     //   * T' = r o Omega leaves as full rows, lane-contiguous (a lane writing its row 4 bytes at a time at a 128-byte
     //     stride cost 4.3x write amplification), and
@@ -398,12 +399,53 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
             const float zf = (4 * jq + t < l) ? (float)z[t] : 0.f;
             zt[wv][lane][4 * jq + t] = zf;
             // the blocked operand layout of the f32 path interleaves rows: its lane-per-row stores are already contiguous
-            if (blocked && i < Mpad) Tb[blocked_t_index(i, 4 * jq + t, LT)] = rs[wv][lane] * zf;
+            if (blocked && Tb && i < Mpad) Tb[blocked_t_index(i, 4 * jq + t, LT)] = rs[wv][lane] * zf;
         }
     }
     __syncthreads();
+    if (Td) {
+        // Exact-integer path: the digit planes of T' = r o Omega leave this kernel directly (no f32 T', no quantisation pass over
+        // it).  The column scale is an analytic bound instead of the measured maximum: |z| <= sqrt(-2 ln 2^-32) = 6.6604 for the
+        // Box-Muller draw above and r <= rmax, so |T'| <= 6.67 rmax -- at M = 10^6 rows that is within a factor ~2 of the measured
+        // maximum (one bit of the 28), and the same for every column, shard and panel.
+        const double bound = 6.67 * (double)rmax[0];
+        const double S = nd == 3 ? kDigitScale3 : kDigitScale;
+        const double inv = bound > 0.0 ? S / bound : 0.0;
+        if (blockIdx.x == 0 && (int)threadIdx.x < L) {
+            tscale[threadIdx.x] = ((int)threadIdx.x < l && bound > 0.0) ? bound / S : 0.0;
+            tinv[threadIdx.x] = ((int)threadIdx.x < l) ? inv : 0.0;
+        }
+        const int cc = lane & 31, hh = lane >> 5;
+        for (int hf = 0; hf < LT; ++hf)
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int64_t blk = (i0 >> 5) + b2;
+                if (blk * 32 >= Mpad) break;
+                unsigned w[kDigits][4];
+#pragma unroll
+                for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[d][q] = 0u;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int row = 32 * b2 + 16 * hh + j;
+                    const float t = __fmul_rn(rs[wv][row], zt[wv][row][32 * hf + cc]);
+                    int v = __double2int_rn((double)t * inv);
+#pragma unroll
+                    for (int d = 0; d < kDigits; ++d) {
+                        int dg;
+                        if (nd == 3) { if (d < 2) { dg = ((v + 128) & 255) - 128; v = (v - dg) >> 8; } else { dg = v; v = 0; } }
+                        else if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
+                        w[d][j >> 2] |= ((unsigned)(dg & 0xff)) << (8 * (j & 3));
+                    }
+                }
+                int8_t* out = Td + (size_t)hf * (size_t)Mpad * 32 * kDigits;
+#pragma unroll
+                for (int d = 0; d < kDigits; ++d)
+                    *reinterpret_cast<uint4*>(out + ((blk * kDigits + d) * 64 + lane) * 16) = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
+            }
+    }
     // T' rows: element e = row * L + col of the tile, lanes take consecutive elements
-    if (!blocked)
+    if (!blocked && Tb)
         for (int e = lane; e < 64 * L; e += 64) {
             const int row = e / L, col = e % L;
             const int64_t gr = i0 + row;
@@ -443,7 +485,30 @@ void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t
                   const float* b, float* Tb, float* cpart, double* apart, int blocked) {
     const int64_t waves = omega_num_parts(Mpad);
     hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
-                       cpart, apart, blocked);
+                       cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4);
+}
+// Exact-integer path: T' = r o Omega straight into digit planes Td ([L/32 halves][Mpad/32][kDigits][64][16 B]) against the analytic
+// column bound 6.67 * rmax; tscale / tinv [L] receive the scale (columns >= l: 0); cpart as above.  No f32 copy of T'.
+void launch_omega_planes(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
+                         const float* b, float* cpart, int8_t* Td, const float* rmax, double* tscale, double* tinv, int nd) {
+    const int64_t waves = omega_num_parts(Mpad);
+    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
+                       cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd);
+}
+// rmax[0] = max_i r[i] (r >= 0: non-negative floats order like their bit patterns); the caller zeroes rmax first
+__global__ __launch_bounds__(256) void k_max_f32(const float* __restrict__ r, int64_t n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a = fmaxf(a, r[i]);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) { if ((int)threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]); __syncthreads(); }
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(red[0]));
+}
+void launch_max_f32(hipStream_t st, const float* r, int64_t n, float* out) {
+    int64_t blocks = (n + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    hipLaunchKernelGGL(k_max_f32, dim3((unsigned)blocks), dim3(256), 0, st, r, n, out);
 }
 
 __global__ __launch_bounds__(256) void k_reduce_y(const float* __restrict__ Ypart, int W, int64_t Npad, int64_t N, int L,
@@ -834,6 +899,69 @@ __global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, 
         for (int i = 0; i < NN; ++i) Zg[i * NN + c] = (i < n && c < n) ? x[i] : 0.0;
     }
 }
+// The same factorisation with the sum over the Gram partials folded in, and the matrix in LDS instead of registers: 256 threads add
+// the P <= 64 slices in a fixed order into LDS, then wave 0 carries on alone.  Lane c owns column c (Ws[r][c], lanes side by side:
+// conflict-free); the element R[j][r] every lane needs for its update is ONE broadcast ds_read of what lane r wrote.  A single
+// wave's LDS instructions execute in issue order, so no barrier is involved -- the wavefront fences only keep the compiler from
+// moving reads above the writes they depend on -- and the loops are run-time loops (fully unrolled, with the column in registers,
+// the compiler hoisted hundreds of broadcast reads and spilled 7 KB per lane at NN = 64).  k_chol_inv spends two v_readlane plus
+// wait states per FMA on one serial chain (20-25 us at n = 30); here a step is a handful of pipelined LDS operations.  Every
+// element sees the same operations in the same order as in k_chol_inv.
+template <int NN>
+__global__ __launch_bounds__(256) void k_sum_chol_inv(const double* __restrict__ part, int P, int n, double* __restrict__ Zg,
+                                                      int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double chol_smem[];   // dynamic: 66 KB at NN = 64 (opted in per device, init_device_kernels_common)
+    double* Ws = chol_smem;                // the Gram matrix, then (upper triangle, row by row) R
+    double* Xs = chol_smem + NN * NN;      // R^-1, column c by lane c
+    double* Dinv = chol_smem + 2 * NN * NN;
+    for (int e = threadIdx.x; e < NN * NN; e += 256) {
+        double a = 0.0;
+        for (int p = 0; p < P; ++p) a += part[(int64_t)p * NN * NN + e];
+        const int r = e / NN, cc = e % NN;
+        Ws[e] = (r < n && cc < n) ? a : ((r == cc) ? 1.0 : 0.0);     // rows / columns n..NN-1 are treated as identity
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int c = threadIdx.x & (NN - 1);
+    const bool act = (int)threadIdx.x < NN;
+    const double d0own = Ws[c * NN + c];                              // column c's own squared norm before the elimination
+    for (int j = 0; j < NN; ++j) {
+        double piv = Ws[j * NN + j];                                  // what is left of column j's squared norm
+        const double d0 = __shfl(d0own, j);
+        if (!isfinite(piv) || !isfinite(d0)) {
+            if (threadIdx.x == 0) atomicCAS(flag, 0, j + 1);
+            piv = 1.0;
+        }
+        const bool dependent = !(piv > kCholRankTol * d0);            // (see CholStep: the column leaves the basis)
+        const double dj = dependent ? 0.0 : rsqrt_nr(piv);
+        double my = Ws[j * NN + c];
+        my = (c == j) ? piv * dj : my * dj;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (every lane has read the pivot before row j is overwritten)
+        if (act) Ws[j * NN + c] = my;                                 // row j of R
+        if (threadIdx.x == 0) Dinv[j] = dj;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll 4
+        for (int r = j + 1; r < NN; ++r) {
+            const double v = Ws[r * NN + c] - Ws[j * NN + r] * my;
+            if (act) Ws[r * NN + c] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // R^-1: lane c back-substitutes R x = e_c from the bottom row up
+    for (int i = NN - 1; i >= 0; --i) {
+        double acc = (c == i) ? 1.0 : 0.0;
+#pragma unroll 4
+        for (int k = i + 1; k < NN; ++k) acc -= Ws[i * NN + k] * Xs[k * NN + c];
+        const double xi = acc * Dinv[i];
+        if (act) Xs[i * NN + c] = xi;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (act) Zg[i * NN + c] = (i < n && c < n) ? xi : 0.0;
+    }
+}
+void launch_sum_chol_inv(hipStream_t st, const double* part, int64_t P, int n, int ld, double* Z, int* flag) {
+    if (ld == 32) hipLaunchKernelGGL(k_sum_chol_inv<32>, dim3(1), dim3(256), (2 * 32 * 32 + 32) * sizeof(double), st, part, (int)P, n, Z, flag);
+    else hipLaunchKernelGGL(k_sum_chol_inv<64>, dim3(1), dim3(256), (2 * 64 * 64 + 64) * sizeof(double), st, part, (int)P, n, Z, flag);
+}
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
     if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
     else hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
@@ -882,7 +1010,9 @@ __global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, cons
     for (int e = threadIdx.x; e < total; e += 256) dst[e] = osm[(e / K) * KP + (e % K)];
 }
 int init_device_kernels_common() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    if (e == 0) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sum_chol_inv<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return e;
 }
 static size_t rightmul_lds(int L, int K, bool f32out) { return sizeof(double) * L * K + (f32out ? sizeof(float) * 256 * (size_t)(K | 1) : 0); }
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
