@@ -187,6 +187,93 @@ void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& pl
     else hipLaunchKernelGGL((k_gq_i8<0>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
 }
 
+// K1 for at most 256 samples (configs[2]'s shape class: 1 066 557 SNPs x 64 samples).  The wide kernels sweep rows padded to 256
+// samples in 128-sample stages and spend most of a launch on padding and per-round prologues (0.5 TB/s at N = 64).  Here the
+// digit planes of ALL of Q sit in registers (NSU x 4 steps x 4 planes), a wave streams its own range of 32-row units -- only the
+// 128-byte lines that hold samples -- PF units ahead, and the launch is bound by its output (128 B of T per row against 64-128 B
+// of genotypes).  Same arithmetic, same epilogue, same per-unit c partials and per-wave abs-max as the other K1 kernels.
+template <int NSU>
+struct GqnG { i32x4 g[4 * NSU]; };
+template <int NSU>
+__device__ __forceinline__ void gqn_load(GqnG<NSU>& b, const int8_t* __restrict__ G, int64_t ldg, int64_t unit, int c, int h) {
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + unit * 32 * ldg);
+    const uint32_t vo = (uint32_t)(c * ldg + 16 * h);
+#pragma unroll
+    for (int j = 0; j < 4 * NSU; ++j) b.g[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, vo, 32u * j, 2);   // nt: streamed once per pass
+}
+template <int NSU, int PF>
+__global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, int64_t ldg, int64_t units,
+                                                  const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
+                                                  const float* __restrict__ rv, const float* __restrict__ bv,
+                                                  const float* __restrict__ sv, float* __restrict__ Tout,
+                                                  float* __restrict__ cunit, double* __restrict__ apart, int scale_out, int64_t ldt) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, waves = (int64_t)gridDim.x * 4;
+    const int64_t u0 = (units * wave) / waves, u1 = (units * (wave + 1)) / waves;
+    const float sj = sv[c];
+    const double qs = qscale[c];
+    float amax = 0.f;
+    if (u0 < u1) {
+        i32x4 q[4 * NSU][kDigits];
+        {
+            const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd);
+#pragma unroll
+            for (int j = 0; j < 4 * NSU; ++j)
+#pragma unroll
+                for (int d = 0; d < kDigits; ++d) q[j][d] = __builtin_amdgcn_raw_buffer_load_b128(rq, (uint32_t)(lane * 16), (uint32_t)((j * kDigits + d) * 1024), 0);
+        }
+        GqnG<NSU> gb[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) gqn_load<NSU>(gb[p], G, ldg, (u0 + p < u1) ? u0 + p : u1 - 1, c, h);
+        for (int64_t u = u0; u < u1; u += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int64_t unit = u + p;
+                if (unit < u1) {                                        // (wave-uniform)
+                    i32x16 acc[kDigits];
+#pragma unroll
+                    for (int d = 0; d < kDigits; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[d][e] = 0;
+#pragma unroll
+                    for (int j = 0; j < 4 * NSU; ++j)
+#pragma unroll
+                        for (int d = 0; d < kDigits; ++d) acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(gb[p].g[j], q[j][d], acc[d], 0, 0, 0);
+                    const int64_t nxt = unit + PF;
+                    gqn_load<NSU>(gb[p], G, ldg, nxt < u1 ? nxt : u1 - 1, c, h);   // the slot's next unit, PF - 1 others still in flight
+                    float ct = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t row = unit * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float ri = rv[row], bi = bv[row];
+                        const float gq = (float)(combine_digits(acc, e) * qs);
+                        const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+                        ct = __fmaf_rn(bi, tv, ct);
+                        const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
+                        amax = fmaxf(amax, fabsf(ov));
+                        Tout[row * ldt + c] = ov;
+                    }
+                    GPCA_STORE_CUNIT(unit)
+                }
+            }
+        }
+    }
+    const float am = fmaxf(amax, __shfl_xor(amax, 32));
+    if (h == 0) apart[wave * 32 + c] = (double)am;
+}
+// Npad = padded sample count of Qd's planes (multiple of 256); N = samples (<= 256)
+int launch_gq_n(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
+                const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
+                int scale_out, int64_t ldt) {
+    if (N < 1 || N > 256 || ldg < 256 || plan.units < 1) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
+    if (N <= 128) hipLaunchKernelGGL((k_gq_n<1, 6>), grid, blk, 0, st, G, ldg, plan.units, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
+    else hipLaunchKernelGGL((k_gq_n<2, 4>), grid, blk, 0, st, G, ldg, plan.units, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
@@ -243,7 +330,10 @@ __device__ __forceinline__ void gtt8_compute(const Gtt8Buf& b, i32x16 (&acc)[4][
         for (int t = 0; t < 4; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.t[d], bt[t], acc[t][d], 0, 0, 0);
 }
 
-template <int AUX>
+// NARROW (at most 256 samples, configs[2]'s shape class): a row has one or two 128-sample blocks, so the four waves of a workgroup
+// take four different ROW chunks (`ngroups` then holds the number of 128-sample blocks that hold samples, 1 or 2) instead of four
+// adjacent sample blocks of one row chunk -- three of which would be padding.
+template <int AUX, bool NARROW = false>
 __global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G, int64_t ldg, int64_t Mpad, int64_t Npad,
                                                     const int8_t* __restrict__ Td, double* __restrict__ Ypart,
                                                     int64_t ngroups, int64_t rows_per_wave) {
@@ -252,9 +342,16 @@ __global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G,
     const int c = lane & 31, h = lane >> 5;
     // (an XCD-aware block -> (row chunk, n-group) remap was measured: no gain -- the skinny operand is already
     //  L2/MALL-served -- and its padded grid broke the all-blocks-resident property, so the plain mapping stays)
-    const int64_t ngroup = blockIdx.x % ngroups;
-    const int64_t wchunk = blockIdx.x / ngroups;
-    const int64_t nblock = ngroup * 4 + wv;
+    int64_t wchunk, nblock;
+    if (NARROW) {
+        const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+        nblock = wave % ngroups; wchunk = wave / ngroups;
+        if (wchunk * rows_per_wave >= Mpad) return;
+    } else {
+        const int64_t ngroup = blockIdx.x % ngroups;
+        wchunk = blockIdx.x / ngroups;
+        nblock = ngroup * 4 + wv;
+    }
     const int64_t n0 = nblock * 128;
     if (n0 >= Npad) return;
     const int64_t m_begin = wchunk * rows_per_wave;
@@ -317,6 +414,27 @@ __global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G,
             *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
         }
     }
+}
+
+// K2 for at most 256 samples (int8 rows): plan = gtt8_plan_narrow; every wave owns a row chunk of its own
+Gtt8Plan gtt8_plan_narrow(int64_t Mpad, int64_t N, int target_waves) {
+    Gtt8Plan p;
+    p.nblocks_n = (N + 127) / 128;                      // 128-sample blocks that hold samples: 1 or 2
+    int64_t W = target_waves / p.nblocks_n;
+    if (W < 1) W = 1;
+    const int64_t maxW = Mpad / 128;
+    if (W > maxW) W = maxW;
+    int64_t rpw = (Mpad + W - 1) / W;
+    rpw = (rpw + 127) / 128 * 128;
+    W = (Mpad + rpw - 1) / rpw;
+    p.W = (int)W;
+    p.rows_per_wave = rpw;
+    p.grid = (W * p.nblocks_n + 3) / 4;
+    return p;
+}
+void launch_gtt_n(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
+                  double* Ypart, const Gtt8Plan& plan) {
+    hipLaunchKernelGGL((k_gtt_i8<2, true>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, plan.nblocks_n, plan.rows_per_wave);
 }
 
 void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,

@@ -132,11 +132,21 @@ static int stage_sum_c(gpca_handle* h, int64_t parts) {
 }
 
 
+// At most 256 samples on int8 rows (configs[2]'s shape class): the narrow kernels (gemm_i8.hip: k_gq_n, k_gtt_i8<.., NARROW>)
+static inline bool narrow_shape(const gpca_handle* h) {
+    return h->narrow_ok && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_INT8 && h->N <= kNarrowSamples;
+}
+static inline Gtt8Plan k2_plan(const gpca_handle* h, int64_t rows_pad) {
+    return narrow_shape(h) ? gtt8_plan_narrow(rows_pad, h->N, std::min(h->gtt_waves_target, 1024)) :   // (one wave per SIMD: k_gtt_i8 holds 1 workgroup per CU)
+                            gtt8_plan(rows_pad, h->ldg, h->gtt_waves_target);
+}
+
 // K2 of one 32-column half over one panel: Ypart = (digit planes of T')^T G, exact integers
 static int k2_panel(gpca_handle* h, const PanelView& pv, const int8_t* Td_half, const Gtt8Plan& plan) {
     const int8_t* Td = Td_half + (size_t)(pv.row0 >> 5) * kPlaneBytesPerBlock;
     const bool packed = h->storage == GPCA_STORE_2BIT;
-    if (h->lds_planes && h->gtt_dma && !packed) {
+    if (narrow_shape(h)) launch_gtt_n(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan);
+    else if (h->lds_planes && h->gtt_dma && !packed) {
         const int e = launch_gtt_d(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d launch failed (hip error " + std::to_string(e) + ")");
     } else if (((h->lds_planes && h->gtt_dma) || h->nd == 3) && packed) {   // (three planes: only this kernel)
@@ -172,7 +182,7 @@ static int stage_AtT_local(gpca_handle* h, bool planes_ready = false) {
             const double by = h->storage == GPCA_STORE_2BIT ? elems / 4 : elems;
             ScopedTimer sweep(h, "gemm_GtT", 2.0 * elems * h->l, by * halves, nullptr, streamed);
             CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
-                const Gtt8Plan plan = streamed ? gtt8_plan(pv.rows_pad, h->ldg, h->gtt_waves_target) : h->plan8;
+                const Gtt8Plan plan = streamed ? k2_plan(h, pv.rows_pad) : h->plan8;
                 for (int hf = 0; hf < halves; ++hf) {
                     {
                         ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l / halves, by, nullptr, !streamed);
@@ -228,6 +238,10 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                     double* ap = h->d_apart + hf * ahalf;
                     ScopedTimer t(h, "gemm_GQ", 2.0 * elems * h->l / halves, by, nullptr, !streamed);
                     if (packed) launch_gq_2bit(h->st, pv.g2, h->ld2, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, h->nd, L);
+                    else if (narrow_shape(h)) {
+                        const int e = launch_gq_n(h->st, pv.g8, h->ld8, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L);
+                        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_n launch failed (hip error " + std::to_string(e) + ")");
+                    }
                     else if (h->lds_planes && h->gq_dma) {
                         const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
                         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
@@ -238,7 +252,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                     }
                     else launch_gq_i8(h->st, pv.g8, h->ld8, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, scale_out, L, h->ko);
                     HIPCHK(hipGetLastError());
-                    if (streamed && scale_out && (packed || h->lds_planes)) {   // (streamed: the per-launch timer above is disabled) fold this panel's column abs-max before the next launch reuses ap
+                    if (streamed && scale_out && (packed || h->lds_planes || narrow_shape(h))) {   // (streamed: the per-launch timer above is disabled) fold this panel's column abs-max before the next launch reuses ap
                         launch_absmax_fold(h->st, ap, plan.waves, h->d_amax_run + 32 * hf);
                         HIPCHK(hipGetLastError());
                     }
@@ -251,7 +265,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                 launch_sum_partials_f32(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, 32, h->d_c + 32 * hf, h->d_scratch64);
                 HIPCHK(hipGetLastError());
             }
-        h->apart_valid = scale_out != 0 && (packed || h->lds_planes);   // (k_gq_i8 has no abs-max epilogue)
+        h->apart_valid = scale_out != 0 && (packed || h->lds_planes || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
         for (int hf = 0; hf < 2; ++hf) h->apart_src[hf] = streamed ? h->d_amax_run + 32 * hf : h->d_apart + hf * ahalf;
         h->apart_parts = streamed ? 1 : h->gqplan.waves;
         return GPCA_OK;
@@ -285,7 +299,7 @@ static int stage_power_fused(gpca_handle* h) {
         ScopedTimer sweep(h, "gemm_fused", 4.0 * elems * h->l, by * halves);
         CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
             const GqPlan plan1 = gq_plan(pv.rows_pad, h->gq_waves_target);
-            const Gtt8Plan plan2 = gtt8_plan(pv.rows_pad, h->ldg, h->gtt_waves_target);
+            const Gtt8Plan plan2 = k2_plan(h, pv.rows_pad);
             const float* rr = h->d_r + pv.row0; const float* bb = h->d_b + pv.row0;
             for (int hf = 0; hf < halves; ++hf) {
                 const int8_t* Qd = h->dQd + hf * qhalf;
@@ -293,6 +307,10 @@ static int stage_power_fused(gpca_handle* h) {
                 float* cp = h->d_cpart + hf * chalf + (size_t)pv.row0;
                 double* ap = h->d_apart + hf * ahalf;
                 if (packed) launch_gq_2bit(h->st, pv.g2, h->ld2, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, h->nd, L);
+                else if (narrow_shape(h)) {
+                    const int e = launch_gq_n(h->st, pv.g8, h->ld8, plan1, h->N, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L);
+                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_n launch failed (hip error " + std::to_string(e) + ")");
+                }
                 else if (h->gq_dma) {
                     const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
                     if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
@@ -324,14 +342,17 @@ static int stage_power_fused(gpca_handle* h) {
     return GPCA_OK;
 }
 
-// CholeskyQR2 of dY -> dQ (f32, padded), s = 1^T Q
-static int stage_orth(gpca_handle* h) {
+// CholeskyQR of dY -> dQ (f32, padded), s = 1^T Q.  rounds = 2 (CholeskyQR2): orthonormal to rounding -- the basis the projection and
+// the scores are built on.  rounds = 1: the basis of an INTERMEDIATE power iteration, which only has to span range(Y) with a modest
+// condition number: after one round ||Q^T Q - I|| ~ cond(Y)^2 eps (1e-11 at a spectrum ratio of 500), and wherever that is not small
+// the second round could not have repaired the first either.  A third of the Gram / Cholesky / apply launches of a call (q = 2) go.
+static int stage_orth(gpca_handle* h, int rounds = 2) {
     const int L = h->L, l = h->l;
     if (h->d_smask) {   // basis learning on a sample subset (gpca_set_sample_mask): the other samples' rows leave the sketch
         launch_mask_rows(h->st, h->dY, h->N, L, h->d_smask);
         HIPCHK(hipGetLastError());
     }
-    for (int round = 0; round < 2; ++round) {      // CholeskyQR2, entirely on the stream (no host round trip)
+    for (int round = 0; round < rounds; ++round) {      // entirely on the stream (no host round trip)
         const int64_t parts = gram_num_parts(h->N);
         launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
         HIPCHK(hipGetLastError());
@@ -342,7 +363,7 @@ static int stage_orth(gpca_handle* h) {
             launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
         }
         HIPCHK(hipGetLastError());
-        if (round == 0) launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, nullptr, h->ldg);
+        if (round + 1 < rounds) launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, nullptr, h->ldg);
         else launch_apply_right_tail(h->st, h->dY, h->N, L, h->dZ, h->dQ, h->ldg, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L);
         HIPCHK(hipGetLastError());
     }
@@ -388,7 +409,7 @@ static int ensure_workspace(gpca_handle* h) {
         HIPCHK(hipMalloc((void**)&h->d_cholflag, 4));
     }
     if (h->precision == GPCA_PREC_I8_EXACT) {
-        h->plan8 = gtt8_plan(gemm_rows, Npad, h->gtt_waves_target);
+        h->plan8 = k2_plan(h, gemm_rows);
         CHK(ensure(h, h->dQd, h->cap_Qd, (size_t)Npad * 32 * kDigits * (size_t)(L / 32)));
         CHK(ensure(h, h->dTd, h->cap_Td, (size_t)h->Mpad * 32 * kDigits * (size_t)(L / 32)));
         CHK(ensure(h, h->dYpart64, h->cap_Ypart64, (size_t)h->plan8.W * (size_t)Npad * 32));
@@ -467,14 +488,14 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     LOCAL(stage_sum_c(h, omega_num_parts(h->Mpad)));
     LOCAL(stage_AtT_local(h, h->precision == GPCA_PREC_I8_EXACT));                       // Y = A^T Omega (exact path: planes already made)
     EXCHANGE(h->dY, h->N * (int64_t)L);
-    LOCAL(stage_orth(h));
+    LOCAL(stage_orth(h, power_iters == 0 ? 2 : 1));   // (the last basis before the projection gets CholeskyQR2, the earlier ones one round)
     // 2. power iterations
-    const bool fused = h->sm.on && h->sm.fused && (h->storage == GPCA_STORE_2BIT || h->lds_planes);   // (k_gq_i8 has no abs-max epilogue)
+    const bool fused = h->sm.on && h->sm.fused && (h->storage == GPCA_STORE_2BIT || h->lds_planes || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
     for (int it = 0; it < power_iters; ++it) {
         if (fused) LOCAL(stage_power_fused(h));
         else { LOCAL(stage_AQ(h, 1)); LOCAL(stage_AtT_local(h)); }
         EXCHANGE(h->dY, h->N * (int64_t)L);
-        LOCAL(stage_orth(h));
+        LOCAL(stage_orth(h, it + 1 == power_iters ? 2 : 1));
     }
     // 3. projection B = A Q, small eigenproblem of B^T B
     LOCAL(stage_AQ(h, 0));

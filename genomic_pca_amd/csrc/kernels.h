@@ -154,6 +154,15 @@ struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid;
 Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves);
 void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
                    double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko = KernelOpts());
+// narrow matrices (N <= 256 samples, int8 rows): every wave owns its own row range, Q's digit planes stay in registers (K1) /
+// the four waves of a workgroup take four row chunks instead of four sample blocks (K2).  launch_gq_n returns a hipError_t value.
+constexpr int64_t kNarrowSamples = 256;
+Gtt8Plan gtt8_plan_narrow(int64_t Mpad, int64_t N, int target_waves);
+void launch_gtt_n(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
+                  const Gtt8Plan& plan);
+int launch_gq_n(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
+                const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
+                int scale_out, int64_t ldt = 32);
 void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
                         const double* tscale, double* Y, int64_t ldy = 32);
 void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first);

@@ -899,68 +899,44 @@ __global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, 
         for (int i = 0; i < NN; ++i) Zg[i * NN + c] = (i < n && c < n) ? x[i] : 0.0;
     }
 }
-// The same factorisation with the sum over the Gram partials folded in, and the matrix in LDS instead of registers: 256 threads add
-// the P <= 64 slices in a fixed order into LDS, then wave 0 carries on alone.  Lane c owns column c (Ws[r][c], lanes side by side:
-// conflict-free); the element R[j][r] every lane needs for its update is ONE broadcast ds_read of what lane r wrote.  A single
-// wave's LDS instructions execute in issue order, so no barrier is involved -- the wavefront fences only keep the compiler from
-// moving reads above the writes they depend on -- and the loops are run-time loops (fully unrolled, with the column in registers,
-// the compiler hoisted hundreds of broadcast reads and spilled 7 KB per lane at NN = 64).  k_chol_inv spends two v_readlane plus
-// wait states per FMA on one serial chain (20-25 us at n = 30); here a step is a handful of pipelined LDS operations.  Every
-// element sees the same operations in the same order as in k_chol_inv.
+// The same factorisation with the sum over the P <= 64 Gram partials folded in (one launch and one trip through global memory
+// less per CholeskyQR round): 256 threads add the slices into LDS -- four independent accumulators per element, combined in a fixed
+// order -- then wave 0 carries on alone with the register / v_readlane factorisation above.  (A version that kept the matrix in LDS
+// and broadcast rows of R with ds_read instead of v_readlane was built and measured: 100-110 us against 25 -- every element update
+// became a read-modify-write through LDS behind a wavefront fence.)
 template <int NN>
 __global__ __launch_bounds__(256) void k_sum_chol_inv(const double* __restrict__ part, int P, int n, double* __restrict__ Zg,
                                                       int* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) double chol_smem[];   // dynamic: 66 KB at NN = 64 (opted in per device, init_device_kernels_common)
-    double* Ws = chol_smem;                // the Gram matrix, then (upper triangle, row by row) R
-    double* Xs = chol_smem + NN * NN;      // R^-1, column c by lane c
-    double* Dinv = chol_smem + 2 * NN * NN;
+    __shared__ double Ws[NN * NN];
     for (int e = threadIdx.x; e < NN * NN; e += 256) {
-        double a = 0.0;
-        for (int p = 0; p < P; ++p) a += part[(int64_t)p * NN * NN + e];
-        const int r = e / NN, cc = e % NN;
-        Ws[e] = (r < n && cc < n) ? a : ((r == cc) ? 1.0 : 0.0);     // rows / columns n..NN-1 are treated as identity
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            a0 += part[(int64_t)p * NN * NN + e]; a1 += part[(int64_t)(p + 1) * NN * NN + e];
+            a2 += part[(int64_t)(p + 2) * NN * NN + e]; a3 += part[(int64_t)(p + 3) * NN * NN + e];
+        }
+        for (; p < P; ++p) a0 += part[(int64_t)p * NN * NN + e];
+        Ws[e] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
-    const int c = threadIdx.x & (NN - 1);
-    const bool act = (int)threadIdx.x < NN;
-    const double d0own = Ws[c * NN + c];                              // column c's own squared norm before the elimination
-    for (int j = 0; j < NN; ++j) {
-        double piv = Ws[j * NN + j];                                  // what is left of column j's squared norm
-        const double d0 = __shfl(d0own, j);
-        if (!isfinite(piv) || !isfinite(d0)) {
-            if (threadIdx.x == 0) atomicCAS(flag, 0, j + 1);
-            piv = 1.0;
-        }
-        const bool dependent = !(piv > kCholRankTol * d0);            // (see CholStep: the column leaves the basis)
-        const double dj = dependent ? 0.0 : rsqrt_nr(piv);
-        double my = Ws[j * NN + c];
-        my = (c == j) ? piv * dj : my * dj;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (every lane has read the pivot before row j is overwritten)
-        if (act) Ws[j * NN + c] = my;                                 // row j of R
-        if (threadIdx.x == 0) Dinv[j] = dj;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll 4
-        for (int r = j + 1; r < NN; ++r) {
-            const double v = Ws[r * NN + c] - Ws[j * NN + r] * my;
-            if (act) Ws[r * NN + c] = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    // R^-1: lane c back-substitutes R x = e_c from the bottom row up
-    for (int i = NN - 1; i >= 0; --i) {
-        double acc = (c == i) ? 1.0 : 0.0;
-#pragma unroll 4
-        for (int k = i + 1; k < NN; ++k) acc -= Ws[i * NN + k] * Xs[k * NN + c];
-        const double xi = acc * Dinv[i];
-        if (act) Xs[i * NN + c] = xi;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (act) Zg[i * NN + c] = (i < n && c < n) ? xi : 0.0;
+    const int c = threadIdx.x;
+    double col[NN], x[NN], dinv[NN];
+#pragma unroll
+    for (int r = 0; r < NN; ++r) col[r] = (r < n && c < n) ? Ws[r * NN + (c & (NN - 1))] : ((r == c) ? 1.0 : 0.0);
+    double diag0 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NN; ++r) diag0 = (r == c) ? col[r] : diag0;
+    CholStep<NN, 0>::run(col, dinv, diag0, c, flag);
+    InvStep<NN, NN - 1>::run(col, x, dinv, c);
+    if (c < NN) {
+#pragma unroll
+        for (int i = 0; i < NN; ++i) Zg[i * NN + c] = (i < n && c < n) ? x[i] : 0.0;
     }
 }
 void launch_sum_chol_inv(hipStream_t st, const double* part, int64_t P, int n, int ld, double* Z, int* flag) {
-    if (ld == 32) hipLaunchKernelGGL(k_sum_chol_inv<32>, dim3(1), dim3(256), (2 * 32 * 32 + 32) * sizeof(double), st, part, (int)P, n, Z, flag);
-    else hipLaunchKernelGGL(k_sum_chol_inv<64>, dim3(1), dim3(256), (2 * 64 * 64 + 64) * sizeof(double), st, part, (int)P, n, Z, flag);
+    if (ld == 32) hipLaunchKernelGGL(k_sum_chol_inv<32>, dim3(1), dim3(256), 0, st, part, (int)P, n, Z, flag);
+    else hipLaunchKernelGGL(k_sum_chol_inv<64>, dim3(1), dim3(256), 0, st, part, (int)P, n, Z, flag);
 }
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
     if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
@@ -1010,9 +986,7 @@ __global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, cons
     for (int e = threadIdx.x; e < total; e += 256) dst[e] = osm[(e / K) * KP + (e % K)];
 }
 int init_device_kernels_common() {
-    int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    if (e == 0) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sum_chol_inv<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    return e;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
 }
 static size_t rightmul_lds(int L, int K, bool f32out) { return sizeof(double) * L * K + (f32out ? sizeof(float) * 256 * (size_t)(K | 1) : 0); }
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,

@@ -914,6 +914,43 @@ def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     assert oracle.max_abs_dpc(res["alt"][1], R["scores"]) < TOL_PC
 
 
+@pytest.mark.parametrize("M,N,k", [(70_001, 64, 20), (70_001, 128, 20), (33_333, 129, 10), (50_000, 256, 40), (40_000, 50, 5), (300, 2, 1)])
+def test_narrow_kernels_same_bits_as_the_wide_ones(gpca, oracle, monkeypatch, M, N, k):
+    """At most 256 samples on int8 rows (BASELINE.json configs[2]'s shape class: 1 066 557 x 64): k_gq_n keeps all of Q's digit
+    planes in registers and streams only the lines that hold samples, the narrow k_gtt_i8 gives every wave a row chunk of its
+    own.  Same integers, same pinned f32 roundings, same per-unit c partials: the results are the wide kernels' bits
+    (GPCA_NARROW=0 runs those on the padded rows) -- resident, streamed 6-pass and fused -- and hold the oracle's parity bar."""
+    from genomic_pca_amd import _lib
+    th = gpca.synth_thresholds(M, 5, seed=2, fst=0.25)
+    l = min(k + 10, N)
+    res = {}
+    for name, env in (("narrow", {}), ("wide", {"GPCA_NARROW": "0"})):
+        with monkeypatch.context() as mp:
+            for key, val in env.items():
+                mp.setenv(key, val)
+            with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
+                e.synth_genotypes(M, N, 2, th)
+                st = e.snp_stats(gpca.QcConfig.none())
+                e.rsvd(k, l - k, 2, seed=4)
+                res[name] = (e.eigenvalues(), e.scores(f64=True), e.loadings(), e.transform())
+                if name == "narrow":
+                    G = e.download_genotypes_i8()
+                    e.stream_open(gpca.PanelSource.synth(th, 2), M, N, panel_rows=8192, ring_slots=2, fused=False)
+                    e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, l - k, 2, seed=4)
+                    assert np.array_equal(e.eigenvalues(), res[name][0]) and np.array_equal(e.scores(f64=True), res[name][1])
+                    e.stream_open(gpca.PanelSource.synth(th, 2), M, N, panel_rows=8192, ring_slots=2, fused=True)
+                    e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, l - k, 2, seed=4)
+                    assert np.max(np.abs(e.eigenvalues() - res[name][0]) / res[name][0]) < 1e-7
+    for a, b in zip(res["narrow"], res["wide"]):
+        assert np.array_equal(a, b)
+    if N >= 50:
+        r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+        R = oracle.rsvd(G, N, r, b, k, l - k, 2, seed=4)
+        nz = R["eigenvalues"] > 1e-9 * R["eigenvalues"][0]
+        assert np.max(np.abs(res["narrow"][0][nz] - R["eigenvalues"][nz]) / R["eigenvalues"][nz]) < TOL_EV
+        assert oracle.max_abs_dpc(res["narrow"][1][:, :3], R["scores"][:, :3]) < TOL_PC
+
+
 @pytest.mark.parametrize("store", ["int8", "2bit"])
 @pytest.mark.parametrize("k,oversample,q", [(22, 10, 2), (6, 0, 0), (1, 3, 1)])
 def test_rsvd_i8_sketch_width_and_iteration_edges(gpca, oracle, store, k, oversample, q):
