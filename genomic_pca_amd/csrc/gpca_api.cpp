@@ -70,6 +70,12 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
         if (dp != 0 && dp != 3 && dp != 4) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes must be 0, 3 or 4"); }
         if (dp == 3 && !(h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT)) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes = 3 is implemented for GPCA_PREC_I8_EXACT with GPCA_STORE_2BIT"); }
         h->nd = dp == 3 ? 3 : 4;
+        // digit_planes = 0 leaves the choice to the library: four planes, or what GPCA_PACKED_PLANES says for the packed kernels (the
+        // switch the whole parity suite is run under to compare the two)
+        if (dp == 0 && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT) {
+            const char* e = getenv("GPCA_PACKED_PLANES");
+            if (e && atoi(e) == 3) h->nd = 3;
+        }
     }
     // diagnostic switches, read once per handle (defaults are the tuned values; DESIGN.md "Diagnostic switches")
     h->gq_waves_target = std::max(4, env_int("GPCA_GQ_WAVES", h->gq_waves_target));
