@@ -193,13 +193,17 @@ void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& pl
 // 128-byte lines that hold samples -- PF units ahead, and the launch is bound by its output (128 B of T per row against 64-128 B
 // of genotypes).  Same arithmetic, same epilogue, same per-unit c partials and per-wave abs-max as the other K1 kernels.
 template <int NSU>
-struct GqnG { i32x4 g[4 * NSU]; };
+struct GqnG { i32x4 g[4 * NSU]; float r, b; };
+// (r and b of the unit's rows ride along, one row per lane: asked for in the epilogue they cost a dependent global-load latency per
+//  unit -- 105 us per launch at 1 066 557 x 64 against 55 with the prefetch)
 template <int NSU>
-__device__ __forceinline__ void gqn_load(GqnG<NSU>& b, const int8_t* __restrict__ G, int64_t ldg, int64_t unit, int c, int h) {
+__device__ __forceinline__ void gqn_load(GqnG<NSU>& b, const int8_t* __restrict__ G, int64_t ldg, int64_t unit, int c, int h,
+                                         const float* __restrict__ rv, const float* __restrict__ bv) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + unit * 32 * ldg);
     const uint32_t vo = (uint32_t)(c * ldg + 16 * h);
 #pragma unroll
     for (int j = 0; j < 4 * NSU; ++j) b.g[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, vo, 32u * j, 2);   // nt: streamed once per pass
+    b.r = rv[unit * 32 + c]; b.b = bv[unit * 32 + c];
 }
 template <int NSU, int PF>
 __global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, int64_t ldg, int64_t units,
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, i
         }
         GqnG<NSU> gb[PF];
 #pragma unroll
-        for (int p = 0; p < PF; ++p) gqn_load<NSU>(gb[p], G, ldg, (u0 + p < u1) ? u0 + p : u1 - 1, c, h);
+        for (int p = 0; p < PF; ++p) gqn_load<NSU>(gb[p], G, ldg, (u0 + p < u1) ? u0 + p : u1 - 1, c, h, rv, bv);
         for (int64_t u = u0; u < u1; u += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
@@ -241,13 +245,15 @@ __global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, i
                     for (int j = 0; j < 4 * NSU; ++j)
 #pragma unroll
                         for (int d = 0; d < kDigits; ++d) acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(gb[p].g[j], q[j][d], acc[d], 0, 0, 0);
+                    const float rrow = gb[p].r, brow = gb[p].b;
                     const int64_t nxt = unit + PF;
-                    gqn_load<NSU>(gb[p], G, ldg, nxt < u1 ? nxt : u1 - 1, c, h);   // the slot's next unit, PF - 1 others still in flight
+                    gqn_load<NSU>(gb[p], G, ldg, nxt < u1 ? nxt : u1 - 1, c, h, rv, bv);   // the slot's next unit, PF - 1 others still in flight
                     float ct = 0.f;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int64_t row = unit * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float ri = rv[row], bi = bv[row];
+                        const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the unit
+                        const int64_t row = unit * 32 + rin;
+                        const float ri = __shfl(rrow, rin), bi = __shfl(brow, rin);
                         const float gq = (float)(combine_digits(acc, e) * qs);
                         const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
                         ct = __fmaf_rn(bi, tv, ct);

@@ -356,12 +356,9 @@ static int stage_orth(gpca_handle* h, int rounds = 2) {
         const int64_t parts = gram_num_parts(h->N);
         launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
         HIPCHK(hipGetLastError());
-        if (parts <= 64) launch_sum_chol_inv(h->st, h->d_part64, parts, l, L, h->dZ, h->d_cholflag);    // (always, for the sample-side Grams below 262 144 samples)
-        else {
-            launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
-            HIPCHK(hipGetLastError());
-            launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
-        }
+        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
+        HIPCHK(hipGetLastError());
+        launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
         HIPCHK(hipGetLastError());
         if (round + 1 < rounds) launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, nullptr, h->ldg);
         else launch_apply_right_tail(h->st, h->dY, h->N, L, h->dZ, h->dQ, h->ldg, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L);

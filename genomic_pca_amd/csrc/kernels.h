@@ -111,8 +111,6 @@ void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax
                      double* scale, double* inv, int nd = 4);
 // W = R^T R (n x n, pitch ld <= 64), Z = R^-1; *flag = j + 1 on a non-positive pivot (first failure wins)
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag);
-// the same from the P <= 64 unsummed Gram partials [P][ld][ld] (sum + factorisation + inverse in one launch)
-void launch_sum_chol_inv(hipStream_t st, const double* part, int64_t P, int n, int ld, double* Z, int* flag);
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qb,
                                 int64_t rows_pad);
 // out[n][kc] = sum_j X[n][j] Z[j][kc]   (Z: [L][K] f64)

@@ -899,45 +899,10 @@ __global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, 
         for (int i = 0; i < NN; ++i) Zg[i * NN + c] = (i < n && c < n) ? x[i] : 0.0;
     }
 }
-// The same factorisation with the sum over the P <= 64 Gram partials folded in (one launch and one trip through global memory
-// less per CholeskyQR round): 256 threads add the slices into LDS -- four independent accumulators per element, combined in a fixed
-// order -- then wave 0 carries on alone with the register / v_readlane factorisation above.  (A version that kept the matrix in LDS
-// and broadcast rows of R with ds_read instead of v_readlane was built and measured: 100-110 us against 25 -- every element update
-// became a read-modify-write through LDS behind a wavefront fence.)
-template <int NN>
-__global__ __launch_bounds__(256) void k_sum_chol_inv(const double* __restrict__ part, int P, int n, double* __restrict__ Zg,
-                                                      int* __restrict__ flag) {
-    __shared__ double Ws[NN * NN];
-    for (int e = threadIdx.x; e < NN * NN; e += 256) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int p = 0;
-        for (; p + 4 <= P; p += 4) {
-            a0 += part[(int64_t)p * NN * NN + e]; a1 += part[(int64_t)(p + 1) * NN * NN + e];
-            a2 += part[(int64_t)(p + 2) * NN * NN + e]; a3 += part[(int64_t)(p + 3) * NN * NN + e];
-        }
-        for (; p < P; ++p) a0 += part[(int64_t)p * NN * NN + e];
-        Ws[e] = (a0 + a1) + (a2 + a3);
-    }
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    const int c = threadIdx.x;
-    double col[NN], x[NN], dinv[NN];
-#pragma unroll
-    for (int r = 0; r < NN; ++r) col[r] = (r < n && c < n) ? Ws[r * NN + (c & (NN - 1))] : ((r == c) ? 1.0 : 0.0);
-    double diag0 = 0.0;
-#pragma unroll
-    for (int r = 0; r < NN; ++r) diag0 = (r == c) ? col[r] : diag0;
-    CholStep<NN, 0>::run(col, dinv, diag0, c, flag);
-    InvStep<NN, NN - 1>::run(col, x, dinv, c);
-    if (c < NN) {
-#pragma unroll
-        for (int i = 0; i < NN; ++i) Zg[i * NN + c] = (i < n && c < n) ? x[i] : 0.0;
-    }
-}
-void launch_sum_chol_inv(hipStream_t st, const double* part, int64_t P, int n, int ld, double* Z, int* flag) {
-    if (ld == 32) hipLaunchKernelGGL(k_sum_chol_inv<32>, dim3(1), dim3(256), 0, st, part, (int)P, n, Z, flag);
-    else hipLaunchKernelGGL(k_sum_chol_inv<64>, dim3(1), dim3(256), 0, st, part, (int)P, n, Z, flag);
-}
+// (Two variants of this kernel were built and measured in round 3, and dropped: the matrix kept in LDS with rows of R broadcast by
+//  ds_read instead of v_readlane -- 100-110 us against 25, every element update became a read-modify-write through LDS behind a
+//  wavefront fence -- and the sum over the Gram partials folded in ahead of the register factorisation -- 45-49 us against 5 + 23:
+//  one workgroup adds 63 slices more slowly than the 16 workgroups of k_sum_partials.)
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
     if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
     else hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);

@@ -11,13 +11,45 @@ __global__ void k_fill(uint32_t* p, int64_t n, uint32_t seed) {
         p[i] = x;
     }
 }
+// "real" operands (argv[2] = real): what the product kernel sees -- 2-bit codes in Hardy-Weinberg-like proportions (55 % / 35 % /
+// 10 % of 0 / 1 / 2, never 3) and the digit planes of an orthonormal basis (planes 0-2 uniform in [-64, 63], the top plane a small
+// signed number): far fewer toggling operand bits than uniform random bytes, which is what the chip's clock responds to.
+__global__ void k_fill_codes(uint32_t* p, int64_t n, uint32_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        uint32_t w = 0;
+        for (int f = 0; f < 16; ++f) {
+            uint32_t x = ((uint32_t)i * 16u + f) * 2654435761u ^ seed; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+            const uint32_t u = x & 255u;
+            w |= (u < 141u ? 0u : (u < 230u ? 1u : 2u)) << (2 * f);
+        }
+        p[i] = w;
+    }
+}
+__global__ void k_fill_planes(int8_t* q, int64_t nsteps, uint32_t seed) {   // [step][4 planes][64 lanes][16 B]
+    const int64_t n = nsteps * 4 * 1024;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+        const int plane = (int)((i >> 10) & 3);
+        int v;
+        if (plane < 3) v = (int)(x & 127u) - 64;
+        else v = (int)__popc(x & 0xffffu) + (int)__popc((x >> 16) & 0xffu) - 12;     // ~N(0, 2.4^2): the top digit of a ~4.5 sigma column maximum
+        q[i] = (int8_t)v;
+    }
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
     const int64_t M = 1000064, N = 10000, Npad = 10240, ld2 = Npad / 4;
     const int waves = argc > 1 ? atoi(argv[1]) : 1024;
     uint8_t* G2; int8_t* Qd; double* qs; float *r, *b, *s, *T, *cp; double* ap;
-    CK(hipMalloc(&G2, M * ld2)); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G2, M * ld2 / 4, 1u);
-    CK(hipMalloc(&Qd, Npad * 32 * 4)); hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, (uint32_t*)Qd, Npad * 32, 2u);
+    const bool real = argc > 2 && argv[2][0] == 'r';
+    CK(hipMalloc(&G2, M * ld2)); CK(hipMalloc(&Qd, Npad * 32 * 4));
+    if (real) {
+        hipLaunchKernelGGL(k_fill_codes, dim3(4096), dim3(256), 0, 0, (uint32_t*)G2, M * ld2 / 4, 1u);
+        hipLaunchKernelGGL(k_fill_planes, dim3(1024), dim3(256), 0, 0, Qd, Npad / 32, 2u);
+    } else {
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G2, M * ld2 / 4, 1u);
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, (uint32_t*)Qd, Npad * 32, 2u);
+    }
     CK(hipMalloc(&qs, 32 * 8)); CK(hipMemset(qs, 0, 32 * 8));
     CK(hipMalloc(&r, M * 4)); CK(hipMalloc(&b, M * 4)); CK(hipMalloc(&s, 32 * 4)); CK(hipMalloc(&T, M * 32 * 4));
     CK(hipMemset(r, 0, M * 4)); CK(hipMemset(b, 0, M * 4)); CK(hipMemset(s, 0, 32 * 4));
@@ -31,7 +63,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); CK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     const double mf = (double)M * Npad * 32 * 4 / 32768.0;   // MFMAs
-    printf("ablate %d waves %d: %.3f ms  (%.1f %% of the i8 MFMA floor %.3f ms)\n", GPCA_ABLATE, waves, ms,
+    printf("ablate %d %s waves %d: %.3f ms  (%.1f %% of the i8 MFMA floor %.3f ms)\n", GPCA_ABLATE, real ? "real-like operands" : "random bytes", waves, ms,
            100.0 * (mf * 32 / (1024 * 2.39e9) * 1e3) / ms, mf * 32 / (1024 * 2.39e9) * 1e3);
 #if GPCA_ABLATE & 16
     {   // steady state: 300 more launches, then read the stamps of the last one
