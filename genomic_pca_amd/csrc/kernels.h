@@ -90,7 +90,7 @@ void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, in
                      double* Y);
 
 // generic tall-skinny helpers
-// scratch: >= 64 * E doubles (kSumScratchElems covers E <= 4096)
+// scratch: >= S * E doubles, S <= 64 slices (<= 256 when E <= 64): kSumScratchElems covers E <= 4096
 constexpr int64_t kSumScratchElems = 64 * 4096;
 void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out, double* scratch);
 void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out, double* scratch);
