@@ -33,6 +33,7 @@ def _worker(rank, world, port, M, N, k, seed, out_dir, poison_rank, streamed):
                 G = e.download_genotypes_i8(); G[11, 3] = -127; e.upload_genotypes_i8(G)
         e.snp_stats(g.QcConfig(0.5, 0.0, 1.0))
         e.comm_init(world, rank, broadcast_unique_id(g.GpcaEngine, rank), a)
+        assert e.comm_count_ranks() == world      # libgpca's own RCCL communicator (beside torch's) reaches every rank
         try:
             e.rsvd(k, 10, 2, seed=seed)
             np.savez(os.path.join(out_dir, f"rank{rank}.npz"), status=0, ev=e.eigenvalues(), sc=e.scores(f64=True), ld=e.loadings())

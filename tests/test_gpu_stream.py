@@ -557,6 +557,7 @@ def _proc_worker(rank, world, port, M, N, k, seed, out_dir, poison_rank):
             G = e.download_genotypes_i8(); G[11, 3] = -127; e.upload_genotypes_i8(G)
         e.snp_stats(g.QcConfig(0.5, 0.0, 1.0))
         e.set_allreduce_hook(torch_allreduce_hook(), world, rank, a)
+        assert e.comm_count_ranks() == world          # a 1.0 per rank through the same transport as the sketch
         try:
             e.rsvd(k, 10, 2, seed=seed)
             np.savez(os.path.join(out_dir, f"rank{rank}.npz"), status=0, ev=e.eigenvalues(), sc=e.scores(f64=True), ld=e.loadings())
