@@ -122,12 +122,12 @@ def timed_run(eng, a, k, barrier, dist, torch):
     return dt, timings
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, planes=4):
     """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/*_pmc.json, produced by
     scripts/gpu_profile.sh: separate rocprofv3 --pmc runs).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     for gfx950 wide coalesced reads (calibrated on k_snp_stats: 2 x 5120.1 MB = the 10 240 MB it streams)."""
     import glob
-    key = {"gemm_GQ_2bit": "gpca::k_gq_2bit<4>", "gemm_GtT_2bit": "gpca::k_gtt_p<4>", "gemm_GQ_i8": "gpca::k_gq_d<1, 6>", "gemm_GtT_i8": "gpca::k_gtt_d<1>", "gemm_GQ_f32": "gpca::k_gq_f32<1, false>",
+    key = {"gemm_GQ_2bit": f"gpca::k_gq_2bit<{planes}>", "gemm_GtT_2bit": f"gpca::k_gtt_p<{planes}>", "gemm_GQ_i8": "gpca::k_gq_d<1, 6>", "gemm_GtT_i8": "gpca::k_gtt_d<1>", "gemm_GQ_f32": "gpca::k_gq_f32<1, false>",
            "gemm_GtT_f32": "gpca::k_gtt_f32<1, false>"}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not key or not files:
@@ -146,7 +146,12 @@ def pmc_traffic(kernel):
 DEFAULT_SHAPE = True   # set in main(): the committed PMC traffic figures belong to the default 1M x 10k workload only
 
 
-def roofline_of(timings, precision, steps, storage="int8"):
+# A register-resident v_mfma_i32_32x32x32_i8 loop on random bytes holds the chip at 1.70 GHz and delivers 3 400 TOP/s (profiles/r1_kbench_summary.md
+# section 8): what the matrix cores sustain under this operand mix, against the 5 000 TOP/s dense peak at the 2.4 GHz they do not hold.
+INT8_MFMA_SUSTAINED_TOPS = 3400.0
+
+
+def roofline_of(timings, precision, steps, storage="int8", planes=4):
     gq, gt = timings.get("gemm_GQ"), timings.get("gemm_GtT")
     dom_name, dom = max((("gemm_GQ", gq), ("gemm_GtT", gt)), key=lambda kv: kv[1]["total_ms"] if kv[1] else 0.0)
     avg_ms = dom["total_ms"] / dom["launches"]
@@ -156,16 +161,18 @@ def roofline_of(timings, precision, steps, storage="int8"):
               "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
               "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
               "all_kernels_ms_per_step": {n: t["total_ms"] / steps for n, t in timings.items()}}
-    traffic, src = pmc_traffic(common["kernel"]) if DEFAULT_SHAPE else (None, None)
+    traffic, src = pmc_traffic(common["kernel"], planes) if DEFAULT_SHAPE else (None, None)
     common["traffic_source"] = (f"profiles/{src}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch, separate rocprofv3 --pmc passes"
                                 if src else None)
     if precision == "i8" and storage == "2bit":
         # 0.25 B per genotype: the exact-integer kernels become matrix-core bound (4 digit planes x 32-cycle int8 MFMAs
         # per 1024 genotypes); peak = dense int8 MFMA rate, 2 x the ~2.5 PF bf16 peak (MI355X_MICROARCH.md)
-        ops = 2.0 * 32 * 4 * (dom["bytes"] / dom["launches"] * 4)          # executed int8 MACs x 2 per launch (4 planes, L = 32)
+        ops = 2.0 * 32 * planes * (dom["bytes"] / dom["launches"] * 4)     # executed int8 MACs x 2 per launch (`planes` digit planes, L = 32)
         tops = ops / (avg_ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": tops, "peak": 5000.0, "unit": "TOP/s (int8, executed digit-plane MFMAs)",
-                "frac": tops / 5000.0, "traffic": traffic, "hbm_GBs_algorithmic": gbs, "algorithmic_TFLOPs_equivalent": tflops, **common}
+                "frac": tops / 5000.0, "frac_of_sustained": tops / INT8_MFMA_SUSTAINED_TOPS, "sustained_peak": INT8_MFMA_SUSTAINED_TOPS,
+                "sustained_peak_source": "bare register-resident int8 MFMA loop on random bytes, 1.70 GHz under load (profiles/r1_kbench_summary.md section 8)",
+                "digit_planes": planes, "traffic": traffic, "hbm_GBs_algorithmic": gbs, "algorithmic_TFLOPs_equivalent": tflops, **common}
     if precision == "i8":   # exact-integer MFMA needs ~1/10 of the matrix-core time per byte: HBM-bound
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_TFLOPs_equivalent": tflops, **common}
@@ -366,7 +373,8 @@ def main():
     ap.add_argument("--storage", default="int8", choices=["int8", "2bit"],
                     help="HBM residency of the genotypes: int8 = 1 B/genotype (the BASELINE.json configs), 2bit = 0.25 B, decoded in the GEMM prologues")
     ap.add_argument("--digit-planes", type=int, default=0, choices=[0, 3, 4],
-                    help="exact path: 4 (default) signed base-128 digit planes, or 3 base-256 planes (24-bit; --storage 2bit only)")
+                    help="exact path: 4 signed base-128 digit planes or 3 base-256 planes (24-bit; --storage 2bit only); 0 = the library's choice "
+                         "(4 on int8 rows, 3 on 2-bit rows)")
     ap.add_argument("--precision", default="i8", choices=["f32", "i8"],
                     help="i8 = exact-integer GEMMs (default, fastest parity-green path); f32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--streamed", action="store_true",
@@ -427,14 +435,14 @@ def main():
     order = [a.precision] + ([] if (not extras or a.precision == "f32" or l > 32) else ["f32"])
     if a.precision == "i8" and a.storage == "int8" and extras:
         order.append("i8_2bit")
-        order.append("i8_2bit_3p")
+        order.append("i8_2bit_4p")
     th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
     t_stats = None
     head_rank_info = None
     for prec in order:
-        packed = prec in ("i8_2bit", "i8_2bit_3p")
+        packed = prec in ("i8_2bit", "i8_2bit_4p")
         store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == a.precision) or packed) else g._lib.STORE_INT8
-        planes = 3 if prec == "i8_2bit_3p" else (a.digit_planes if (prec == "i8" and store == g._lib.STORE_2BIT) else 0)
+        planes = 4 if prec == "i8_2bit_4p" else (a.digit_planes if (prec == "i8" and store == g._lib.STORE_2BIT) else 0)
         eng = g.GpcaEngine(device=local_rank, precision=PREC["i8" if packed else prec], storage=store, digit_planes=planes)
         engines[:] = [eng]
         eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
@@ -472,7 +480,7 @@ def main():
                        "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample,
                        "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}", "gemm_path": a.precision,
                        "residency": a.storage},
-            "roofline": roofline_of(timings, a.precision, a.steps, a.storage),
+            "roofline": roofline_of(timings, a.precision, a.steps, a.storage, planes=(a.digit_planes or 3) if a.storage == "2bit" else 4),
             "snp_stats_s": t_stats,
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
@@ -486,17 +494,19 @@ def main():
         if "i8_2bit" in results:
             dt3, tim3, ev3 = results["i8_2bit"]
             out["packed_2bit_residency"] = {
-                "note": "same job, same exact-integer arithmetic, genotypes resident as 2-bit dosage codes (0.25 B each, decoded in the GEMM prologue)",
+                "note": "same job, same exact-integer arithmetic, genotypes resident as 2-bit dosage codes (0.25 B each, decoded in the GEMM prologue); "
+                        "the library's default for 2-bit rows: three signed base-256 digit planes (24-bit fixed point per column, exact integer "
+                        "accumulation; max|dPC| <= 3e-7 against the f64 checker on every parity shape, profiles/r3_planes3_parity.json)",
                 "value": M_total * N / (dt3 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt3 / a.steps * 1e3,
-                "roofline": roofline_of(tim3, "i8", a.steps, "2bit"),
+                "roofline": roofline_of(tim3, "i8", a.steps, "2bit", planes=3),
                 "max_rel_d_eigenvalue_vs_default_path": float(np.max(np.abs(ev3 - ev) / ev))}
-        if "i8_2bit_3p" in results:
-            dt4, tim4, ev4 = results["i8_2bit_3p"]
-            out["packed_2bit_three_planes"] = {
-                "note": "2-bit residency with gpca_config.digit_planes = 3: three signed base-256 digit planes (24-bit fixed point per column, "
-                        "exact integer accumulation) instead of four base-128 planes -- a quarter less matrix-core work",
+        if "i8_2bit_4p" in results:
+            dt4, tim4, ev4 = results["i8_2bit_4p"]
+            out["packed_2bit_four_planes"] = {
+                "note": "2-bit residency with gpca_config.digit_planes = 4: four signed base-128 digit planes (28-bit fixed point per column), "
+                        "bit-compatible with int8 residency",
                 "value": M_total * N / (dt4 / a.steps), "unit": "SNPs*samples/s", "ms_per_step": dt4 / a.steps * 1e3,
-                "all_kernels_ms_per_step": {n: t["total_ms"] / a.steps for n, t in tim4.items()},
+                "roofline": roofline_of(tim4, "i8", a.steps, "2bit", planes=4),
                 "max_rel_d_eigenvalue_vs_default_path": float(np.max(np.abs(ev4 - ev) / ev))}
         if a.streamed_extra and a.precision == "i8":
             # (not in the default run: its panel launches use the same kernels as the headline and would blur the per-kernel

@@ -205,6 +205,10 @@ __device__ __forceinline__ void gqn_load(GqnG<NSU>& b, const int8_t* __restrict_
     for (int j = 0; j < 4 * NSU; ++j) b.g[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, vo, 32u * j, 2);   // nt: streamed once per pass
     b.r = rv[unit * 32 + c]; b.b = bv[unit * 32 + c];
 }
+// (On gfx9 stores count in vmcnt like loads.  With the epilogue's 16 dword stores per unit between a unit's loads and the wait for
+//  them, six units in flight overran the 6-bit counter and the effective prefetch depth fell to under three units: 85 us per launch
+//  at 1 066 557 x 64.  The unit's 32 x 32 tile of T is therefore turned through a wave-private 4 KiB of LDS and leaves as four
+//  16-byte stores per lane -- 5 stores + 6 loads per unit, PF = 5 units stay inside the counter.)
 template <int NSU, int PF>
 __global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, int64_t ldg, int64_t units,
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
@@ -219,6 +223,8 @@ __global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, i
     const float sj = sv[c];
     const double qs = qscale[c];
     float amax = 0.f;
+    __shared__ __attribute__((aligned(16))) float tile_all[4][32 * 32];
+    float* tile = tile_all[wv];
     if (u0 < u1) {
         i32x4 q[4 * NSU][kDigits];
         {
@@ -252,16 +258,23 @@ __global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, i
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the unit
-                        const int64_t row = unit * 32 + rin;
                         const float ri = __shfl(rrow, rin), bi = __shfl(brow, rin);
                         const float gq = (float)(combine_digits(acc, e) * qs);
                         const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
                         ct = __fmaf_rn(bi, tv, ct);
                         const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
                         amax = fmaxf(amax, fabsf(ov));
-                        Tout[row * ldt + c] = ov;
+                        tile[rin * 32 + c] = ov;
                     }
                     GPCA_STORE_CUNIT(unit)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (one wave's LDS operations execute in order: no barrier)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = (lane >> 3) + 8 * i;
+                        const float4 v = *reinterpret_cast<const float4*>(tile + rr * 32 + 4 * (lane & 7));
+                        *reinterpret_cast<float4*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)) = v;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the tile is free again before the next unit writes it)
                 }
             }
         }
@@ -275,7 +288,7 @@ int launch_gq_n(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
                 int scale_out, int64_t ldt) {
     if (N < 1 || N > 256 || ldg < 256 || plan.units < 1) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
-    if (N <= 128) hipLaunchKernelGGL((k_gq_n<1, 6>), grid, blk, 0, st, G, ldg, plan.units, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
+    if (N <= 128) hipLaunchKernelGGL((k_gq_n<1, 5>), grid, blk, 0, st, G, ldg, plan.units, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
     else hipLaunchKernelGGL((k_gq_n<2, 4>), grid, blk, 0, st, G, ldg, plan.units, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
     return 0;
 }

@@ -70,11 +70,13 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
         if (dp != 0 && dp != 3 && dp != 4) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes must be 0, 3 or 4"); }
         if (dp == 3 && !(h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT)) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes = 3 is implemented for GPCA_PREC_I8_EXACT with GPCA_STORE_2BIT"); }
         h->nd = dp == 3 ? 3 : 4;
-        // digit_planes = 0 leaves the choice to the library: four planes, or what GPCA_PACKED_PLANES says for the packed kernels (the
-        // switch the whole parity suite is run under to compare the two)
+        // digit_planes = 0 leaves the choice to the library: four planes on int8 rows (HBM-bound: the planes cost nothing there), THREE
+        // on 2-bit rows, whose kernels are matrix-core bound (a quarter less work).  Round 3 ran the whole parity suite and
+        // scripts/planes3_parity.py under both settings: three planes sit within 3e-7 (max|dPC|) / 5e-8 (eigenvalues) of the f64
+        // checker on every shape -- closer than the f32-MFMA path (7e-7 / 2e-7).  GPCA_PACKED_PLANES=4 restores four.
         if (dp == 0 && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT) {
             const char* e = getenv("GPCA_PACKED_PLANES");
-            if (e && atoi(e) == 3) h->nd = 3;
+            h->nd = (e && atoi(e) == 4) ? 4 : 3;
         }
     }
     // diagnostic switches, read once per handle (defaults are the tuned values; DESIGN.md "Diagnostic switches")

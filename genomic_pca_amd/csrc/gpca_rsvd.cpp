@@ -141,6 +141,8 @@ static inline Gtt8Plan k2_plan(const gpca_handle* h, int64_t rows_pad) {
                             gtt8_plan(rows_pad, h->ldg, h->gtt_waves_target);
 }
 
+static inline GqPlan k1_plan(const gpca_handle* h, int64_t rows_pad) { return gq_plan(rows_pad, h->gq_waves_target); }
+
 // K2 of one 32-column half over one panel: Ypart = (digit planes of T')^T G, exact integers
 static int k2_panel(gpca_handle* h, const PanelView& pv, const int8_t* Td_half, const Gtt8Plan& plan) {
     const int8_t* Td = Td_half + (size_t)(pv.row0 >> 5) * kPlaneBytesPerBlock;
@@ -227,7 +229,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
             const double by = packed ? elems / 4 : elems;
             ScopedTimer sweep(h, "gemm_GQ", 2.0 * elems * h->l, by * halves, nullptr, streamed);
             CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
-                const GqPlan plan = streamed ? gq_plan(pv.rows_pad, h->gq_waves_target) : h->gqplan;
+                const GqPlan plan = streamed ? k1_plan(h, pv.rows_pad) : h->gqplan;
                 for (int hf = 0; hf < halves; ++hf) {
                     const int8_t* Qd = h->dQd + hf * qhalf;
                     const double* qsc = h->d_qscale + 32 * hf;
@@ -298,7 +300,7 @@ static int stage_power_fused(gpca_handle* h) {
         const double by = packed ? elems / 4 : elems;
         ScopedTimer sweep(h, "gemm_fused", 4.0 * elems * h->l, by * halves);
         CHK(for_each_panel(h, [&](const PanelView& pv) -> int {
-            const GqPlan plan1 = gq_plan(pv.rows_pad, h->gq_waves_target);
+            const GqPlan plan1 = k1_plan(h, pv.rows_pad);
             const Gtt8Plan plan2 = k2_plan(h, pv.rows_pad);
             const float* rr = h->d_r + pv.row0; const float* bb = h->d_b + pv.row0;
             for (int hf = 0; hf < halves; ++hf) {
@@ -385,7 +387,7 @@ static int ensure_workspace(gpca_handle* h) {
     // streamed mode: the GEMM grids are sized per panel (all panels but the last have panel_rows rows)
     const int64_t gemm_rows = h->sm.on ? h->sm.panel_rows : h->Mpad;
     h->plan = gtt_plan(h->Mpad, Npad, L, h->gtt_waves_target);
-    h->gqplan = gq_plan(gemm_rows, h->gq_waves_target);
+    h->gqplan = k1_plan(h, gemm_rows);
     CHK(ensure(h, h->dQ, h->cap_Q, (size_t)Npad * L));
     CHK(ensure(h, h->dT, h->cap_T, (size_t)h->Mpad * L));
     if (h->precision == GPCA_PREC_F32_MFMA) CHK(ensure(h, h->dTb, h->cap_Tb, (size_t)h->Mpad * L));

@@ -10,7 +10,7 @@ python - <<PY
 import json
 d=json.loads(open('gpurun_out/bench_$tag.json').read().strip().splitlines()[-1])
 print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['all_kernels_ms_per_step'])
-for k in ('f32_mfma_path','packed_2bit_residency','packed_2bit_three_planes'):
+for k in ('f32_mfma_path','packed_2bit_residency','packed_2bit_four_planes'):
     print(k, d[k]['ms_per_step'])
 PY
 timeout -k 10 400 python bench.py --streamed --snps 6250000 --samples 500000 -k 40 --storage 2bit --steps 1 --warmup 0 > gpurun_out/stream_c5_2bit_$tag.json 2> gpurun_out/stream_c5_2bit_$tag.err || tail -5 gpurun_out/stream_c5_2bit_$tag.err

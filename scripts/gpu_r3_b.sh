@@ -11,7 +11,7 @@ python - <<PY
 import json
 d = json.load(open("gpurun_out/bench_$tag.json"))
 print("ms_per_step", d["ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["all_kernels_ms_per_step"])
-for k in ("f32_mfma_path", "packed_2bit_residency", "packed_2bit_three_planes"):
+for k in ("f32_mfma_path", "packed_2bit_residency", "packed_2bit_four_planes"):
     if k in d: print(k, d[k]["ms_per_step"])
 PY
 timeout -k 10 300 python scripts/bench_config3.py > gpurun_out/config3_$tag.json 2> gpurun_out/config3_$tag.err; tail -3 gpurun_out/config3_$tag.err; cat gpurun_out/config3_$tag.json

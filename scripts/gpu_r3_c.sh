@@ -12,7 +12,7 @@ for k,v in d.items():
     if isinstance(v,dict): print(k, 'rsvd_ms', round(v['rsvd_ms'],3), v['gemm_launch_us'], v['stages_us_per_call'])"
 timeout -k 10 300 python bench.py --no-extras --no-cpu-baseline > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err || tail -5 gpurun_out/bench_$tag.err
 python -c "
-import json; d=json.load(open('gpurun_out/bench_$tag.json')); print('ms_per_step', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'], [d[k]['ms_per_step'] for k in ('f32_mfma_path','packed_2bit_residency','packed_2bit_three_planes')])"
+import json; d=json.load(open('gpurun_out/bench_$tag.json')); print('ms_per_step', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'], [d[k]['ms_per_step'] for k in ('f32_mfma_path','packed_2bit_residency','packed_2bit_four_planes')])"
 timeout -k 10 300 python scripts/planes3_parity.py > gpurun_out/planes3_$tag.json 2> gpurun_out/planes3_$tag.err; tail -3 gpurun_out/planes3_$tag.err
 python -c "
 import json; d=json.load(open('gpurun_out/planes3_$tag.json'))

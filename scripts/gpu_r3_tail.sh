@@ -11,7 +11,7 @@ python - <<PY
 import json
 d = json.load(open("gpurun_out/bench_$tag.json"))
 print("ms_per_step", d["ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["all_kernels_ms_per_step"])
-for k in ("f32_mfma_path", "packed_2bit_residency", "packed_2bit_three_planes"):
+for k in ("f32_mfma_path", "packed_2bit_residency", "packed_2bit_four_planes"):
     if k in d: print(k, d[k]["ms_per_step"])
 print(d.get("parity"))
 PY

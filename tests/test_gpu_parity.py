@@ -532,13 +532,13 @@ def test_full_size_properties(gpca, oracle, prec, store):
     bench.py (k_gq_d / k_gtt_d, LDS-DMA), ("i8", "2bit") the packed kernels (k_gq_2bit / k_gtt_p), ("f32", "int8") the
     f32 matrix-core kernels.  The oracle cannot run at this size, so: spot rows against the oracle, orthogonality,
     centring, idempotence, PCA::transform consistency (_full_size_case), and agreement of the structured PCs between the paths:
-    every path against the headline path -- 1e-8 for the exact-integer pair (the same integers up to the T' quantisation grid),
+    every path against the headline path -- 1e-6 for the exact-integer pair (the same integers; 24-bit against 28-bit digit planes),
     1e-5 for the f32 paths -- and f32 on 2-bit rows == f32 on int8 rows bit for bit.  The headline result is computed on demand
     (and cached), so no comparison depends on the order the parameters run in."""
     ev, sc2, ld2 = _full_size_case(gpca, oracle, prec, store)
     ev0, sc0, ld0 = _full_size_case(gpca, oracle, "i8", "int8")
     if (prec, store) != ("i8", "int8"):
-        tol = 1e-8 if prec == "i8" else 1e-5
+        tol = 1e-6 if prec == "i8" else 1e-5      # (i8 on 2-bit rows: three digit planes by default, a 24-bit fixed point per column)
         assert np.max(np.abs(ev[:2] - ev0[:2]) / ev0[:2]) < tol
         assert oracle.max_abs_dpc(sc2, sc0) < tol and oracle.max_abs_dpc(ld2, ld0) < 10 * tol
     if (prec, store) == ("f32", "2bit"):      # same f32 FMA chains on the decoded codes: the same bits
@@ -579,8 +579,9 @@ def test_c4_per_gpu_shard_i8_and_2bit(gpca, oracle, M, N):
             tr = e.transform()
             assert oracle.max_abs_dpc(tr[:, :2], sc[:, :2]) < 1e-4
             res[store] = (ev, sc, ld)
-    assert np.max(np.abs(res["int8"][0] - res["2bit"][0]) / res["int8"][0]) < 1e-8
-    assert oracle.max_abs_dpc(res["int8"][1][:, :2], res["2bit"][1][:, :2]) < 1e-8
+    # (2-bit rows run three digit planes by default: a 24-bit fixed point per column against the 28 bits of the int8-resident run)
+    assert np.max(np.abs(res["int8"][0][:2] - res["2bit"][0][:2]) / res["int8"][0][:2]) < 1e-6
+    assert oracle.max_abs_dpc(res["int8"][1][:, :2], res["2bit"][1][:, :2]) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------------
@@ -744,15 +745,20 @@ def test_rsvd_parity_2bit(gpca, oracle, engine_2bit, M, N, P, k):
 
 
 def test_2bit_equals_int8_residency(gpca, oracle, engine_i8, engine_2bit):
-    """Same exact-integer arithmetic on the same codes: the packed path reproduces the int8-resident path."""
+    """Same exact-integer arithmetic on the same codes: with the same four digit planes the packed path reproduces the int8-resident
+    path (1e-8: only the quantisation grid of T' per launch differs); the packed default (three planes) sits within 1e-6."""
+    from genomic_pca_amd import _lib
     M, N = 6000, 900
     G = oracle.synth_genotypes(M, N, 5, gpca.synth_thresholds(M, 8, seed=5, fst=0.3))
     res = []
-    for e in (engine_i8, engine_2bit):
-        e.upload_genotypes_i8(G); e.snp_stats(); e.rsvd(6, 10, 2, seed=3)
-        res.append((e.eigenvalues(), e.scores(f64=True)))
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT, digit_planes=4) as engine_2bit_4p:
+        for e in (engine_i8, engine_2bit_4p, engine_2bit):
+            e.upload_genotypes_i8(G); e.snp_stats(); e.rsvd(6, 10, 2, seed=3)
+            res.append((e.eigenvalues(), e.scores(f64=True)))
     assert np.max(np.abs(res[0][0] - res[1][0]) / res[0][0]) < 1e-8
     assert oracle.max_abs_dpc(res[0][1], res[1][1]) < 1e-8
+    assert np.max(np.abs(res[0][0] - res[2][0]) / res[0][0]) < 1e-6
+    assert oracle.max_abs_dpc(res[0][1], res[2][1]) < 1e-6
 
 
 @pytest.mark.parametrize("M,N,P,k", [(4096, 512, 12, 8), (20000, 1000, 16, 10), (3000, 1500, 10, 6), (999, 257, 8, 4), (130, 70, 4, 3), (6000, 700, 48, 40)])
@@ -977,7 +983,8 @@ def test_rsvd_i8_sketch_width_and_iteration_edges(gpca, oracle, store, k, oversa
 def test_rsvd_parity_2bit_three_planes(gpca, oracle, M, N, P, k):
     from genomic_pca_amd import _lib
     with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT, digit_planes=3) as e3, \
-         gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT) as e4:
+         gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT, digit_planes=4) as e4, \
+         gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT) as e0:
         G, r, b, R = _rsvd_case(gpca, oracle, e3, M, N, P, k, seed=1, fst=0.2)
         assert np.max(np.abs(e3.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
         assert oracle.max_abs_dpc(e3.scores(f64=True), R["scores"]) < TOL_PC
@@ -986,6 +993,9 @@ def test_rsvd_parity_2bit_three_planes(gpca, oracle, M, N, P, k):
         e4.upload_genotypes_i8(G); e4.snp_stats(gpca.QcConfig.none()); e4.rsvd(k, 10, 2, seed=1)
         assert oracle.max_abs_dpc(e3.scores(f64=True), e4.scores(f64=True)) < 2e-6
         assert oracle.max_abs_dpc(e3.transform(), e4.transform()) < 2e-6
+        # digit_planes = 0 (the library's choice) on 2-bit rows IS three planes: the same bits
+        e0.upload_genotypes_i8(G); e0.snp_stats(gpca.QcConfig.none()); e0.rsvd(k, 10, 2, seed=1)
+        assert np.array_equal(e0.eigenvalues(), e3.eigenvalues()) and np.array_equal(e0.scores(f64=True), e3.scores(f64=True))
 
 
 def test_three_planes_need_packed_exact_path(gpca):

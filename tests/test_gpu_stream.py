@@ -298,7 +298,7 @@ def test_streamed_fused_power_iteration(gpca, oracle, store, planes, k):
     for key in ("mu", "sigma", "keep", "counts", "reason"):
         assert np.array_equal(res[key], stm[key])
     _same(stm, again)                                        # deterministic: fixed panel order, no atomics
-    tol = 2e-6 if planes == 3 else 2e-8                      # (three base-256 planes: a 24-bit grid)
+    tol = 2e-6 if (planes == 3 or (planes == 0 and store == "2bit")) else 2e-8   # (three base-256 planes, the default on 2-bit rows: a 24-bit grid)
     kk = min(k, 20)
     assert np.max(np.abs(stm["ev"] - res["ev"]) / res["ev"]) < tol
     assert oracle.max_abs_dpc(stm["sc"][:, :kk], res["sc"][:, :kk]) < 10 * tol
@@ -715,8 +715,8 @@ def test_config5_sample_count_k40(gpca, oracle):
                 a_i = (g_row - float(st["mu"][i])) / float(st["sigma"][i])
                 assert np.max(np.abs(a_i @ V / sv[:2] - ld[i, :2].astype(np.float64))) < 1e-5
             out[store] = (ev, sc, ld)
-    assert np.max(np.abs(out["int8"][0] - out["2bit"][0]) / out["int8"][0]) < 1e-8
-    assert oracle.max_abs_dpc(out["int8"][1][:, :2], out["2bit"][1][:, :2]) < 1e-8
+    assert np.max(np.abs(out["int8"][0][:2] - out["2bit"][0][:2]) / out["int8"][0][:2]) < 1e-6    # (2-bit rows: three digit planes by default)
+    assert oracle.max_abs_dpc(out["int8"][1][:, :2], out["2bit"][1][:, :2]) < 1e-6
     with gpca.GpcaEngine(**_modes("2bit")) as e:
         e.stream_open(gpca.PanelSource.synth(th, seed), M, N, panel_rows=4096, ring_slots=2, fused=False)
         e.snp_stats(); e.rsvd(k, 10, 2, seed=seed)
