@@ -250,6 +250,37 @@ def extra_resident_line(g, a, name, M, N, k, precision, storage, steps, warmup, 
         eng.close()
 
 
+def extra_config2_line(g, a, device):
+    """BASELINE.json configs[2] at its own size: data/chr22_subset50.bed is 1 066 557 SNPs x 64 samples.  /root/reference does not exist
+    on the GPU box, so the committed 120 000-SNP slice of that file (tests/golden/chr22_subset50_120k.npz: .bed bytes, data only) is
+    tiled to the full row count; --eigensnp defaults (QC 0.98 / 0.01 / 1e-6, k = 20 here, l = 30, q = 2), int8 rows, the narrow kernels."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "chr22_subset50_120k.npz"))
+    rows, n = z["bed_rows"], int(z["n_samples"])
+    M = 1_066_557
+    bed = np.tile(rows, (M // rows.shape[0] + 1, 1))[:M]
+    with g.GpcaEngine(device=device, precision=g._lib.PREC_I8_EXACT, storage=g._lib.STORE_INT8) as e:
+        t0 = time.perf_counter(); e.upload_bed2bit(bed, n); t_up = time.perf_counter() - t0
+        t0 = time.perf_counter(); e.snp_stats(g.QcConfig(), fetch=False); t_qc = time.perf_counter() - t0
+        e.rsvd(20, 10, 2, seed=2025)
+        e.enable_timings(True); e.reset_timings(); e.synchronize()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e.rsvd(20, 10, 2, seed=2025)
+        e.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        tim = e.timings()
+        n_pca = e.num_pca_snps()
+        return {"workload": f"chr22_subset50-shaped: {M} SNPs x {n} samples (.bed rows of the committed slice of the reference's own file, tiled), "
+                            f"QC defaults -> {n_pca} PCA SNPs, k = 20, l = 30, q = 2, int8 rows",
+                "snps": M, "samples": n, "pca_snps": n_pca, "steps": reps, "ms_per_step": dt * 1e3, "value": M * n / dt, "unit": "SNPs*samples/s",
+                "upload_s": t_up, "snp_stats_s": t_qc,
+                "gemm_launch_us": {k_: v_["total_ms"] / v_["launches"] * 1e3 for k_, v_ in tim.items() if k_.startswith("gemm")},
+                "gemm_ms_per_step": sum(v_["total_ms"] for k_, v_ in tim.items() if k_.startswith("gemm")) / reps,
+                "hbm_GBs_algorithmic_per_gemm_launch": {k_: M * n / (v_["total_ms"] / v_["launches"] * 1e-3) / 1e9 for k_, v_ in tim.items() if k_.startswith("gemm")},
+                "top_eigenvalues": [float(x) for x in e.eigenvalues()[:3]]}
+
+
 def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn=None, steps=None, warmup=None, cache_gb=0.0):
     """One out-of-core job: stats sweep + `steps` timed gpca_rsvd calls over panels that are regenerated on every sweep."""
     steps = a.steps if steps is None else steps
@@ -368,7 +399,7 @@ def main():
     ap.add_argument("--no-second-path", action="store_true", help="skip the extra f32-MFMA measurement")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra BASELINE.json workloads of the default one-GPU run (configs[3]'s per-GPU shard 1.25M x 100k int8 and "
-                         "north_star's literal 10M x 100k MFMA-fp32 job on 2-bit rows): use it under rocprofv3, whose per-kernel averages "
+                         "north_star's literal 10M x 100k MFMA-fp32 job on 2-bit rows, configs[4]'s per-GPU shard streamed out of core): use it under rocprofv3, whose per-kernel averages "
                          "would otherwise mix three shapes")
     ap.add_argument("--storage", default="int8", choices=["int8", "2bit"],
                     help="HBM residency of the genotypes: int8 = 1 B/genotype (the BASELINE.json configs), 2bit = 0.25 B, decoded in the GEMM prologues")
@@ -526,6 +557,22 @@ def main():
             out["north_star_literal"] = extra_resident_line(
                 g, a, "north_star's literal target: 10M SNPs x 100k samples, k = 20, MFMA-fp32 GEMMs on ONE MI355X (2-bit resident rows, 250 GB)",
                 10_000_000, 100_000, k, "f32", "2bit", steps=2, warmup=1, device=local_rank)
+            out["config2_chr22_shape"] = extra_config2_line(g, a, local_rank)
+            # configs[4]'s per-GPU shard, out of core: 6.25M SNPs x 500k samples, k = 40, 2-bit panels from the device generator through
+            # the ring, the leading panels kept in spare HBM (one call: the first pass's workspace allocation is noise next to ~7 s)
+            a5 = argparse.Namespace(**vars(a)); a5.panel_rows = 0; a5.ring = 3; a5.unfused = False; a5.digit_planes = 0
+            M5, N5, k5 = 6_250_000, 500_000, 40
+            dt5, tim5, ev5, t_stats5 = streamed_run(g, a5, M5, N5, k5, "2bit", local_rank, 0, None, None, steps=1, warmup=0, cache_gb=-1.0)
+            n_cached5 = tim5.pop("_panels_cached")
+            out["config5_per_gpu_shard_streamed"] = {
+                "workload": "BASELINE.json configs[4] per-GPU shard, out of core: 6.25M SNPs x 500k samples (781 GB of 2-bit codes per pass, never "
+                            "resident), k = 40, l = 50, panels of 131 072 rows from the device generator (GPCA_PANEL_SYNTH16) through a ring of 3",
+                "snps": M5, "samples": N5, "k": k5, "steps": 1, "warmup": 0, "ms_per_step": dt5 * 1e3, "value": M5 * N5 / dt5,
+                "unit": "SNPs*samples/s", "snp_stats_s": t_stats5, "panels_cached_in_hbm": n_cached5,
+                "streaming": streamed_summary(tim5, 1, M5, N5, k5 + a.oversample, "2bit"),
+                "top_eigenvalues": [float(x) for x in ev5[:3]],
+                "properties": {"eigenvalues_descending": bool(np.all(np.diff(ev5) <= 0)), "structured_eigenvalues_found": int(np.sum(ev5 > 20 * ev5[-1])),
+                               "structured_eigenvalues_expected": 2}}
         # bench lines of the other BASELINE.json configs, measured with this build by the scripts named in DESIGN.md (too large or too
         # long for the default run; each file holds one line in this same format)
         out["see_also"] = {k_: v_ for k_, v_ in {

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&qs, 32 * 8)); CK(hipMemset(qs, 0, 32 * 8));
     CK(hipMalloc(&r, M * 4)); CK(hipMalloc(&b, M * 4)); CK(hipMalloc(&s, 32 * 4)); CK(hipMalloc(&T, M * 32 * 4));
     CK(hipMemset(r, 0, M * 4)); CK(hipMemset(b, 0, M * 4)); CK(hipMemset(s, 0, 32 * 4));
-    CK(hipMalloc(&cp, waves * 32 * 4)); CK(hipMalloc(&ap, waves * 32 * 8));
+    CK(hipMalloc(&cp, (M / 32) * 32 * 4));   /* one c partial per 32-row unit (not per wave: the kernels write cunit[unit][32]) */ CK(hipMalloc(&ap, waves * 32 * 8));
     gpca::GqPlan plan{M / 32, waves};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 2; ++it) gpca::launch_gq_2bit(0, G2, ld2, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1);
