@@ -83,6 +83,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     h->gq_waves_target = std::max(4, env_int("GPCA_GQ_WAVES", h->gq_waves_target));
     h->gtt_waves_target = std::max(4, env_int("GPCA_GTT_WAVES", h->gtt_waves_target));
     h->lds_planes = env_int("GPCA_LDS_PLANES", h->lds_planes);
+    h->compact_ok = env_int("GPCA_COMPACT", h->compact_ok);
     h->narrow_ok = env_int("GPCA_NARROW", h->narrow_ok);
     h->gq_dma = env_int("GPCA_GQ_DMA", h->gq_dma);
     h->spin_sync = env_int("GPCA_SPIN_SYNC", h->spin_sync);
@@ -115,18 +116,28 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     return GPCA_OK;
 }
 
+void drop_child(gpca_handle* h) {
+    h->child_valid = false; h->rsvd_on_child = false;
+    if (!h->child) return;
+    gpca_handle* c = h->child;
+    h->child = nullptr;
+    c->d_row_ids = nullptr;
+    (void)gpca_destroy(c);
+}
+
 extern "C" int gpca_destroy(gpca_handle* h) {
     if (!h) return GPCA_OK;
     { LOCK(h);
       (void)hipSetDevice(h->device);
       (void)hipStreamSynchronize(h->st);
+      drop_child(h);
       stream_close(h);
       for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
       for (auto e : h->ev_pool) (void)hipEventDestroy(e);
       if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
       free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
       dfree(h->d_blk_rows); dfree(h->d_blk_cols); dfree(h->d_blk_out); dfree(h->d_blk_err); dfree(h->d_status); if (h->h_status) { (void)hipHostFree(h->h_status); h->h_status = nullptr; }
-      (void)hipStreamDestroy(h->st);
+      if (!h->is_child) (void)hipStreamDestroy(h->st);      // (a compact child runs on its parent's stream)
     }
     delete h;
     return GPCA_OK;
@@ -197,7 +208,7 @@ extern "C" int gpca_snp_stats(gpca_handle* h, const gpca_qc_config* qc, float* m
     if (h->sm.on && h->sm.fl.d_flags) CHK(finish_pack_flags(h, h->sm.fl.d_flags, h->sm.st_fill));   // int8 panels packed on the way in
     h->flags |= h->pack_flags;   // 2-bit mode: values outside {0,1,2,-127} were seen (and stored as missing) at upload
     CHK(refresh_pca_rows(h));
-    h->have_stats = true; h->have_rsvd = false; h->rmax_valid = false;
+    h->have_stats = true; h->have_rsvd = false; h->rmax_valid = false; drop_child(h);
     if (mu) HIPCHK(hipMemcpy(mu, h->d_mu, (size_t)h->M * 4, hipMemcpyDeviceToHost));
     if (sigma) HIPCHK(hipMemcpy(sigma, h->d_sigma, (size_t)h->M * 4, hipMemcpyDeviceToHost));
     if (keep) HIPCHK(hipMemcpy(keep, h->d_keep, (size_t)h->M, hipMemcpyDeviceToHost));
@@ -250,7 +261,7 @@ extern "C" int gpca_set_standardization(gpca_handle* h, const float* mu, const f
         if ((int64_t)c[0] != h->N) h->flags |= 1u;
         if ((uint64_t)c[1] + c[2] + c[3] != c[0]) h->flags |= 2u;
     }
-    h->have_rsvd = false; h->rmax_valid = false;
+    h->have_rsvd = false; h->rmax_valid = false; drop_child(h);
     return GPCA_OK;
 }
 
@@ -452,7 +463,13 @@ extern "C" int gpca_comm_count_ranks(gpca_handle* h, int32_t* ranks) {
 }
 
 // ---- d: timings ------------------------------------------------------------------------------------------------
-extern "C" int gpca_enable_timings(gpca_handle* h, int32_t on) { if (!h) return GPCA_ERR_BAD_ARG; LOCK(h); h->timing_on = on != 0; return GPCA_OK; }
+extern "C" int gpca_enable_timings(gpca_handle* h, int32_t on) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    h->timing_on = on != 0;
+    if (h->child) h->child->timing_on = h->timing_on;
+    return GPCA_OK;
+}
 extern "C" int gpca_reset_timings(gpca_handle* h) {
     if (!h) return GPCA_ERR_BAD_ARG;
     LOCK(h);
@@ -460,6 +477,7 @@ extern "C" int gpca_reset_timings(gpca_handle* h) {
     HIPCHK(hipStreamSynchronize(h->st));
     for (auto& r : h->recs) { h->ev_pool.push_back(r.a); h->ev_pool.push_back(r.b); }
     h->recs.clear(); h->agg.clear();
+    if (h->child) CHK(gpca_reset_timings(h->child));
     return GPCA_OK;
 }
 extern "C" int gpca_get_timings(gpca_handle* h, gpca_kernel_timing* out, int32_t cap, int32_t* n) {
@@ -468,7 +486,17 @@ extern "C" int gpca_get_timings(gpca_handle* h, gpca_kernel_timing* out, int32_t
     if (h->sm.st_fill) HIPCHK(hipStreamSynchronize(h->sm.st_fill));
     HIPCHK(hipStreamSynchronize(h->st));
     fold_timings(h);
-    *n = (int32_t)h->agg.size();
-    if (out) for (int32_t i = 0; i < *n && i < cap; ++i) out[i] = h->agg[(size_t)i];
+    std::vector<gpca_kernel_timing> all = h->agg;
+    if (h->child) {      // the passes that ran on the compact child count as this handle's
+        fold_timings(h->child);
+        for (const gpca_kernel_timing& t : h->child->agg) {
+            size_t i = 0;
+            for (; i < all.size(); ++i) if (strcmp(all[i].name, t.name) == 0) break;
+            if (i == all.size()) all.push_back(t);
+            else { all[i].launches += t.launches; all[i].total_ms += t.total_ms; all[i].flops += t.flops; all[i].bytes += t.bytes; }
+        }
+    }
+    *n = (int32_t)all.size();
+    if (out) for (int32_t i = 0; i < *n && i < cap; ++i) out[i] = all[(size_t)i];
     return GPCA_OK;
 }

@@ -193,6 +193,16 @@ struct gpca_handle {
     int narrow_ok = 1;    // matrices of at most 256 samples (int8 rows) run the narrow K1 / K2 (GPCA_NARROW=0: the wide kernels on padded rows)
     int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
 
+    // Compact child: when QC dropped most SNP rows (the reference's solver only ever sees the PCA SNPs, prepare.rs:1465-1469), the kept
+    // rows are gathered into a matrix of their own and gpca_rsvd / gpca_transform / the getters run on it: every pass, the sketch and
+    // the quantisations then cost n_pca rows instead of M (configs[2]: 203 512 of 1 066 557).  The child shares the parent's stream,
+    // draws Omega by the ORIGINAL row index of its rows (row_ids), and is rebuilt whenever the parent's rows or keep mask change.
+    gpca_handle* child = nullptr;
+    bool child_valid = false, rsvd_on_child = false;
+    bool is_child = false;           // (a child never compacts again and does not own its stream)
+    const int64_t* d_row_ids = nullptr;   // child: original row of every row (the parent's d_pca_rows; not owned)
+    int compact_ok = 1;              // GPCA_COMPACT=0: never compact
+
     // comm
     int world = 1, rank = 0;
     int64_t snp_offset = 0;
@@ -280,6 +290,7 @@ void filler_cancel(Filler& f);                              // drop what was pos
 int allreduce_f64(gpca_handle* h, double* dbuf, int64_t count);   // in-place sum across the ranks that share the sharded matrix
 hipError_t stream_wait(gpca_handle* h);
 int agree_status(gpca_handle* h, int local_rc, const char* where);
+void drop_child(gpca_handle* h);    // the compact child is stale (rows, statistics or keep mask changed) or the handle goes away
 
 // fn(view) once for the resident matrix, or once per panel (generated / copied ahead on the fill stream)
 template <class F>

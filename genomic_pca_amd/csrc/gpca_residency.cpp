@@ -138,6 +138,7 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     if (M <= 0 || N <= 0) return fail(h, GPCA_ERR_BAD_ARG, "genotype matrix must have M > 0 SNPs and N > 0 samples");
     HIPCHK(hipSetDevice(h->device));
     stream_close(h);
+    drop_child(h);
     free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
     h->M = M; h->N = N; h->Mpad = round_up(M, kGQRowsPerWave); h->pack_flags = 0;
     h->cap_rows_pad = resident ? h->Mpad : 0;
@@ -338,6 +339,7 @@ static int host_rows_to_device(gpca_handle* h, Filler& f, const void* src, int64
 int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst, hipStream_t st) {
     const bool packed = h->storage == GPCA_STORE_2BIT;
     const gpca_panel_source& s = f.src;
+    f.fills++;
     switch (s.kind) {
         case GPCA_PANEL_SYNTH:
             if (packed) {
@@ -352,7 +354,6 @@ int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst
             return GPCA_OK;
         case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED: case GPCA_PANEL_MAPPED_I8: case GPCA_PANEL_MAPPED_BED: {
             if (rows > f.chunk_rows) return fail(h, GPCA_ERR_BAD_ARG, "panel source: more rows asked than the staging holds");
-            f.fills++;
             if (f.registered)      // zero staging: straight out of the caller's page-locked mapping
                 return host_rows_to_device(h, f, f.map_base + (size_t)row0 * (size_t)f.map_ld, f.map_ld, rows, dst, st);
             size_t b;
@@ -581,6 +582,7 @@ extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, 
         HIPCHK(hipStreamSynchronize(dst->st));
         dst->M = rows; dst->Mpad = new_pad;
         dst->have_stats = false; dst->have_rsvd = false; dst->n_pca = 0; dst->pca_rows.clear(); dst->flags = 0; dst->apart_valid = false; dst->rmax_valid = false;
+        drop_child(dst);
         free_eigensnp(dst);
         if (dst->d_r && dst->cap_stats_pad < new_pad) free_stats(dst);      // (allocated for a smaller block: the next stats pass re-makes them)
         if (dst->d_r) {

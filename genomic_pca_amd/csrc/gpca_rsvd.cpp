@@ -454,9 +454,82 @@ static int rsvd_preflight(gpca_handle* h, int32_t k, int32_t oversample, int32_t
     return GPCA_OK;
 }
 
+// ---- compact child (gpca_internal.h): the kept rows as a matrix of their own -------------------------------------------------------
+// Worth it when QC dropped at least half of the rows; only for a resident, unsharded matrix without a sample mask (the EigenSNP stage
+// calls work on the handle itself), and only when the copy fits beside the parent with room for the solver's workspace.
+static bool wants_child(gpca_handle* h, int32_t k, int32_t oversample) {
+    if (!h->compact_ok || h->is_child || h->sm.on || multi_rank(h) || h->d_smask || !h->have_stats || (!h->dG && !h->dG2)) return false;
+    if (h->n_pca < 1 || k + oversample > h->n_pca) return false;                       // (the usual preflight reports these)
+    if ((h->flags & 3u) != 0) return false;                                             // (missing / invalid genotypes: ditto)
+    return 2 * round_up(h->n_pca, kGQRowsPerWave) <= h->Mpad;
+}
+static int ensure_child(gpca_handle* h) {
+    if (h->child && h->child_valid) return GPCA_OK;
+    drop_child(h);
+    const bool packed = h->storage == GPCA_STORE_2BIT;
+    const int64_t n = h->n_pca, npad = round_up(n, kGQRowsPerWave), pitch = packed ? h->ld2 : h->ld8;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double)npad * (double)pitch + (double)npad * 1024.0 + (double)h->ldg * 8192.0 + 1073741824.0;
+    if (need > (double)free_b) return GPCA_ERR_OOM;                                     // (the caller carries on without the child)
+    gpca_handle* c = new gpca_handle();
+    c->is_child = true; c->compact_ok = 0;
+    c->device = h->device; c->precision = h->precision; c->storage = h->storage; c->nd = h->nd; c->ko = h->ko;
+    c->st = h->st;                                                                      // same stream: ordered with the parent's work
+    c->gtt_dma = h->gtt_dma; c->gq_dma = h->gq_dma; c->lds_planes = h->lds_planes; c->narrow_ok = h->narrow_ok; c->spin_sync = h->spin_sync;
+    c->gq_waves_target = h->gq_waves_target; c->gtt_waves_target = h->gtt_waves_target;
+    c->timing_on = h->timing_on;
+    c->M = n; c->N = h->N; c->Mpad = npad; c->ldg = h->ldg; c->ld8 = h->ld8; c->ld2 = h->ld2; c->cap_rows_pad = npad; c->pack_flags = h->pack_flags;
+    h->child = c;                                                                       // (from here on drop_child releases whatever exists)
+    auto build = [&]() -> int {
+        gpca_handle* hh = h;
+        (void)hh;
+        if (packed) { HIPCHK(hipMalloc((void**)&c->dG2, (size_t)npad * (size_t)pitch)); }
+        else { HIPCHK(hipMalloc((void**)&c->dG, (size_t)npad * (size_t)pitch)); }
+        char* gdst = packed ? (char*)c->dG2 : (char*)c->dG;
+        if (npad > n) HIPCHK(hipMemsetAsync(gdst + (size_t)n * pitch, 0, (size_t)(npad - n) * pitch, h->st));
+        launch_gather_rows(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, pitch, h->d_pca_rows, n, gdst);
+        HIPCHK(hipGetLastError());
+        {
+            gpca_handle* h = c;     // (alloc_stats reports through the handle it is given)
+            CHK(alloc_stats(h));
+        }
+        launch_gather_elems(h->st, h->d_mu, 4, h->d_pca_rows, n, c->d_mu); launch_gather_elems(h->st, h->d_sigma, 4, h->d_pca_rows, n, c->d_sigma);
+        launch_gather_elems(h->st, h->d_r, 4, h->d_pca_rows, n, c->d_r); launch_gather_elems(h->st, h->d_b, 4, h->d_pca_rows, n, c->d_b);
+        launch_gather_elems(h->st, h->d_counts, 16, h->d_pca_rows, n, c->d_counts);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(c->d_keep, 1, (size_t)n, h->st)); HIPCHK(hipMemsetAsync(c->d_reason, 0, (size_t)npad, h->st));
+        c->pca_rows.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) c->pca_rows[(size_t)i] = i;
+        c->n_pca = n;
+        HIPCHK(hipMalloc((void**)&c->d_pca_rows, (size_t)n * 8));
+        HIPCHK(hipMemcpyAsync(c->d_pca_rows, c->pca_rows.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        c->d_row_ids = h->d_pca_rows;                                                   // Omega by the rows' ORIGINAL index
+        c->snp_offset = h->snp_offset;
+        c->flags = 0; c->have_stats = true;
+        return GPCA_OK;
+    };
+    const int rc = build();
+    if (rc != GPCA_OK) { const std::string keep = c->err.empty() ? h->err : c->err; drop_child(h); h->err = keep; return rc; }
+    h->child_valid = true;
+    return GPCA_OK;
+}
+
 extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t power_iters, uint64_t seed) {
     if (!h) return GPCA_ERR_BAD_ARG;
     LOCK(h);
+    h->rsvd_on_child = false;
+    if (wants_child(h, k, oversample) && ensure_child(h) == GPCA_OK) {
+        // QC dropped most rows: the whole call runs on the kept rows gathered into a matrix of their own
+        gpca_handle* c = h->child;
+        c->timing_on = h->timing_on;
+        const int rc = gpca_rsvd(c, k, oversample, power_iters, seed);
+        if (rc != GPCA_OK) { h->err = c->err; h->have_rsvd = false; return rc; }
+        h->k = c->k; h->l = c->l; h->L = c->L; h->eig = c->eig; h->sv = c->sv;
+        h->have_rsvd = true; h->loadings_valid = true; h->rsvd_on_child = true;
+        return GPCA_OK;
+    }
     // Ranks of a sharded run leave together: agree on the preflight status before the first exchange ...
     int lrc = agree_status(h, rsvd_preflight(h, k, oversample, power_iters), "gpca_rsvd (before the sketch)");
     if (lrc != GPCA_OK) return lrc;
@@ -477,9 +550,9 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
                 HIPCHK(hipGetLastError());
                 h->rmax_valid = true;
             }
-            launch_omega_planes(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->d_cpart, h->dTd, h->d_rmax, h->d_tscale, h->d_tinv, h->nd);
+            launch_omega_planes(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->d_cpart, h->dTd, h->d_rmax, h->d_tscale, h->d_tinv, h->nd, h->d_row_ids);
             h->apart_valid = false;
-        } else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart, nullptr, 1);
+        } else launch_omega(h->st, h->M, h->Mpad, l, L, h->snp_offset, seed, h->d_r, h->d_b, h->dTb, h->d_cpart, nullptr, 1, h->d_row_ids);
         HIPCHK(hipGetLastError());
         return GPCA_OK;
     };
@@ -564,14 +637,19 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     if (!h || !out) return GPCA_ERR_BAD_ARG; \
     LOCK(h); \
     if (!h->have_rsvd) return fail(h, GPCA_ERR_STATE, name ": run gpca_rsvd first")
+// the last gpca_rsvd ran on the compact child: its results are this handle's (scores per sample; loadings per PCA SNP, in their order)
+#define ON_CHILD(call) \
+    if (h->rsvd_on_child && h->child) { const int rc_ = (call); if (rc_ != GPCA_OK) h->err = h->child->err; return rc_; }
 
 extern "C" int gpca_get_scores(gpca_handle* h, float* out) {
     NEED_RSVD("gpca_get_scores");
+    ON_CHILD(gpca_get_scores(h->child, out));
     HIPCHK(hipMemcpy(out, h->d_scores32, (size_t)h->N * h->k * 4, hipMemcpyDeviceToHost));
     return GPCA_OK;
 }
 extern "C" int gpca_get_scores_f64(gpca_handle* h, double* out) {
     NEED_RSVD("gpca_get_scores_f64");
+    ON_CHILD(gpca_get_scores_f64(h->child, out));
     HIPCHK(hipMemcpy(out, h->d_scores64, (size_t)h->N * h->k * 8, hipMemcpyDeviceToHost));
     return GPCA_OK;
 }
@@ -587,6 +665,7 @@ extern "C" int gpca_get_singular_values(gpca_handle* h, double* out) {
 }
 extern "C" int gpca_get_loadings(gpca_handle* h, float* out) {
     NEED_RSVD("gpca_get_loadings");
+    ON_CHILD(gpca_get_loadings(h->child, out));
     if (!h->loadings_valid) return fail(h, GPCA_ERR_STATE, "gpca_get_loadings: the last call (gpca_rsvd_condensed) produced sample scores only");
     if (h->n_pca) HIPCHK(hipMemcpy(out, h->d_load32, (size_t)h->n_pca * h->k * 4, hipMemcpyDeviceToHost));
     return GPCA_OK;
@@ -595,6 +674,7 @@ extern "C" int gpca_get_loadings(gpca_handle* h, float* out) {
 // PCA::transform (main.rs:659): scores = A^T U on the resident (or streamed) matrix, U = loadings.
 extern "C" int gpca_transform(gpca_handle* h, double* out) {
     NEED_RSVD("gpca_transform");
+    ON_CHILD(gpca_transform(h->child, out));
     if (!h->loadings_valid) return fail(h, GPCA_ERR_STATE, "gpca_transform: the last call (gpca_rsvd_condensed) produced sample scores only");
     HIPCHK(hipSetDevice(h->device));
     const int L = h->L, k = h->k;
@@ -785,7 +865,7 @@ extern "C" int gpca_rsvd_condensed(gpca_handle* h, int32_t k, int32_t oversample
     launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
     HIPCHK(hipGetLastError());
     HIPCHK(stream_wait(h));
-    h->have_rsvd = true; h->loadings_valid = false;
+    h->have_rsvd = true; h->loadings_valid = false; h->rsvd_on_child = false;
     return GPCA_OK;
 }
 
@@ -847,6 +927,6 @@ extern "C" int gpca_refine(gpca_handle* h, const double* S0, int32_t k) {
     launch_rightmul_gather_f32(h->st, h->d_lqr, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);   // loadings = L W
     HIPCHK(hipGetLastError());
     HIPCHK(stream_wait(h));
-    h->have_rsvd = true; h->loadings_valid = true;
+    h->have_rsvd = true; h->loadings_valid = true; h->rsvd_on_child = false;
     return GPCA_OK;
 }

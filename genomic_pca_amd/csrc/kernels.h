@@ -64,12 +64,16 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
 
 // sketch operand: Tb (blocked, all Mpad rows) = r_i * Omega[i][j] (j < l, else 0); cpart[wave][j] = sum_i b_i Omega[i][j]
 int64_t omega_num_parts(int64_t Mpad);
+// row_ids (may be NULL): global index of every row (a matrix of gathered rows draws the normals its rows would draw in place)
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
-                  const float* r, const float* b, float* Tb, float* cpart, double* apart, int blocked = 1);
+                  const float* r, const float* b, float* Tb, float* cpart, double* apart, int blocked = 1, const int64_t* row_ids = nullptr);
+void launch_gather_rows(hipStream_t st, const void* src, int64_t pitch, const int64_t* ids, int64_t n, void* dst);      // dst row i <- src row ids[i]
+void launch_gather_elems(hipStream_t st, const void* src, int elem_bytes, const int64_t* ids, int64_t n, void* dst);   // 1-, 4- or 16-byte elements
 
 // exact-integer path: the digit planes of T' = r o Omega directly (analytic column bound 6.67 * rmax[0]; no f32 T')
 void launch_omega_planes(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
-                         const float* b, float* cpart, int8_t* Td, const float* rmax, double* tscale, double* tinv, int nd);
+                         const float* b, float* cpart, int8_t* Td, const float* rmax, double* tscale, double* tinv, int nd,
+                         const int64_t* row_ids = nullptr);
 // out[0] = max_i r[i] for r >= 0 (the caller zeroes out first)
 void launch_max_f32(hipStream_t st, const float* r, int64_t n, float* out);
 

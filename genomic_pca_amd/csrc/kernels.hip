@@ -361,7 +361,8 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
                                                const float* __restrict__ r, const float* __restrict__ b,
                                                float* __restrict__ Tb, float* __restrict__ cpart, double* __restrict__ apart,
                                                int blocked, int8_t* __restrict__ Td, const float* __restrict__ rmax,
-                                               double* __restrict__ tscale, double* __restrict__ tinv, int nd) {
+                                               double* __restrict__ tscale, double* __restrict__ tinv, int nd,
+                                               const int64_t* __restrict__ row_ids) {
     // Each lane draws the L normals of its own SNP row; the wave's 64 x L tile is staged in LDS (pitch L + 1) so that
     //   * T' = r o Omega leaves as full rows, lane-contiguous (a lane writing its row 4 bytes at a time at a 128-byte
     //     stride cost 4.3x write amplification), and
@@ -374,7 +375,9 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
     const bool live = i < M;
     rs[wv][lane] = live ? r[i] : 0.f;
     bs[wv][lane] = live ? b[i] : 0.f;
-    const uint64_t gi = (uint64_t)(i + snp_offset);
+    // the row's GLOBAL index keys its normals: a matrix of gathered rows (the kept SNPs of a larger one, row_ids) draws what they
+    // would draw in place
+    const uint64_t gi = (uint64_t)(((row_ids && live) ? row_ids[i] : i) + snp_offset);
     const int LT = L >> 5;
     for (int jq = 0; jq < L / 4; ++jq) {
         double z[4] = {0, 0, 0, 0};
@@ -482,18 +485,44 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
 }
 
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
-                  const float* b, float* Tb, float* cpart, double* apart, int blocked) {
+                  const float* b, float* Tb, float* cpart, double* apart, int blocked, const int64_t* row_ids) {
     const int64_t waves = omega_num_parts(Mpad);
     hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
-                       cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4);
+                       cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4, row_ids);
 }
 // Exact-integer path: T' = r o Omega straight into digit planes Td ([L/32 halves][Mpad/32][kDigits][64][16 B]) against the analytic
 // column bound 6.67 * rmax; tscale / tinv [L] receive the scale (columns >= l: 0); cpart as above.  No f32 copy of T'.
 void launch_omega_planes(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
-                         const float* b, float* cpart, int8_t* Td, const float* rmax, double* tscale, double* tinv, int nd) {
+                         const float* b, float* cpart, int8_t* Td, const float* rmax, double* tscale, double* tinv, int nd,
+                         const int64_t* row_ids) {
     const int64_t waves = omega_num_parts(Mpad);
     hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
-                       cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd);
+                       cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);
+}
+// dst row i <- src row ids[i] (rows of `pitch` bytes, a multiple of 16): the kept SNPs of a matrix gathered into one of their own
+__global__ __launch_bounds__(256) void k_gather_rows(const uint8_t* __restrict__ src, int64_t pitch, const int64_t* __restrict__ ids,
+                                                     int64_t n, uint8_t* __restrict__ dst) {
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)ids[i] * (size_t)pitch);
+    uint4* d = reinterpret_cast<uint4*>(dst + (size_t)i * (size_t)pitch);
+    for (int64_t v = threadIdx.x; v < pitch / 16; v += 256) d[v] = s[v];
+}
+void launch_gather_rows(hipStream_t st, const void* src, int64_t pitch, const int64_t* ids, int64_t n, void* dst) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n), dim3(256), 0, st, (const uint8_t*)src, pitch, ids, n, (uint8_t*)dst);
+}
+// dst[i] <- src[ids[i]] for elements of `eb` bytes (1, 4 or 16)
+__global__ __launch_bounds__(256) void k_gather_elems(const uint8_t* __restrict__ src, int eb, const int64_t* __restrict__ ids, int64_t n,
+                                                      uint8_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = ids[i];
+    if (eb == 4) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[j];
+    else if (eb == 16) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[j];
+    else dst[i] = src[j];
+}
+void launch_gather_elems(hipStream_t st, const void* src, int elem_bytes, const int64_t* ids, int64_t n, void* dst) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_elems, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)src, elem_bytes, ids, n, (uint8_t*)dst);
 }
 // rmax[0] = max_i r[i] (r >= 0: non-negative floats order like their bit patterns); the caller zeroes rmax first
 __global__ __launch_bounds__(256) void k_max_f32(const float* __restrict__ r, int64_t n, float* __restrict__ out) {

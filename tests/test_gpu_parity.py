@@ -957,6 +957,62 @@ def test_narrow_kernels_same_bits_as_the_wide_ones(gpca, oracle, monkeypatch, M,
         assert oracle.max_abs_dpc(res["narrow"][1][:, :3], R["scores"][:, :3]) < TOL_PC
 
 
+@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("f32", "int8")])
+def test_compact_child_when_qc_drops_most_rows(gpca, oracle, monkeypatch, prec, store):
+    """QC that drops most SNP rows (configs[2] keeps 203 512 of 1 066 557): gpca_rsvd gathers the kept rows into a matrix of their
+    own and runs there -- the passes, the sketch and the quantisations cost n_pca rows instead of M.  Omega is drawn by the rows'
+    ORIGINAL index, so the sketch is the one of the uncompacted run (GPCA_COMPACT=0): same answers (only the grouping of the
+    f32 partial sums of c moves), the oracle's parity bar, loadings in PCA-SNP order, PCA::transform, the pull API still served
+    by the parent, and a changed keep mask rebuilds the child."""
+    from genomic_pca_amd import _lib
+    M, N, k = 60_000, 700, 8
+    th = gpca.synth_thresholds(M, 6, seed=3, fst=0.25)
+    G = oracle.synth_genotypes(M, N, 3, th)
+    rng = np.random.default_rng(0)
+    keep = (rng.random(M) < 0.2).astype(np.uint8)            # 20 % of the rows stay
+    kw = dict(precision=_lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8)
+    res = {}
+    for name, env in (("compact", {}), ("plain", {"GPCA_COMPACT": "0"})):
+        with monkeypatch.context() as mp:
+            for key, val in env.items():
+                mp.setenv(key, val)
+            with gpca.GpcaEngine(**kw) as e:
+                e.upload_genotypes_i8(G)
+                st = e.snp_stats(gpca.QcConfig.none())
+                e.set_standardization(st["mu"], st["sigma"], keep)
+                e.enable_timings(True)
+                e.rsvd(k, 10, 2, seed=5)
+                tim = e.timings()
+                res[name] = (e.eigenvalues(), e.scores(f64=True), e.loadings(), e.transform(), e.singular_values())
+                assert e.num_pca_snps() == int(keep.sum()) and res[name][2].shape == (int(keep.sum()), k)
+                # algorithmic bytes of a GEMM launch: the rows it swept
+                per = 0.25 if store == "2bit" else 1.0
+                rows_swept = tim["gemm_GQ"]["bytes"] / tim["gemm_GQ"]["launches"] / (N * per)
+                assert abs(rows_swept - (int(keep.sum()) if name == "compact" else M)) < 1
+                blk = e.standardize_block([0, 5], [0, 1, 2])             # the pull API: served by the parent, PCA-SNP numbering
+                rows = e.pca_snp_rows()
+                ref, err = oracle.standardize_block(G, st["mu"], st["sigma"], rows[[0, 5]], [0, 1, 2])
+                assert err is None and np.array_equal(blk, ref)
+                if name == "compact":                                    # a different keep mask: the child is rebuilt
+                    keep2 = keep.copy(); keep2[::3] = 0
+                    e.set_standardization(st["mu"], st["sigma"], keep2)
+                    e.rsvd(k, 10, 2, seed=5)
+                    assert e.loadings().shape == (int(keep2.sum()), k)
+                    r2, b2 = oracle.scale_shift(st["mu"], st["sigma"], keep2)
+                    R2 = oracle.rsvd(G, N, r2, b2, k, 10, 2, seed=5)
+                    assert oracle.max_abs_dpc(e.scores(f64=True)[:, :5], R2["scores"][:, :5]) < TOL_PC
+    tol = 1e-7 if prec == "i8" else 1e-5
+    assert np.max(np.abs(res["compact"][0] - res["plain"][0]) / res["plain"][0]) < tol
+    assert oracle.max_abs_dpc(res["compact"][1][:, :5], res["plain"][1][:, :5]) < tol
+    assert oracle.max_abs_dpc(res["compact"][2].astype(np.float64)[:, :5], res["plain"][2].astype(np.float64)[:, :5]) < 10 * tol
+    assert oracle.max_abs_dpc(res["compact"][3][:, :5], res["plain"][3][:, :5]) < 10 * tol
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], keep)
+    R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=5)
+    assert np.max(np.abs(res["compact"][0] - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+    assert oracle.max_abs_dpc(res["compact"][1][:, :5], R["scores"][:, :5]) < TOL_PC
+    assert oracle.max_abs_dpc(res["compact"][2].astype(np.float64)[:, :5], R["loadings"][keep.astype(bool)][:, :5]) < TOL_PC
+
+
 @pytest.mark.parametrize("store", ["int8", "2bit"])
 @pytest.mark.parametrize("k,oversample,q", [(22, 10, 2), (6, 0, 0), (1, 3, 1)])
 def test_rsvd_i8_sketch_width_and_iteration_edges(gpca, oracle, store, k, oversample, q):
