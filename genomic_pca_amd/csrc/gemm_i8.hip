@@ -1075,8 +1075,30 @@ int launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
 //     The prologue issues G0 G1 Q0 G2 G3 G4 G5 so that the same counts hold from the first stage on.
 //   A wave reads only its own unit slots: its counted vmcnt orders those reads; the planes are shared, so their wait is
 //   followed by the workgroup barrier.
+//   * rounds of fewer tiles (R = 3, 2, 1; ring of 6).  A workgroup's range rarely ends on a full round of 16 units (1M rows on
+//     256 workgroups: 122 units = 7 full rounds + 10 units); the short last round used to sweep the samples with four tiles per
+//     wave all the same (the missing ones re-reading tile 0), an eighth round's time for 0.63 rounds of work = 4.6 % of the launch.
+//     Now a wave with nv < 4 units runs the round with R = nv tiles -- its own instantiation, beside waves of the same workgroup
+//     that run another R: the stage barrier and the plane DMAs (wave w: plane w) are the same for every R.  Counts for R tiles:
+//     - stage start: the R refills of the previous stage are younger than Q(s): vmcnt(4 R) (stricter than needed in stage 0,
+//       where the prologue's 4 fills follow Q(0)).
+//     - before the first read of unit m + 1 (during unit m, before m's own refill): fills m+2..m+5 are younger (16) plus 4 per
+//       stage start since fill m+1 was issued at the end of unit m-5, i.e. per unit u in [m-4, m] with u mod R = 0.  In the steady
+//       state that depends on t = m mod R only (gqd_q_young); the first units of a round have fewer stage starts behind them, so
+//       the stages before gqd_early_stages(R) wait with the smallest count any of them needs (a stricter wait is always safe).
 // ================================================================================================
 constexpr int kGqdSlots = 6;
+// plane batches younger than the fill of unit m + 1 while unit m (tile t = m mod R) is consumed, steady state (m >= 4)
+constexpr int gqd_q_young(int R, int t) {
+    int n = 0;
+    for (int j = 0; j <= 4; ++j) n += (((t - j) % R + R) % R == 0) ? 1 : 0;
+    return n;
+}
+constexpr int gqd_early_stages(int R) { return R == 3 ? 2 : (R == 2 ? 2 : 4); }   // stages holding a unit m < 4 (R = 1: 0..3)
+constexpr int gqd_q_young_early(int R) { return R == 1 ? 2 : 1; }                  // fewest plane batches behind any unit of those stages
+static_assert(gqd_q_young(4, 0) == 2 && gqd_q_young(4, 1) == 1 && gqd_q_young(4, 2) == 1 && gqd_q_young(4, 3) == 1, "R = 4: vmcnt 24/20/20/20");
+static_assert(gqd_q_young(3, 0) == 2 && gqd_q_young(3, 1) == 2 && gqd_q_young(3, 2) == 1, "R = 3: vmcnt 24/24/20");
+static_assert(gqd_q_young(2, 0) == 3 && gqd_q_young(2, 1) == 2 && gqd_q_young(1, 0) == 5, "R = 2: vmcnt 28/24; R = 1: 36");
 template <int S>
 struct GqdSmemT {
     i32x4 q[2][4][kDigits][64];          // digit planes: [slot][step][digit][lane]          32 KiB
@@ -1097,6 +1119,16 @@ __device__ __forceinline__ void gqd_dma(uint32_t lds_addr, uint32_t voff, i32x4 
                      : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 template <int N> __device__ __forceinline__ void gqd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// the same with the count chosen by a value that is a constant after unrolling (16 + 4 x plane batches)
+__device__ __forceinline__ void gqd_wait_young(int qb) {
+    switch (qb) {
+        case 1: gqd_wait_vm<20>(); break;
+        case 2: gqd_wait_vm<24>(); break;
+        case 3: gqd_wait_vm<28>(); break;
+        case 4: gqd_wait_vm<32>(); break;
+        default: gqd_wait_vm<36>(); break;
+    }
+}
 __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
     const uint64_t a = (uint64_t)p;
     i32x4 r;
@@ -1107,13 +1139,13 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
     return r;
 }
 
-template <int NT, int S>
+template <int NT, int S, int R = 4>
 __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
                                           const int8_t* __restrict__ Qd, GqdSmemT<S>* sm, int wv, int lane, int c, int h,
                                           int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float* __restrict__ cunit, float& amax) {
-    constexpr int R = 4;
+    static_assert(R >= 1 && R <= 4 && (S == 6 || R == 4), "rounds of fewer than 4 tiles are derived for the 6-slot ring");
     const int64_t row0 = unit0 * 32;
     const i32x4 rg = gqd_rsrc(G + row0 * ldg);
     const i32x4 rq = gqd_rsrc(Qd + wv * 1024);
@@ -1163,21 +1195,30 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
             gqd_dma(lds_q + (uint32_t)(((QS) * 4 + j) * kDigits) * 1024u, qvo, rq, ((uint32_t)(ST) * 4u + j) * QCH); \
     }
-    const int64_t s1 = nstage > 1 ? 1 : 0;
-    // ring of S slots: the unit consumed is re-filled with the unit S ahead; S - 4 units precede Q(0) in the prologue so
-    // that the steady-state counts hold from the first stage on (S = 6: G0 G1 Q0 G2..G5;  S = 7: G0 G1 G2 Q0 G3..G6)
-    GQD_ISSUE_G(0, 0, 0) GQD_ISSUE_G(0, 1, 1)
-    if constexpr (S == 7) GQD_ISSUE_G(0, 2, 2)
+    // ring of S slots: the unit consumed is re-filled with the unit S ahead, units in the order they are consumed (stage-major,
+    // R tiles per stage; past the last stage the fills wrap to stage 0 and are never read); S - 4 units precede Q(0) in the
+    // prologue so that the steady-state counts hold from the first stage on (S = 6: G0 G1 Q0 G2..G5;  S = 7: G0 G1 G2 Q0 G3..G6)
+    int64_t ist = 0;         // next unit to issue: (stage ist, tile it)
+    int it = 0;
+#define GQD_ISSUE_NEXT(SLOT)                                                                              \
+    {                                                                                                     \
+        GQD_ISSUE_G(ist, it, SLOT)                                                                        \
+        if (++it == R) { it = 0; ist = ist + 1 < nstage ? ist + 1 : 0; }                                  \
+    }
+    GQD_ISSUE_NEXT(0) GQD_ISSUE_NEXT(1)
+    if constexpr (S == 7) GQD_ISSUE_NEXT(2)
     GQD_ISSUE_Q(0, 0)
-    if constexpr (S == 6) { GQD_ISSUE_G(0, 2, 2) GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) }
-    else { GQD_ISSUE_G(0, 3, 3) GQD_ISSUE_G(s1, 0, 4) GQD_ISSUE_G(s1, 1, 5) GQD_ISSUE_G(s1, 2, 6) }
-    int64_t ist = s1;        // next unit to issue: (stage ist, tile it), always into the slot just consumed
-    int it = S - 4;
+#pragma unroll
+    for (int sl = S - 4; sl < S; ++sl) GQD_ISSUE_NEXT(sl)
     uint32_t rslot = 0;      // slot of the unit being consumed
     i32x4 gcur, gnxt;
 
     for (int64_t st = 0; st < nstage; ++st) {
-        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");      // Q(st) landed in every wave's plane
+        // Q(st) landed in every wave's plane: the R refills of the previous stage are younger
+        if constexpr (R == 4) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        else if constexpr (R == 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else if constexpr (R == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         GQD_ISSUE_Q(st + 1 < nstage ? st + 1 : 0, (int)((st + 1) & 1))
         i32x4 q[4][kDigits];
 #pragma unroll
@@ -1202,8 +1243,13 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                 } else {
                     if (s4 == 2) {
                         // younger than the next unit: S - 2 unit fills + 1 plane batch (2 when a stage start falls in the window)
-                        if (S == 6) { if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>(); }
-                        else { if (t <= 1) gqd_wait_vm<28>(); else gqd_wait_vm<24>(); }
+                        if constexpr (R == 4) {
+                            if (S == 6) { if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>(); }
+                            else { if (t <= 1) gqd_wait_vm<28>(); else gqd_wait_vm<24>(); }
+                        } else {
+                            if (st < gqd_early_stages(R)) gqd_wait_young(gqd_q_young_early(R));
+                            else gqd_wait_young(gqd_q_young(R, t));
+                        }
                     }
                     gfar = *reinterpret_cast<const i32x4*>(gl + nslot * 4096u + loff[s4 - 2]);
                 }
@@ -1213,8 +1259,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                 if (s4 == 3) {
                     // every read of this unit has returned (its last operand fed the MFMAs above): re-fill its slot
                     asm volatile("" :: "v"(gcur));
-                    GQD_ISSUE_G(ist, it, rslot)
-                    if (++it == R) { it = 0; ist = ist + 1 < nstage ? ist + 1 : 0; }
+                    GQD_ISSUE_NEXT(rslot)
                 }
                 gcur = gnxt; gnxt = gfar;
             }
@@ -1222,6 +1267,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // ring and plane slots quiescent before the next round
+#undef GQD_ISSUE_NEXT
 #undef GQD_ISSUE_G
 #undef GQD_ISSUE_Q
 #pragma unroll
@@ -1250,7 +1296,8 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
-                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt) {
+                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt,
+                                                  int short_rounds) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmemT<S>* sm = reinterpret_cast<GqdSmemT<S>*>(gqd_smem);
     i32x4 (*tds)[4][kDigits][64] = sm->q;
@@ -1265,16 +1312,25 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
     int64_t u = u0;
     while (u < u1) {
         const int64_t rem = u1 - u;
-        if (rem > 8) {           // up to 4 tiles per wave, genotypes by LDS-DMA
-            // a short last round (9..15 units) is split evenly -- (3,3,2,2) rather than (4,4,2,0) -- so that no wave sweeps
-            // the samples for nothing while another carries a full load
+        const bool shorter = S == 6 && short_rounds;
+        if (shorter || rem > 8) {           // up to 4 tiles per wave, genotypes by LDS-DMA
+            // a short last round (1..15 units) is split evenly -- (3,3,2,2) rather than (4,4,2,0) -- and every wave sweeps the
+            // samples with as many tiles as it has units (6-slot ring; a wave without a unit rides along for the planes and the
+            // barriers)
             const int64_t take = rem < 16 ? rem : 16;
             const int64_t base = take >> 2, extra = take & 3;
             const int64_t mine = u + wv * base + (wv < extra ? wv : extra);
             const int nv = (int)(base + (wv < extra ? 1 : 0));
-            gqd_round<NT, S>(G, ldg, nstage, Qd, sm, wv, lane, c, h, mine, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
+#define GPCA_GQD_ROUND(RR, UNIT0, NV) gqd_round<NT, S, RR>(G, ldg, nstage, Qd, sm, wv, lane, c, h, (UNIT0), (NV), qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax)
+            if constexpr (S == 6) {
+                if (!shorter || nv == 4) GPCA_GQD_ROUND(4, mine, nv);
+                else if (nv == 3) GPCA_GQD_ROUND(3, mine, 3);
+                else if (nv == 2) GPCA_GQD_ROUND(2, mine, 2);
+                else GPCA_GQD_ROUND(1, nv ? mine : u, nv);
+            } else GPCA_GQD_ROUND(4, mine, nv);
+#undef GPCA_GQD_ROUND
             u += take;
-        } else if (rem > 4) {    // tails: the register-staged rounds
+        } else if (rem > 4) {    // tails (7-slot ring, GPCA_GQ_SHORT=0): the register-staged rounds
             const int64_t mine = u + 2 * wv;
             const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
             gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
@@ -1303,7 +1359,7 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
 #define GPCA_GQD(NTV, SV)                                                                                                       \
     {                                                                                                                          \
         hipLaunchKernelGGL((k_gq_d<NTV, SV>), grid, blk, sizeof(GqdSmemT<SV>), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, \
-                           Tout, cpart, apart, scale_out, ldt);                                                                \
+                           Tout, cpart, apart, scale_out, ldt, ko.gq_short);                                                   \
     }
     if (slots == 7) { if (g_dma_nt) GPCA_GQD(1, 7) else GPCA_GQD(0, 7) }
     else { if (g_dma_nt) GPCA_GQD(1, 6) else GPCA_GQD(0, 6) }

@@ -92,6 +92,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     h->ko.dma_nt = env_int("GPCA_GQ_DMA_NT", 1) != 0;
     h->ko.gq_r = env_int("GPCA_GQ_R", 4);
     h->ko.gq_slots = env_int("GPCA_GQ_SLOTS", 6) == 7 ? 7 : 6;
+    h->ko.gq_short = env_int("GPCA_GQ_SHORT", 1) != 0;
     h->ko.gtt_xcd = env_int("GPCA_GTT_XCD", 1);
     h->ko.gttx_xcd = env_int("GPCA_GTTX_XCD", 0);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
@@ -134,6 +135,7 @@ extern "C" int gpca_destroy(gpca_handle* h) {
       stream_close(h);
       for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
       for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+      if (h->ev_status) (void)hipEventDestroy(h->ev_status);
       if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
       free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
       dfree(h->d_blk_rows); dfree(h->d_blk_cols); dfree(h->d_blk_out); dfree(h->d_blk_err); dfree(h->d_status); if (h->h_status) { (void)hipHostFree(h->h_status); h->h_status = nullptr; }
@@ -424,18 +426,12 @@ hipError_t stream_wait(gpca_handle* h) {
 // summed through the same transport as the sketch; all ranks then return the most severe (smallest) status any rank saw.
 // A rank whose own shard is clean therefore leaves the call with the failing rank's code instead of waiting in a collective
 // that the failing rank never enters.  Single-rank handles return local_rc untouched (no device work).
-int agree_status(gpca_handle* h, int local_rc, const char* where) {
-    if (!multi_rank(h)) return local_rc;
-    const std::string own = h->err;
-    if (!h->d_status || !h->h_status) return fail(h, GPCA_ERR_STATE, "agree_status: no status buffer (gpca_comm_init / gpca_set_allreduce_hook allocate it)");
-    double* v = h->h_status + 16;
-    for (int i = 0; i < 16; ++i) h->h_status[i] = 0.0;
-    h->h_status[local_rc == GPCA_OK ? 0 : std::min(15, -local_rc)] = 1.0;
-    // pinned staging both ways and one wait: H2D, exchange and D2H are stream-ordered
-    HIPCHK(hipMemcpyAsync(h->d_status, h->h_status, 16 * sizeof(double), hipMemcpyHostToDevice, h->st));
-    CHK(allreduce_f64(h, h->d_status, 16));
-    HIPCHK(hipMemcpyAsync(v, h->d_status, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-    HIPCHK(stream_wait(h));
+void status_histogram(double* slots16, int local_rc) {
+    for (int i = 0; i < 16; ++i) slots16[i] = 0.0;
+    slots16[local_rc == GPCA_OK ? 0 : std::min(15, -local_rc)] = 1.0;
+}
+// what the ranks agreed on, from the summed histogram v[16]; `own` = this rank's error text at the time of its contribution
+int status_verdict(gpca_handle* h, const double* v, int local_rc, const std::string& own, const char* where) {
     int agreed = GPCA_OK;
     for (int i = 15; i >= 1; --i) if (v[i] > 0.5) agreed = -i;    // ends on the smallest index = GPCA_ERR_BAD_ARG first ... any is fine, all ranks pick the same
     if (agreed == GPCA_OK) return GPCA_OK;
@@ -445,6 +441,35 @@ int agree_status(gpca_handle* h, int local_rc, const char* where) {
              gpca_status_string(agreed), "all ranks leave the call together", h->rank, local_rc == GPCA_OK ? "ok" : gpca_status_string(local_rc),
              local_rc == GPCA_OK ? "" : " -- ", local_rc == GPCA_OK ? "" : own.c_str());
     return fail(h, agreed, buf);
+}
+// The agreement in two halves, so that the host does not stand still for it: _begin enqueues contribution, exchange and the copy back
+// and records an event; the caller goes on enqueueing rank-local work and asks for the verdict (_end) only before it would enter the
+// next exchange -- by then the event is long past and the stream has work queued behind it.
+int agree_status_begin(gpca_handle* h, int local_rc) {
+    if (!multi_rank(h)) return GPCA_OK;
+    if (!h->d_status || !h->h_status) return fail(h, GPCA_ERR_STATE, "agree_status: no status buffer (gpca_comm_init / gpca_set_allreduce_hook allocate it)");
+    h->status_own = h->err;
+    status_histogram(h->h_status, local_rc);
+    // pinned staging both ways: H2D, exchange and D2H are stream-ordered
+    HIPCHK(hipMemcpyAsync(h->d_status, h->h_status, 16 * sizeof(double), hipMemcpyHostToDevice, h->st));
+    CHK(allreduce_f64(h, h->d_status, 16));
+    HIPCHK(hipMemcpyAsync(h->h_status + 16, h->d_status, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    if (!h->ev_status) HIPCHK(hipEventCreateWithFlags(&h->ev_status, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->ev_status, h->st));
+    return GPCA_OK;
+}
+int agree_status_end(gpca_handle* h, int local_rc, const char* where) {
+    if (!multi_rank(h)) return local_rc;
+    hipError_t e;
+    if (h->spin_sync) { while ((e = hipEventQuery(h->ev_status)) == hipErrorNotReady) {} }
+    else e = hipEventSynchronize(h->ev_status);
+    HIPCHK(e);
+    return status_verdict(h, h->h_status + 16, local_rc, h->status_own, where);
+}
+int agree_status(gpca_handle* h, int local_rc, const char* where) {
+    if (!multi_rank(h)) return local_rc;
+    CHK(agree_status_begin(h, local_rc));
+    return agree_status_end(h, local_rc, where);
 }
 
 extern "C" int gpca_comm_count_ranks(gpca_handle* h, int32_t* ranks) {

@@ -181,6 +181,8 @@ struct gpca_handle {
     bool loadings_valid = true;      // (gpca_rsvd_condensed leaves scores only)
     double* d_status = nullptr;      // [16] status word the ranks agree on
     double* h_status = nullptr;      // pinned [32]: contribution | agreed histogram
+    hipEvent_t ev_status = nullptr;  // after the agreed histogram has landed in h_status (agree_status_begin / _end)
+    std::string status_own;          // this rank's error text when it contributed
     // persistent scratch of the pull API (no allocation per call)
     int64_t *d_blk_rows = nullptr, *d_blk_cols = nullptr; float* d_blk_out = nullptr; unsigned long long* d_blk_err = nullptr;
     size_t cap_blk_rows = 0, cap_blk_cols = 0, cap_blk_out = 0;
@@ -290,6 +292,10 @@ void filler_cancel(Filler& f);                              // drop what was pos
 int allreduce_f64(gpca_handle* h, double* dbuf, int64_t count);   // in-place sum across the ranks that share the sharded matrix
 hipError_t stream_wait(gpca_handle* h);
 int agree_status(gpca_handle* h, int local_rc, const char* where);
+int agree_status_begin(gpca_handle* h, int local_rc);                        // enqueue contribution + exchange + copy back, record ev_status
+int agree_status_end(gpca_handle* h, int local_rc, const char* where);       // wait for ev_status, return what the ranks agreed on
+void status_histogram(double* slots16, int local_rc);
+int status_verdict(gpca_handle* h, const double* v, int local_rc, const std::string& own, const char* where);
 void drop_child(gpca_handle* h);    // the compact child is stale (rows, statistics or keep mask changed) or the handle goes away
 
 // fn(view) once for the resident matrix, or once per panel (generated / copied ahead on the fill stream)

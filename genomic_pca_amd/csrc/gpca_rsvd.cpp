@@ -396,12 +396,12 @@ static int ensure_workspace(gpca_handle* h) {
     // c partials: per wave x L (f32 path, Omega: 64-row groups), or per 32-row unit x 32 per column half (exact path)
     const int64_t cparts = std::max({h->gqplan.waves * (int64_t)L, omega_num_parts(h->Mpad) * (int64_t)L, h->Mpad * (int64_t)(L / 32)});
     CHK(ensure(h, h->d_cpart, h->cap_cpart, (size_t)cparts));
-    CHK(ensure(h, h->dY, h->cap_Y, (size_t)N * L));
+    CHK(ensure(h, h->dY, h->cap_Y, (size_t)N * L + 16));   // (+ 16 status slots: gpca_transform's agreement rides its exchange)
     const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L, absmax_num_parts(h->Mpad) * (int64_t)32, 2 * tail_num_parts(Npad) * (int64_t)L});
     CHK(ensure(h, h->d_part64, h->cap_part64, (size_t)p64));
     if (!h->d_c) {
         HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));
-        HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, 64 * 64 * 8));
+        HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, (64 * 64 + 16) * 8));   // (+ the 16 status slots that ride the Gram's exchange)
         HIPCHK(hipMalloc((void**)&h->dZ, 2 * 64 * 64 * 8));
         HIPCHK(hipHostMalloc((void**)&h->h_pin, (3 * 64 * 64 + 16) * 8, hipHostMallocDefault)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
         HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
@@ -530,15 +530,29 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         h->have_rsvd = true; h->loadings_valid = true; h->rsvd_on_child = true;
         return GPCA_OK;
     }
-    // Ranks of a sharded run leave together: agree on the preflight status before the first exchange ...
-    int lrc = agree_status(h, rsvd_preflight(h, k, oversample, power_iters), "gpca_rsvd (before the sketch)");
-    if (lrc != GPCA_OK) return lrc;
-    const int l = h->l, L = h->L;
+    // Ranks of a sharded run leave together: they agree on the preflight status before the first exchange.  The agreement is
+    // enqueued here and read just before that exchange (agree_status_begin / _end): a clean rank enqueues its sketch meanwhile, so the
+    // host never stands still for the round trip; a rank whose preflight failed waits for the verdict and leaves.
     const bool mr = multi_rank(h);
+    const int pre = rsvd_preflight(h, k, oversample, power_iters);
+    if (!mr) { if (pre != GPCA_OK) return pre; }
+    else {
+        CHK(agree_status_begin(h, pre));
+        if (pre != GPCA_OK) return agree_status_end(h, pre, "gpca_rsvd (before the sketch)");
+    }
+    bool agreement_pending = mr;
+    int lrc = GPCA_OK;
+    const int l = h->l, L = h->L;
     // ... and from here on a rank-local failure is remembered (lrc) while the rank keeps entering every exchange of the call, so
     // that its peers are not left inside a collective; the second agreement below returns the failure on every rank.
 #define LOCAL(x) do { if (lrc == GPCA_OK) lrc = (x); if (lrc != GPCA_OK && !mr) return lrc; } while (0)
-#define EXCHANGE(buf, count) do { const int xrc_ = allreduce_f64(h, (buf), (count)); if (xrc_ != GPCA_OK) return xrc_; } while (0)
+#define EXCHANGE(buf, count) do { \
+        if (agreement_pending) { \
+            agreement_pending = false; \
+            const int arc_ = agree_status_end(h, GPCA_OK, "gpca_rsvd (before the sketch)"); \
+            if (arc_ != GPCA_OK) { (void)hipStreamSynchronize(h->st); return arc_; }   /* a peer's preflight failed: nobody enters the exchange */ \
+        } \
+        const int xrc_ = allreduce_f64(h, (buf), (count)); if (xrc_ != GPCA_OK) return xrc_; } while (0)
     auto omega = [&]() -> int {
         // 1. sketch: T' = r o Omega, c = b^T Omega
         ScopedTimer t(h, "omega", 0.0, (double)h->M * L * 4.0);
@@ -580,18 +594,28 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         return GPCA_OK;
     };
     LOCAL(gram_b());
-    EXCHANGE(h->dW, (int64_t)L * L);
+    // the second agreement rides the Gram's exchange: every rank appends its status histogram to the l x l block (no round trip of its own)
+    if (mr) {
+        h->status_own = h->err;
+        status_histogram(h->h_status, lrc);
+        if (hipMemcpyAsync(h->dW + (size_t)L * L, h->h_status, 16 * sizeof(double), hipMemcpyHostToDevice, h->st) != hipSuccess && lrc == GPCA_OK)
+            lrc = fail(h, GPCA_ERR_HIP, "gpca_rsvd: status copy failed");
+    }
+    EXCHANGE(h->dW, (int64_t)L * L + (mr ? 16 : 0));
     // The only host step: the l x l eigenproblem.  Pinned staging + a busy-polled stream keep the round trip short
     // (pageable copies and a sleeping hipStreamSynchronize cost ~220 us here); everything after it is enqueued at once.
     std::vector<double> C((size_t)l * l), V((size_t)l * l), w((size_t)l);
     double* Wfull = h->h_pin;
     double* Zpin = h->h_pin + 64 * 64;                    // [scores Z (L x k) | loadings Z (L x k)]
     int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * 64 * 64);
+    bool status_here = false;     // the summed status slots have landed in h_status[16..32)
     auto fetch_w = [&]() -> int {
         HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
+        if (mr) HIPCHK(hipMemcpyAsync(h->h_status + 16, h->dW + (size_t)L * L, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipMemcpyAsync(flagpin, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
         HIPCHK(stream_wait(h));
-        if (*flagpin) {
+        status_here = true;
+        if (*flagpin) {   // (computed redundantly on the replicated Y: the same on every rank)
             char buf[160];
             snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not finite (overflow or NaN in the sketch)", *flagpin - 1, l);
             return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
@@ -599,7 +623,15 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         return GPCA_OK;
     };
     LOCAL(fetch_w());
-    lrc = agree_status(h, lrc, "gpca_rsvd (after the last exchange)");
+    if (mr) {
+        // a rank that failed earlier skipped the fetch: it still reads what the ranks agreed on
+        if (!status_here && (hipMemcpyAsync(h->h_status + 16, h->dW + (size_t)L * L, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st) != hipSuccess ||
+                             stream_wait(h) != hipSuccess)) return lrc != GPCA_OK ? lrc : fail(h, GPCA_ERR_HIP, "gpca_rsvd: status fetch failed");
+        const std::string own_now = h->err;
+        const int agreed = status_verdict(h, h->h_status + 16, lrc, h->status_own, "gpca_rsvd (after the last exchange)");
+        if (agreed != GPCA_OK) return agreed;
+        h->err = own_now;
+    }
     if (lrc != GPCA_OK) return lrc;
 #undef LOCAL
 #undef EXCHANGE
@@ -694,8 +726,23 @@ extern "C" int gpca_transform(gpca_handle* h, double* out) {
     };
     LOCAL(prep());
     LOCAL(stage_AtT_local(h));
-    { const int xrc = allreduce_f64(h, h->dY, h->N * (int64_t)L); if (xrc != GPCA_OK) return xrc; }
-    lrc = agree_status(h, lrc, "gpca_transform");
+    const size_t nY = (size_t)h->N * L;
+    if (mr) {
+        // the agreement rides the one exchange of the call: 16 status slots behind the N x L block (no round trip of its own)
+        if (h->cap_Y < nY + 16) return fail(h, GPCA_ERR_STATE, "gpca_transform: workspace of the last gpca_rsvd is gone");
+        h->status_own = h->err;
+        status_histogram(h->h_status, lrc);
+        if (hipMemcpyAsync(h->dY + nY, h->h_status, 16 * sizeof(double), hipMemcpyHostToDevice, h->st) != hipSuccess && lrc == GPCA_OK)
+            lrc = fail(h, GPCA_ERR_HIP, "gpca_transform: status copy failed");
+    }
+    { const int xrc = allreduce_f64(h, h->dY, (int64_t)nY + (mr ? 16 : 0)); if (xrc != GPCA_OK) return xrc; }
+    if (mr) {
+        const int own_rc = lrc;
+        if (hipMemcpyAsync(h->h_status + 16, h->dY + nY, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st) != hipSuccess || stream_wait(h) != hipSuccess)
+            return own_rc != GPCA_OK ? own_rc : fail(h, GPCA_ERR_HIP, "gpca_transform: status fetch failed");
+        lrc = status_verdict(h, h->h_status + 16, own_rc, h->status_own, "gpca_transform");
+        if (lrc == GPCA_OK) lrc = own_rc;
+    }
     if (lrc != GPCA_OK) return lrc;
 #undef LOCAL
     // only the k columns asked for leave the device (the whole N x L block was 256 MB at N = 500k, L = 64): compacted on the device

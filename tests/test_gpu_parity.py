@@ -894,7 +894,8 @@ def test_random_shapes_against_the_oracle(gpca, oracle, monkeypatch, case):
                                  {"GPCA_GQ_SLOTS": "7", "GPCA_GQ_WAVES": "8"}, {"GPCA_GTT_XCD": "0"}, {"GPCA_GQ_DMA_NT": "0"},
                                  {"GPCA_GQ_DMA": "0", "GPCA_GQ_R": "2"}, {"GPCA_LDS_PLANES": "0", "GPCA_STREAM_NT": "1"},
                                  {"GPCA_GTT_DMA": "0", "GPCA_GTTX_XCD": "1"},
-                                 {"GPCA_GQ_WAVES": "12", "GPCA_GQ_SLOTS": "7"}, {"GPCA_GQ_WAVES": "8", "GPCA_GQ_DMA_NT": "0"}])
+                                 {"GPCA_GQ_WAVES": "12", "GPCA_GQ_SLOTS": "7"}, {"GPCA_GQ_WAVES": "8", "GPCA_GQ_DMA_NT": "0"},
+                                 {"GPCA_GQ_SHORT": "0"}, {"GPCA_GQ_SHORT": "0", "GPCA_GQ_WAVES": "12"}])
 def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     """Register-staged (k_gq_x / k_gtt_x) and per-wave-plane (k_gq_i8 / k_gtt_i8) kernels, and a tiny grid that forces
     full LDS-DMA rounds on a small matrix, against the default configuration: the integer products are exact, so only
@@ -918,6 +919,37 @@ def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
     R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=1)
     assert oracle.max_abs_dpc(res["alt"][1], R["scores"]) < TOL_PC
+
+
+@pytest.mark.parametrize("N", [200, 1000])
+@pytest.mark.parametrize("M", [500, 1500, 2500, 3700])
+def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, monkeypatch, M, N):
+    """k_gq_d's rounds of fewer than four tiles per wave (R = 3, 2, 1 and waves that only ride along): grids of 1, 2 and 3 workgroups
+    over 16 ... 116 row units leave every remainder class behind the full rounds -- (3,3,2,2), (2,2,1,1), (1,1,1,1), (2,1,1,1),
+    (1,1,0,0) ... --, on 2 stages (the ring's prologue wraps around the sample axis) and on 8.  The register-staged kernel
+    (GPCA_GQ_DMA=0) computes the same integers with the same pinned f32 roundings: every result must be the same bits, and the
+    oracle bar holds."""
+    from genomic_pca_amd import _lib
+    k = 5
+    th = gpca.synth_thresholds(M, 3, seed=5, fst=0.1)
+    G = oracle.synth_genotypes(M, N, 5, th)
+    res = {}
+    for name, env in (("staged", {"GPCA_GQ_DMA": "0"}), ("w4", {"GPCA_GQ_WAVES": "4"}), ("w8", {"GPCA_GQ_WAVES": "8"}), ("w12", {"GPCA_GQ_WAVES": "12"}),
+                      ("default", {})):
+        with monkeypatch.context() as mp:
+            for key, val in env.items():
+                mp.setenv(key, val)
+            with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
+                e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 5, 2, seed=3)
+                res[name] = (e.eigenvalues().copy(), e.scores(f64=True).copy(), e.loadings().copy())
+    for name in ("w4", "w8", "w12", "default"):
+        for a, b in zip(res[name], res["staged"]):
+            assert np.array_equal(a, b), name
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r, b, k, 5, 2, seed=3)
+    assert np.max(np.abs(res["default"][0] - R["eigenvalues"]) / R["eigenvalues"]) < 1e-4
+    assert oracle.max_abs_dpc(res["default"][1][:, :2], R["scores"][:, :2]) < TOL_PC
 
 
 @pytest.mark.parametrize("M,N,k", [(70_001, 64, 20), (70_001, 128, 20), (33_333, 129, 10), (50_000, 256, 40), (40_000, 50, 5), (300, 2, 1)])

@@ -17,6 +17,15 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 LUT_A1 = np.array([2, -127, 1, 0], np.int8)          # count_a1: 00->2, 01->missing, 10->1, 11->0 (prepare.rs:622-629)
 
 
+@pytest.fixture(autouse=True)
+def _resident_reference_uncompacted(monkeypatch):
+    """The resident engines of this module are the references of bit-for-bit comparisons with streamed and sharded runs.  A resident
+    matrix whose QC dropped more than half of the rows would run gpca_rsvd on the kept rows gathered into a matrix of their own
+    (tests/test_gpu_parity.py::test_compact_child_when_qc_drops_most_rows), which regroups the f32 partial sums of c = b^T T -- 1e-9,
+    not the same bits; a streamed or sharded handle never compacts.  GPCA_COMPACT=0 keeps the references on the full matrix."""
+    monkeypatch.setenv("GPCA_COMPACT", "0")
+
+
 def _modes(store):
     from genomic_pca_amd import _lib
     return dict(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8)
