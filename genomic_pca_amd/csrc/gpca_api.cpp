@@ -8,8 +8,12 @@ using namespace gpca;
 RcclApi g_rccl;
 thread_local std::string g_last_global_err;
 
+// The failing call's text is kept twice: on the handle, and for the calling thread -- several threads may be inside
+// gpca_standardize_block on one handle at once, and each must read ITS failure back from gpca_last_error.
+static thread_local const gpca_handle* g_tls_err_handle = nullptr;
+static thread_local std::string g_tls_err;
 int fail(gpca_handle* h, int code, const std::string& msg) {
-    if (h) h->err = msg; else g_last_global_err = msg;
+    if (h) { h->err = msg; g_tls_err_handle = h; g_tls_err = msg; } else g_last_global_err = msg;
     return code;
 }
 
@@ -46,7 +50,12 @@ extern "C" const char* gpca_status_string(int s) {
     }
 }
 
-extern "C" const char* gpca_last_error(gpca_handle* h) { return h ? h->err.c_str() : g_last_global_err.c_str(); }
+extern "C" const char* gpca_last_error(gpca_handle* h) {
+    if (!h) return g_last_global_err.c_str();
+    // this thread's own last failure on this handle (a thread that never failed here reads the handle's text)
+    if (g_tls_err_handle == h) return g_tls_err.c_str();
+    return h->err.c_str();
+}
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -128,6 +137,7 @@ void drop_child(gpca_handle* h) {
 
 extern "C" int gpca_destroy(gpca_handle* h) {
     if (!h) return GPCA_OK;
+    if (g_tls_err_handle == h) g_tls_err_handle = nullptr;    // (the address may come back as another handle)
     { LOCK(h);
       (void)hipSetDevice(h->device);
       (void)hipStreamSynchronize(h->st);
@@ -138,7 +148,11 @@ extern "C" int gpca_destroy(gpca_handle* h) {
       if (h->ev_status) (void)hipEventDestroy(h->ev_status);
       if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
       free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
-      dfree(h->d_blk_rows); dfree(h->d_blk_cols); dfree(h->d_blk_out); dfree(h->d_blk_err); dfree(h->d_status); if (h->h_status) { (void)hipHostFree(h->h_status); h->h_status = nullptr; }
+      for (auto* ln : h->lanes_free) {       // (LOCK drained the pulls: every lane is back in the pool)
+          (void)hipStreamDestroy(ln->st); (void)hipEventDestroy(ln->dep); dfree(ln->d_rows); dfree(ln->d_cols); dfree(ln->d_out); dfree(ln->d_err); delete ln;
+      }
+      h->lanes_free.clear(); h->lanes_total = 0;
+      dfree(h->d_status); if (h->h_status) { (void)hipHostFree(h->h_status); h->h_status = nullptr; }
       if (!h->is_child) (void)hipStreamDestroy(h->st);      // (a compact child runs on its parent's stream)
     }
     delete h;
@@ -293,58 +307,112 @@ extern "C" double gpca_hwe_chi_squared_p_value(uint64_t n1h, uint64_t nhet, uint
 
 
 // ---- a2 ---------------------------------------------------------------------------------------------------
-extern "C" int64_t gpca_num_pca_snps(gpca_handle* h) { if (!h) return 0; LOCK(h); return h->have_stats ? h->n_pca : 0; }
-extern "C" int64_t gpca_num_qc_samples(gpca_handle* h) { if (!h) return 0; LOCK(h); return h->N; }
+extern "C" int64_t gpca_num_pca_snps(gpca_handle* h) { if (!h) return 0; LOCK_SHARED(h); return h->have_stats ? h->n_pca : 0; }
+extern "C" int64_t gpca_num_qc_samples(gpca_handle* h) { if (!h) return 0; LOCK_SHARED(h); return h->N; }
 extern "C" int gpca_get_pca_snp_rows(gpca_handle* h, int64_t* rows) {
     if (!h || !rows) return GPCA_ERR_BAD_ARG;
-    LOCK(h);
+    LOCK_SHARED(h);
     if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_get_pca_snp_rows: run gpca_snp_stats first");
     std::copy(h->pca_rows.begin(), h->pca_rows.end(), rows);
     return GPCA_OK;
 }
 
-// The reference's solver calls this once per strip from many rayon workers (prepare.rs:1838): the id lists, the output block
-// and the error word live in scratch that persists on the handle (grown on demand, never freed per call).
+// The reference's solver calls this once per strip from many rayon workers (prepare.rs:1838) and serves the calls from 1-16 actor
+// threads in parallel (main.rs:279-283).  Here a call holds the handle's lock only while it validates its ids and claims a lane; the
+// id lists, the output block and the error word live in the lane's persistent scratch, and the copies and the kernel run on the
+// lane's own stream with the lock released -- calls from different threads overlap (H2D of one, kernel of another, D2H of a third).
+static int lane_ensure(gpca_handle::PullLane* ln, int64_t ns, int64_t nj) {
+    auto grow = [](void** p, size_t& cap, size_t need, size_t elem) -> hipError_t {
+        if (cap >= need) return hipSuccess;
+        if (*p) { (void)hipFree(*p); *p = nullptr; cap = 0; }
+        const hipError_t e = hipMalloc(p, need * elem);
+        if (e == hipSuccess) cap = need;
+        return e;
+    };
+    if (grow((void**)&ln->d_rows, ln->cap_rows, (size_t)ns, 8) != hipSuccess) return GPCA_ERR_OOM;
+    if (grow((void**)&ln->d_cols, ln->cap_cols, (size_t)nj, 8) != hipSuccess) return GPCA_ERR_OOM;
+    if (grow((void**)&ln->d_out, ln->cap_out, (size_t)ns * (size_t)nj, 4) != hipSuccess) return GPCA_ERR_OOM;
+    if (!ln->d_err && hipMalloc((void**)&ln->d_err, 8) != hipSuccess) return GPCA_ERR_OOM;
+    return GPCA_OK;
+}
+
 extern "C" int gpca_standardize_block(gpca_handle* h, const int64_t* snp_ids, int64_t ns, const int64_t* sample_ids,
                                       int64_t nj, float* out) {
     if (!h) return GPCA_ERR_BAD_ARG;
-    LOCK(h);
-    if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_standardize_block: run gpca_snp_stats first");
-    if (h->sm.on) return fail(h, GPCA_ERR_STATE, "gpca_standardize_block: the pull API needs a resident matrix (this handle streams panels)");
-    if (ns < 0 || nj < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: negative block size");
-    if (ns == 0 || nj == 0) return GPCA_OK;  // prepare.rs:1848-1850: empty block, nothing to fill
-    if (!snp_ids || !sample_ids || !out) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: NULL pointer");
-    HIPCHK(hipSetDevice(h->device));
-    std::vector<int64_t> rows((size_t)ns);
-    for (int64_t a = 0; a < ns; ++a) {
-        if (snp_ids[a] < 0 || snp_ids[a] >= h->n_pca) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: PcaSnpId out of range");
-        rows[(size_t)a] = h->pca_rows[(size_t)snp_ids[a]];
+    std::vector<int64_t> rows;
+    gpca_handle::PullLane* ln = nullptr;
+    {
+        LOCK_SHARED(h);
+        if (!h->have_stats) return fail(h, GPCA_ERR_STATE, "gpca_standardize_block: run gpca_snp_stats first");
+        if (h->sm.on) return fail(h, GPCA_ERR_STATE, "gpca_standardize_block: the pull API needs a resident matrix (this handle streams panels)");
+        if (ns < 0 || nj < 0) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: negative block size");
+        if (ns == 0 || nj == 0) return GPCA_OK;  // prepare.rs:1848-1850: empty block, nothing to fill
+        if (!snp_ids || !sample_ids || !out) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: NULL pointer");
+        rows.resize((size_t)ns);
+        for (int64_t a = 0; a < ns; ++a) {
+            if (snp_ids[a] < 0 || snp_ids[a] >= h->n_pca) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: PcaSnpId out of range");
+            rows[(size_t)a] = h->pca_rows[(size_t)snp_ids[a]];
+        }
+        for (int64_t c = 0; c < nj; ++c)
+            if (sample_ids[c] < 0 || sample_ids[c] >= h->N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: QcSampleId out of range");
+        // claim a lane (a 17th concurrent caller waits for one to come back)
+        std::unique_lock<std::mutex> lk(h->pull_mu);
+        if (h->lanes_free.empty() && h->lanes_total < kMaxPullLanes) {
+            auto* fresh = new gpca_handle::PullLane();
+            if (hipStreamCreateWithFlags(&fresh->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&fresh->dep, hipEventDisableTiming) != hipSuccess) {
+                if (fresh->st) (void)hipStreamDestroy(fresh->st);
+                delete fresh;
+                return fail(h, GPCA_ERR_HIP, "gpca_standardize_block: stream creation failed");
+            }
+            h->lanes_free.push_back(fresh); ++h->lanes_total;
+        }
+        h->pull_cv.wait(lk, [&] { return !h->lanes_free.empty(); });
+        ln = h->lanes_free.back(); h->lanes_free.pop_back();
+        // statistics or an upload may still be running on the engine's stream (gpca_snp_stats without a fetch returns at once)
+        if (hipEventRecord(ln->dep, h->st) != hipSuccess || hipStreamWaitEvent(ln->st, ln->dep, 0) != hipSuccess) {
+            h->lanes_free.push_back(ln);
+            return fail(h, GPCA_ERR_HIP, "gpca_standardize_block: could not order the pull behind the engine's stream");
+        }
+        h->pulls_in_flight.fetch_add(1, std::memory_order_acq_rel);
     }
-    for (int64_t c = 0; c < nj; ++c)
-        if (sample_ids[c] < 0 || sample_ids[c] >= h->N) return fail(h, GPCA_ERR_BAD_ARG, "gpca_standardize_block: QcSampleId out of range");
-    CHK(ensure(h, h->d_blk_rows, h->cap_blk_rows, (size_t)ns));
-    CHK(ensure(h, h->d_blk_cols, h->cap_blk_cols, (size_t)nj));
-    CHK(ensure(h, h->d_blk_out, h->cap_blk_out, (size_t)ns * (size_t)nj));
-    if (!h->d_blk_err) HIPCHK(hipMalloc((void**)&h->d_blk_err, 8));
+    // ---- the handle's lock is released: the matrix and its statistics stay put until this pull has left (drain_pulls) ----
+    int rc = GPCA_OK;
+    std::string msg;
     unsigned long long err_idx = ~0ull;
-    HIPCHK(hipMemcpyAsync(h->d_blk_rows, rows.data(), (size_t)ns * 8, hipMemcpyHostToDevice, h->st));
-    HIPCHK(hipMemcpyAsync(h->d_blk_cols, sample_ids, (size_t)nj * 8, hipMemcpyHostToDevice, h->st));
-    HIPCHK(hipMemcpyAsync(h->d_blk_err, &err_idx, 8, hipMemcpyHostToDevice, h->st));
-    if (h->storage == GPCA_STORE_2BIT) launch_standardize_block_2bit(h->st, h->dG2, h->ld2, h->d_mu, h->d_sigma, h->d_blk_rows, ns, h->d_blk_cols, nj, h->d_blk_out, h->d_blk_err);
-    else launch_standardize_block(h->st, h->dG, h->ld8, h->d_mu, h->d_sigma, h->d_blk_rows, ns, h->d_blk_cols, nj, h->d_blk_out, h->d_blk_err);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&err_idx, h->d_blk_err, 8, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(hipMemcpyAsync(out, h->d_blk_out, (size_t)ns * (size_t)nj * 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(hipStreamSynchronize(h->st));
-    if (err_idx != ~0ull) {
-        const int64_t a = (int64_t)(err_idx / (unsigned long long)nj), c = (int64_t)(err_idx % (unsigned long long)nj);
-        char buf[400];  // wording of prepare.rs:1910-1911
-        snprintf(buf, sizeof buf,
-                 "Unexpected missing genotype (-127i8) in SnpBlockData for PCA SNP ID %lld (original BIM index %lld), "
-                 "requested sample index %lld. This should have been filtered by QC.",
-                 (long long)snp_ids[a], (long long)rows[(size_t)a], (long long)sample_ids[c]);
-        return fail(h, GPCA_ERR_MISSING_GENOTYPE, buf);
+    auto run = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = hipMemcpyAsync(ln->d_rows, rows.data(), (size_t)ns * 8, hipMemcpyHostToDevice, ln->st)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(ln->d_cols, sample_ids, (size_t)nj * 8, hipMemcpyHostToDevice, ln->st)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(ln->d_err, &err_idx, 8, hipMemcpyHostToDevice, ln->st)) != hipSuccess) return e;
+        if (h->storage == GPCA_STORE_2BIT) launch_standardize_block_2bit(ln->st, h->dG2, h->ld2, h->d_mu, h->d_sigma, ln->d_rows, ns, ln->d_cols, nj, ln->d_out, ln->d_err);
+        else launch_standardize_block(ln->st, h->dG, h->ld8, h->d_mu, h->d_sigma, ln->d_rows, ns, ln->d_cols, nj, ln->d_out, ln->d_err);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(&err_idx, ln->d_err, 8, hipMemcpyDeviceToHost, ln->st)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(out, ln->d_out, (size_t)ns * (size_t)nj * 4, hipMemcpyDeviceToHost, ln->st)) != hipSuccess) return e;
+        return hipStreamSynchronize(ln->st);
+    };
+    rc = lane_ensure(ln, ns, nj);
+    if (rc != GPCA_OK) msg = "gpca_standardize_block: out of device memory for the block";
+    else {
+        const hipError_t e = run();
+        if (e != hipSuccess) { rc = GPCA_ERR_HIP; msg = std::string("gpca_standardize_block: ") + hipGetErrorString(e); (void)hipStreamSynchronize(ln->st); }
+        else if (err_idx != ~0ull) {
+            const int64_t a = (int64_t)(err_idx / (unsigned long long)nj), c = (int64_t)(err_idx % (unsigned long long)nj);
+            char buf[400];  // wording of prepare.rs:1910-1911
+            snprintf(buf, sizeof buf,
+                     "Unexpected missing genotype (-127i8) in SnpBlockData for PCA SNP ID %lld (original BIM index %lld), "
+                     "requested sample index %lld. This should have been filtered by QC.",
+                     (long long)snp_ids[a], (long long)rows[(size_t)a], (long long)sample_ids[c]);
+            rc = GPCA_ERR_MISSING_GENOTYPE; msg = buf;
+        }
     }
+    {   // the lane goes back and the pull leaves BEFORE the handle's lock is asked for again (a caller that waits in drain_pulls holds it)
+        std::lock_guard<std::mutex> lk(h->pull_mu);
+        h->lanes_free.push_back(ln);
+        h->pulls_in_flight.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    h->pull_cv.notify_all();
+    if (rc != GPCA_OK) { LOCK_SHARED(h); return fail(h, rc, msg); }
     return GPCA_OK;
 }
 

@@ -183,9 +183,21 @@ struct gpca_handle {
     double* h_status = nullptr;      // pinned [32]: contribution | agreed histogram
     hipEvent_t ev_status = nullptr;  // after the agreed histogram has landed in h_status (agree_status_begin / _end)
     std::string status_own;          // this rank's error text when it contributed
-    // persistent scratch of the pull API (no allocation per call)
-    int64_t *d_blk_rows = nullptr, *d_blk_cols = nullptr; float* d_blk_out = nullptr; unsigned long long* d_blk_err = nullptr;
-    size_t cap_blk_rows = 0, cap_blk_cols = 0, cap_blk_out = 0;
+    // The pull API (gpca_standardize_block) is served concurrently, the way the reference's accessor is called from many workers at once
+    // (prepare.rs:1770-1779, 1838; 1-16 actor threads, main.rs:279-283): a call validates and claims a lane under the handle's lock,
+    // then runs its copies and its kernel on the lane's own stream WITHOUT the lock.  Every other entry point waits until no pull is
+    // in flight (LOCK -> drain_pulls), so the matrix and its statistics never change under a running pull.
+    struct PullLane {
+        hipStream_t st = nullptr;
+        hipEvent_t dep = nullptr;                                // recorded on the engine's stream when the lane is claimed: the pull starts after the work queued there
+        int64_t *d_rows = nullptr, *d_cols = nullptr; float* d_out = nullptr; unsigned long long* d_err = nullptr;
+        size_t cap_rows = 0, cap_cols = 0, cap_out = 0;          // persistent scratch (grown on demand, never freed per call)
+    };
+    std::mutex pull_mu;                    // lanes_free, lanes_total, pulls_in_flight
+    std::condition_variable pull_cv;
+    std::vector<PullLane*> lanes_free;
+    int lanes_total = 0;
+    std::atomic<int> pulls_in_flight{0};
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
     int nd = 4;           // digit planes of the exact path (gpca_config.digit_planes): 4 x base 128, or 3 x base 256 (packed storage)
@@ -223,7 +235,15 @@ struct gpca_handle {
 constexpr size_t kMaxTimingRecs = 32768;
 // every entry point: take the handle's lock and make its device the calling thread's current one (a host thread that drives
 // several handles on different GPUs, or that last touched another device, would otherwise launch on the wrong one)
-#define LOCK(h) std::lock_guard<std::recursive_mutex> lock_guard_(h->mu); (void)hipSetDevice(h->device)
+#define LOCK(h) std::lock_guard<std::recursive_mutex> lock_guard_(h->mu); (void)hipSetDevice(h->device); drain_pulls(h)
+// read-only getters and the first half of a pull: the lock without waiting for the pulls in flight
+#define LOCK_SHARED(h) std::lock_guard<std::recursive_mutex> lock_guard_(h->mu); (void)hipSetDevice(h->device)
+constexpr int kMaxPullLanes = 16;        // the reference serves its accessor from at most 16 actor threads (main.rs:279-283)
+inline void drain_pulls(gpca_handle* h) {
+    if (h->pulls_in_flight.load(std::memory_order_acquire) == 0) return;
+    std::unique_lock<std::mutex> lk(h->pull_mu);   // (no new pull can start: its first half needs the handle's lock, which the caller holds)
+    h->pull_cv.wait(lk, [&] { return h->pulls_in_flight.load(std::memory_order_acquire) == 0; });
+}
 
 extern thread_local std::string g_last_global_err;
 int fail(gpca_handle* h, int code, const std::string& msg);

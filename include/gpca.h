@@ -17,10 +17,14 @@
  * Threading: one handle = one GPU.  Every entry point takes the handle's (recursive) lock, so a handle may be shared
  * between host threads the way the reference shares its `Clone + Send + Sync` accessor between rayon workers
  * (prepare.rs:1770-1779, 1838): calls are serialised per handle, different handles run concurrently (one host thread may
- * drive handles on several GPUs: every entry point makes the handle's device the calling thread's current HIP device).  gpca_destroy
- * must not race with other calls on the same handle; gpca_last_error() returns the handle's last message (read it
- * before another thread's call on the same handle overwrites it).  Functions return GPCA_OK (0) or a negative
- * gpca_status.
+ * drive handles on several GPUs: every entry point makes the handle's device the calling thread's current HIP device).
+ * The pull API is the exception, as in the reference, whose accessor is served by 1-16 actor threads in parallel
+ * (main.rs:279-283): gpca_standardize_block holds the lock only while it checks its ids, then runs its copies and its
+ * kernel on one of up to 16 lanes (a stream and scratch of its own) -- calls from different threads overlap; every other
+ * entry point first waits until no pull is in flight, so the matrix and its statistics never change under one.  gpca_destroy
+ * must not race with other calls on the same handle; gpca_last_error() returns the calling thread's own last failure on
+ * the handle (or, for a thread that has not failed on it, the handle's last message).  Functions return GPCA_OK (0) or a
+ * negative gpca_status.
  *
  * Limits: k + oversample <= 64 sketch columns; GPCA_PREC_I8_EXACT holds up to 2^22 (4 194 304) samples per matrix (i32
  * accumulators; GPCA_PREC_F32_MFMA has no such bound); SNP rows per handle are bounded by device memory only (64M rows x 1 000

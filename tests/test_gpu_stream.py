@@ -603,17 +603,32 @@ def test_two_process_shards_through_libgpca(tmp_path, gpca, oracle, poison_rank)
 # ------------------------------------------------------------------------------------------------
 # boundary hardening
 # ------------------------------------------------------------------------------------------------
-def test_handle_shared_between_threads(gpca, oracle):
-    """The reference's accessor is Clone + Send + Sync and is called from rayon workers (prepare.rs:1770-1779, 1838):
-    eight threads pull blocks through ONE handle concurrently; every block is bit-exact."""
+@pytest.mark.parametrize("store,threads", [("int8", 8), ("2bit", 20)])
+def test_handle_shared_between_threads(gpca, oracle, store, threads):
+    """The reference's accessor is Clone + Send + Sync, is called from rayon workers and served by 1-16 actor threads in parallel
+    (prepare.rs:1770-1779, 1838; main.rs:279-283): many threads pull blocks through ONE handle concurrently -- each on a lane of
+    its own (stream + scratch; 20 threads: four of them wait for one of the 16 lanes) -- while another thread keeps calling the
+    entry points that take the whole handle (the same QC statistics again, a randomized PCA): those wait for the pulls in flight,
+    nothing deadlocks and every block is bit-exact."""
     M, N = 4000, 700
     G = oracle.synth_genotypes(M, N, 9, gpca.synth_thresholds(M, 3, seed=9, fst=0.1))
-    with gpca.GpcaEngine(**_modes("int8")) as e:
+    with gpca.GpcaEngine(**_modes(store)) as e:
         e.upload_genotypes_i8(G)
         st = e.snp_stats(gpca.QcConfig(0.0, 0.05, 1.0))
         rows = e.pca_snp_rows()
         acc = gpca.MicroarrayGenotypeAccessor(e)
         errs = []
+
+        def owner():
+            try:
+                for i in range(6):
+                    st2 = e.snp_stats(gpca.QcConfig(0.0, 0.05, 1.0))
+                    assert np.array_equal(st2["mu"], st["mu"]) and np.array_equal(st2["keep"], st["keep"])
+                    if i % 3 == 2:
+                        e.rsvd(4, 6, 1, seed=1)
+                        assert acc.num_pca_snps() == len(rows) and acc.num_qc_samples() == N
+            except BaseException as ex:  # noqa: BLE001
+                errs.append(ex)
 
         def worker(t):
             rng = np.random.default_rng(t)
@@ -626,9 +641,15 @@ def test_handle_shared_between_threads(gpca, oracle):
                     assert err is None and np.array_equal(out, ref)
             except BaseException as ex:  # noqa: BLE001
                 errs.append(ex)
-        ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)] + [threading.Thread(target=owner)]
         [t.start() for t in ts]; [t.join() for t in ts]
         assert not errs, errs[0]
+        # an error inside a concurrent pull reaches the thread that made the call, with the reference's wording
+        Gm = G.copy(); Gm[rows[3], 5] = -127
+        e.upload_genotypes_i8(Gm); e.set_standardization(st["mu"], st["sigma"], st["keep"])
+        with pytest.raises(gpca.GpcaError, match="Unexpected missing genotype") as err:
+            acc.get_standardized_snp_sample_block(np.array([3]), np.array([5]))
+        assert err.value.status == -5
 
 
 def test_no_device_memory_is_lost_across_handles_and_modes(gpca, oracle):
