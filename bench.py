@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+HBM_ACHIEVABLE_GBS = 6290.0    # MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79 %)" -- reported beside frac, never instead of it
 
 
 def cpu_baseline(N, k, oversample, q, seed, target_s=15.0):
@@ -175,6 +176,8 @@ def roofline_of(timings, precision, steps, storage="int8", planes=4):
                 "digit_planes": planes, "traffic": traffic, "hbm_GBs_algorithmic": gbs, "algorithmic_TFLOPs_equivalent": tflops, **common}
     if precision == "i8":   # exact-integer MFMA needs ~1/10 of the matrix-core time per byte: HBM-bound
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "frac_of_achievable": gbs / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
+                "achievable_peak_source": "MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy (79 % of the 8 TB/s spec)",
                 "traffic": traffic, "algorithmic_TFLOPs_equivalent": tflops, **common}
     return {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "hbm_GBs_algorithmic": gbs, **common}
@@ -197,7 +200,7 @@ def kernel_rooflines(timings, precision, storage):
             tops = 2.0 * 32 * 4 * (t["bytes"] / t["launches"] * 4) / (ms * 1e-3) / 1e12
             d.update(bound="mfma", achieved=tops, peak=5000.0, unit="TOP/s (int8, executed digit-plane MFMAs)", frac=tops / 5000.0)
         else:
-            d.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+            d.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, frac_of_achievable=gbs / HBM_ACHIEVABLE_GBS)
         out[name] = d
     return out
 
