@@ -48,13 +48,23 @@ template <typename F> static float time_ms(F f, int reps) {
     (void)hipEventRecord(a); for (int r = 0; r < reps; ++r) f(); (void)hipEventRecord(b); (void)hipEventSynchronize(b);
     float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / reps;
 }
-int main() {
+// usage: kbench_place [contig]   (contig: every second buffer is asked for with hipDeviceMallocContiguous -- physically contiguous,
+// the largest page fragments the driver can give -- to see whether the spread between buffers is a matter of fragments)
+int main(int argc, char** argv) {
+    const bool contig = argc > 1 && argv[1][0] == 'c';
     const int64_t M = 1000064, ld = 10496;
     const int64_t bytes = M * ld;
     const int NB = 10;
     std::vector<char*> buf(NB);
     int* out; CK(hipMalloc(&out, 4)); CK(hipMemset(out, 0, 4));
-    for (int b = 0; b < NB; ++b) { CK(hipMalloc(&buf[b], bytes)); CK(hipMemset(buf[b], 1, bytes)); }
+    for (int b = 0; b < NB; ++b) {
+        if (contig && (b & 1)) {
+            const hipError_t e = hipExtMallocWithFlags((void**)&buf[b], bytes, hipDeviceMallocContiguous);
+            printf("buffer %2d: hipDeviceMallocContiguous -> %s\n", b, hipGetErrorString(e));
+            if (e != hipSuccess) { (void)hipGetLastError(); CK(hipMalloc(&buf[b], bytes)); }
+        } else CK(hipMalloc(&buf[b], bytes));
+        CK(hipMemset(buf[b], 1, bytes));
+    }
     for (int pass = 0; pass < 2; ++pass)
         for (int b = 0; b < NB; ++b) {
             float t1 = time_ms([&] { hipLaunchKernelGGL((k_pieces<4>), dim3(256), dim3(256), 0, 0, (const char*)buf[b], M, ld, out); }, 5);
