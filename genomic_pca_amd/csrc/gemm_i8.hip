@@ -587,6 +587,7 @@ void launch_absmax_fold(hipStream_t st, const double* apart, int64_t P, double* 
 #endif                  // bit4 clock stamps (s_memtime / s_memrealtime per workgroup into g_kbench_stamp)
 #if GPCA_ABLATE & 16
 __device__ unsigned long long g_kbench_stamp[2 * 4096];
+__device__ unsigned long long g_kbench_abs[2 * 4096];     // s_memrealtime (100 MHz) at the start and at the end of every workgroup
 #endif
 // 16 samples (one 32-bit word of 2-bit codes) -> 16 int8 bytes:  per output dword 5 VALU ops (bfe, 2 x (lshl_or, and))
 __device__ __forceinline__ i32x4 spread16(unsigned w) {
@@ -758,7 +759,9 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
 #if GPCA_ABLATE & 16
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         g_kbench_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
-        g_kbench_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        const unsigned long long r1_ = __builtin_amdgcn_s_memrealtime();
+        g_kbench_stamp[2 * blockIdx.x + 1] = r1_ - st_r0;
+        g_kbench_abs[2 * blockIdx.x] = st_r0; g_kbench_abs[2 * blockIdx.x + 1] = r1_;
     }
 #endif
 }

@@ -75,6 +75,19 @@ int main(int argc, char** argv) {
         for (int b2 = 0; b2 < waves / 4; ++b2) ghz.push_back((double)st[2 * b2] / (double)st[2 * b2 + 1] * 0.1);
         std::sort(ghz.begin(), ghz.end());
         printf("  in-kernel clock: median %.3f GHz (min %.3f max %.3f), median wave cycles %.0f\n", ghz[ghz.size() / 2], ghz.front(), ghz.back(), (double)st[0]);
+        // where the launch's time goes: every workgroup's own span (100 MHz ticks) against first start -> last end
+        std::vector<unsigned long long> ab(2 * 4096);
+        CK(hipMemcpyFromSymbol(ab.data(), HIP_SYMBOL(gpca::g_kbench_abs), ab.size() * 8));
+        const int nb = waves / 4;
+        unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1x = 0;
+        std::vector<double> dur;
+        for (int b2 = 0; b2 < nb; ++b2) {
+            s0 = std::min(s0, ab[2 * b2]); s1 = std::max(s1, ab[2 * b2]); e0 = std::min(e0, ab[2 * b2 + 1]); e1x = std::max(e1x, ab[2 * b2 + 1]);
+            dur.push_back((double)(ab[2 * b2 + 1] - ab[2 * b2]) * 0.01);
+        }
+        std::sort(dur.begin(), dur.end());
+        printf("  workgroup spans: min %.1f median %.1f max %.1f us; first start -> last start %.1f us, first end -> last end %.1f us, first start -> last end %.1f us\n",
+               dur.front(), dur[dur.size() / 2], dur.back(), (double)(s1 - s0) * 0.01, (double)(e1x - e0) * 0.01, (double)(e1x - s0) * 0.01);
     }
 #endif
     return 0;
