@@ -148,7 +148,7 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
         // 1.145 / 1.142 ms padded vs 1.167 / 1.164), nothing on K2; GPCA_PITCH_PAD=0 restores ldg / 4
         if (!(getenv("GPCA_PITCH_PAD") && atoi(getenv("GPCA_PITCH_PAD")) == 0) && !((h->ld2 / 256) & 1)) h->ld2 += 256;
         if (!resident) return GPCA_OK;
-        HIPCHK(malloc_genotypes((void**)&h->dG2, (size_t)h->Mpad * (size_t)h->ld2));
+        HIPCHK(malloc_genotypes(h, (void**)&h->dG2, (size_t)h->Mpad * (size_t)h->ld2));
         if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG2 + (size_t)M * (size_t)h->ld2, 0, (size_t)(h->Mpad - M) * (size_t)h->ld2, h->st));
         return GPCA_OK;
     }
@@ -159,7 +159,7 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     h->ld8 = ((h->ldg / 256) & 1) ? h->ldg : h->ldg + 256;
     if (getenv("GPCA_PITCH_PAD") && atoi(getenv("GPCA_PITCH_PAD")) == 0) h->ld8 = h->ldg;
     if (!resident) return GPCA_OK;
-    HIPCHK(malloc_genotypes((void**)&h->dG, (size_t)h->Mpad * (size_t)h->ld8));
+    HIPCHK(malloc_genotypes(h, (void**)&h->dG, (size_t)h->Mpad * (size_t)h->ld8));
     if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG + (size_t)M * (size_t)h->ld8, 0, (size_t)(h->Mpad - M) * (size_t)h->ld8, h->st));
     return GPCA_OK;
 }
@@ -457,7 +457,7 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
     int rc = GPCA_OK;
     for (int i = 0; i < ring_slots && rc == GPCA_OK; ++i) {
         void* p = nullptr; hipEvent_t a = nullptr, b = nullptr;
-        hipError_t e = malloc_genotypes(&p, (size_t)panel_rows * (size_t)row_bytes);
+        hipError_t e = malloc_genotypes(h, &p, (size_t)panel_rows * (size_t)row_bytes);
         if (e == hipSuccess) { sm.slot.push_back(p); e = hipMemsetAsync(p, 0, (size_t)panel_rows * (size_t)row_bytes, sm.st_fill); }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
         if (e == hipSuccess) { sm.ev_filled.push_back(a); e = hipEventCreateWithFlags(&b, hipEventDisableTiming); }
@@ -509,7 +509,7 @@ extern "C" int gpca_stream_set_cache(gpca_handle* h, int64_t max_bytes, int32_t*
     int rc = GPCA_OK;
     while (sm.cache.size() < want) {
         void* p = nullptr; hipEvent_t e = nullptr;
-        hipError_t err = malloc_genotypes(&p, panel_bytes);
+        hipError_t err = malloc_genotypes(h, &p, panel_bytes);
         // zeroed like the ring slots: a HOST_I8 source writes N bytes per row, and the kernels' vector loads assume the bytes between
         // N and the row pitch are 0 (recycled device memory need not be)
         if (err == hipSuccess) err = hipMemsetAsync(p, 0, panel_bytes, sm.st_fill);

@@ -484,8 +484,8 @@ static int ensure_child(gpca_handle* h) {
     auto build = [&]() -> int {
         gpca_handle* hh = h;
         (void)hh;
-        if (packed) { HIPCHK(malloc_genotypes((void**)&c->dG2, (size_t)npad * (size_t)pitch)); }
-        else { HIPCHK(malloc_genotypes((void**)&c->dG, (size_t)npad * (size_t)pitch)); }
+        if (packed) { HIPCHK(malloc_genotypes(h, (void**)&c->dG2, (size_t)npad * (size_t)pitch)); }
+        else { HIPCHK(malloc_genotypes(h, (void**)&c->dG, (size_t)npad * (size_t)pitch)); }
         char* gdst = packed ? (char*)c->dG2 : (char*)c->dG;
         if (npad > n) HIPCHK(hipMemsetAsync(gdst + (size_t)n * pitch, 0, (size_t)(npad - n) * pitch, h->st));
         launch_gather_rows(h->st, packed ? (const void*)h->dG2 : (const void*)h->dG, pitch, h->d_pca_rows, n, gdst);
