@@ -93,7 +93,6 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     h->gtt_waves_target = std::max(4, env_int("GPCA_GTT_WAVES", h->gtt_waves_target));
     h->lds_planes = env_int("GPCA_LDS_PLANES", h->lds_planes);
     h->compact_ok = env_int("GPCA_COMPACT", h->compact_ok);
-    h->contig = env_int("GPCA_CONTIG", h->contig);
     h->narrow_ok = env_int("GPCA_NARROW", h->narrow_ok);
     h->gq_dma = env_int("GPCA_GQ_DMA", h->gq_dma);
     h->spin_sync = env_int("GPCA_SPIN_SYNC", h->spin_sync);

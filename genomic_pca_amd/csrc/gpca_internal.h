@@ -216,7 +216,6 @@ struct gpca_handle {
     bool is_child = false;           // (a child never compacts again and does not own its stream)
     const int64_t* d_row_ids = nullptr;   // child: original row of every row (the parent's d_pca_rows; not owned)
     int compact_ok = 1;              // GPCA_COMPACT=0: never compact
-    int contig = 0;                  // GPCA_CONTIG=1: genotype storage from hipExtMallocWithFlags(hipDeviceMallocContiguous)
 
     // comm
     int world = 1, rank = 0;
@@ -270,18 +269,12 @@ inline int ensure(gpca_handle* h, T*& p, size_t& cap, size_t need_elems) {
 template <typename T>
 inline void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
-// Genotype storage (resident matrix, panel ring, panel cache), optionally physically contiguous (GPCA_CONTIG=1, read per handle).
-// Ten 10.5 GB buffers from plain hipMalloc stream at 6.68 - 6.95 TB/s depending on where each landed; the same buffers asked for
-// with hipDeviceMallocContiguous all stream at 6.94 - 6.96 (scripts/kbench/kbench_place.hip contig,
-// profiles/r3_kbench_place_contig.log).  A request the driver cannot serve in one piece falls back to hipMalloc.
-inline hipError_t malloc_genotypes(const gpca_handle* h, void** p, size_t bytes) {
-    if (h->contig) {
-        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
-        (void)hipGetLastError();
-        *p = nullptr;
-    }
-    return hipMalloc(p, bytes);
-}
+// Genotype storage (resident matrix, panel ring, panel cache).  Plain hipMalloc on purpose: physically contiguous allocations
+// (hipExtMallocWithFlags + hipDeviceMallocContiguous) stream 0 - 4 % faster in a microbenchmark (profiles/r3_kbench_place_contig.log)
+// but a SECOND such allocation in one process, after the first was freed, gave kernels stale contents while copies read the right
+// bytes (profiles/r3_diag_contig.log: wrong mu / sigma / eigenvalues on the second engine of a process, never on the first) -- not
+// something this library can repair, so it does not use them.
+inline hipError_t malloc_genotypes(const gpca_handle*, void** p, size_t bytes) { return hipMalloc(p, bytes); }
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
