@@ -566,6 +566,7 @@ extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, 
     if (!dst || !src || dst == src) return fail(dst, GPCA_ERR_BAD_ARG, "gpca_copy_rows: two different handles are required");
     std::lock(dst->mu, src->mu);
     std::lock_guard<std::recursive_mutex> g1(dst->mu, std::adopt_lock), g2(src->mu, std::adopt_lock);
+    drain_pulls(dst);        // (pulls in flight on src only read it: they may go on)
     gpca_handle* h = dst;
     if (src->sm.on || (!src->dG && !src->dG2)) return fail(h, GPCA_ERR_STATE, "gpca_copy_rows: the source matrix is not resident");
     if (dst->device != src->device || dst->storage != src->storage) return fail(h, GPCA_ERR_BAD_ARG, "gpca_copy_rows: handles differ in device or storage mode");
