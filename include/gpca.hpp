@@ -159,7 +159,8 @@ struct LdBlockSpecification {                       // prepare.rs:1540-1543
 
 /* impl PcaReadyGenotypeAccessor for MicroarrayGenotypeAccessor (prepare.rs:1838-2030), backed by genotypes resident in
  * HBM (or streamed panels) instead of the IoService actor pool.  Copyable like the reference's `Clone` accessor: copies
- * share the engine, whose handle serialises concurrent callers (gpca.h, "Threading"). */
+ * share the engine: pulls from different threads run concurrently on the handle's lanes, every other call waits for them (gpca.h,
+ * "Threading"). */
 class MicroarrayGenotypeAccessor {
 public:
     explicit MicroarrayGenotypeAccessor(Engine& e) : eng_(&e) {}
