@@ -357,6 +357,9 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
 // ------------------------------------------------------------------------------------------------
 int64_t omega_num_parts(int64_t Mpad) { return (Mpad + 63) / 64; }
 
+// LP = LDS pitch of the staged tile: L + 1 (33 for a 32-column sketch -- half the LDS of the 64-column form, so four waves per SIMD
+// stay resident beside the f64 log / sincospi chains instead of two; 90 VGPRs would allow five).
+template <int LP>
 __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
                                                const float* __restrict__ r, const float* __restrict__ b,
                                                float* __restrict__ Tb, float* __restrict__ cpart, double* __restrict__ apart,
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
     //   * T' = r o Omega leaves as full rows, lane-contiguous (a lane writing its row 4 bytes at a time at a 128-byte
     //     stride cost 4.3x write amplification), and
     //   * the wave's partial of c = b^T Omega is a conflict-free column walk instead of 6 cross-lane steps per column.
-    __shared__ float zt[2][64][65];
+    __shared__ float zt[2][64][LP];
     __shared__ float rs[2][64], bs[2][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 2 + wv;
@@ -487,8 +490,10 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
 void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed, const float* r,
                   const float* b, float* Tb, float* cpart, double* apart, int blocked, const int64_t* row_ids) {
     const int64_t waves = omega_num_parts(Mpad);
-    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
-                       cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4, row_ids);
+    if (L == 32) hipLaunchKernelGGL(k_omega<33>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
+                                    cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4, row_ids);
+    else hipLaunchKernelGGL(k_omega<65>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
+                            cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4, row_ids);
 }
 // Exact-integer path: T' = r o Omega straight into digit planes Td ([L/32 halves][Mpad/32][kDigits][64][16 B]) against the analytic
 // column bound 6.67 * rmax; tscale / tinv [L] receive the scale (columns >= l: 0); cpart as above.  No f32 copy of T'.
@@ -496,8 +501,10 @@ void launch_omega_planes(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, 
                          const float* b, float* cpart, int8_t* Td, const float* rmax, double* tscale, double* tinv, int nd,
                          const int64_t* row_ids) {
     const int64_t waves = omega_num_parts(Mpad);
-    hipLaunchKernelGGL(k_omega, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
-                       cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);
+    if (L == 32) hipLaunchKernelGGL(k_omega<33>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
+                                    cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);
+    else hipLaunchKernelGGL(k_omega<65>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
+                            cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);
 }
 // dst row i <- src row ids[i] (rows of `pitch` bytes, a multiple of 16): the kept SNPs of a matrix gathered into one of their own
 __global__ __launch_bounds__(256) void k_gather_rows(const uint8_t* __restrict__ src, int64_t pitch, const int64_t* __restrict__ ids,
