@@ -24,7 +24,16 @@ def gpu_count() -> int:
         if gpu_present():
             import subprocess
             try:
-                out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+                # the HIP runtime itself (what libgpca.so links against), not torch: a cold `import torch` costs a fresh box a minute or two
+                code = ("import ctypes\n"
+                        "for n in ('libamdhip64.so.7', '/opt/rocm/lib/libamdhip64.so', 'libamdhip64.so'):\n"
+                        "    try:\n"
+                        "        l = ctypes.CDLL(n); break\n"
+                        "    except OSError:\n"
+                        "        l = None\n"
+                        "c = ctypes.c_int(0)\n"
+                        "print(c.value if (l is None or l.hipGetDeviceCount(ctypes.byref(c)) != 0) else c.value)\n")
+                out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
                 _GPU_COUNT = int(out.stdout.strip().splitlines()[-1])
             except Exception:
                 _GPU_COUNT = 1

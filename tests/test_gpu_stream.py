@@ -549,15 +549,23 @@ def test_sharded_and_streamed(gpca, oracle, store, fused):
     assert [o[0] for o in bad] == ["err", "err"] and [o[1] for o in bad] == [-5, -5]
 
 
-def _proc_worker(rank, world, port, M, N, k, seed, out_dir, poison_rank):
+def _proc_worker(rank, world, conn, M, N, k, seed, out_dir, poison_rank):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import torch.distributed as dist
     import genomic_pca_amd as g
     from genomic_pca_amd import _lib
-    from genomic_pca_amd.distributed import shard_rows, torch_allreduce_hook
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genomic_pca_amd.distributed import shard_rows
+
+    def allreduce(buf):
+        # two ranks, one duplex pipe: rank 0 sends first, rank 1 receives first (a sketch is larger than the pipe's buffer);
+        # a0 + a1 on both sides, so the replicated results are the same bits
+        mine = buf.tobytes()
+        if rank == 0:
+            conn.send_bytes(mine); other = np.frombuffer(conn.recv_bytes(), buf.dtype)
+            buf += other
+        else:
+            other = np.frombuffer(conn.recv_bytes(), buf.dtype); conn.send_bytes(mine)
+            buf[:] = other + buf
     a, b_ = shard_rows(M, world, rank)
     th = g.synth_thresholds(b_ - a, 8, seed=seed, fst=0.3, snp_offset=a)
     with g.GpcaEngine(device=0, precision=_lib.PREC_I8_EXACT) as e:
@@ -565,25 +573,32 @@ def _proc_worker(rank, world, port, M, N, k, seed, out_dir, poison_rank):
         if rank == poison_rank:
             G = e.download_genotypes_i8(); G[11, 3] = -127; e.upload_genotypes_i8(G)
         e.snp_stats(g.QcConfig(0.5, 0.0, 1.0))
-        e.set_allreduce_hook(torch_allreduce_hook(), world, rank, a)
+        e.set_allreduce_hook(allreduce, world, rank, a)
         assert e.comm_count_ranks() == world          # a 1.0 per rank through the same transport as the sketch
         try:
             e.rsvd(k, 10, 2, seed=seed)
             np.savez(os.path.join(out_dir, f"rank{rank}.npz"), status=0, ev=e.eigenvalues(), sc=e.scores(f64=True), ld=e.loadings())
         except g.GpcaError as err:
             np.savez(os.path.join(out_dir, f"rank{rank}.npz"), status=err.status)
-    dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("poison_rank", [-1, 1])
 def test_two_process_shards_through_libgpca(tmp_path, gpca, oracle, poison_rank):
-    """Two PROCESSES, each driving libgpca.so on its row shard (both on GPU 0), exchanging through gloo via
-    gpca_set_allreduce_hook: equals the unsharded engine; with one poisoned shard both processes return -5."""
-    import torch.multiprocessing as mp
+    """Two PROCESSES, each driving libgpca.so on its row shard (both on GPU 0), exchanging through a pipe via
+    gpca_set_allreduce_hook (no torch in the children: the host transport is the caller's business; the gloo transport is
+    tests/test_dist_gloo.py's subject): equals the unsharded engine; with one poisoned shard both processes return -5."""
+    import multiprocessing as mp
     M, N, k, seed, world = 6000, 512, 6, 23, 2
-    port = 29600 + (os.getpid() % 2000)
-    mp.spawn(_proc_worker, args=(world, port, M, N, k, seed, str(tmp_path), poison_rank), nprocs=world, join=True)
+    ctx = mp.get_context("spawn")
+    c0, c1 = ctx.Pipe(duplex=True)
+    procs = [ctx.Process(target=_proc_worker, args=(r, world, c, M, N, k, seed, str(tmp_path), poison_rank)) for r, c in ((0, c0), (1, c1))]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert [p.exitcode for p in procs] == [0, 0]
     z = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(world)]
     if poison_rank >= 0:
         assert int(z[0]["status"]) == -5 and int(z[1]["status"]) == -5
