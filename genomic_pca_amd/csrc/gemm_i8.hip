@@ -1316,9 +1316,6 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
     const float sj = sv[c];
     const double qs = qscale[c];
     int64_t u = u0;
-    // short_rounds = 2: every second workgroup takes its short round FIRST, so that the round boundaries (ring drained, epilogue,
-    // the next prologue's latency: no loads in flight for some microseconds) of neighbouring workgroups do not fall together
-    bool head_short = S == 6 && short_rounds == 2 && (blockIdx.x & 1) && ((u1 - u0) & 15) && (u1 - u0) > 16;
     while (u < u1) {
         const int64_t rem = u1 - u;
         const bool shorter = S == 6 && short_rounds;
@@ -1326,8 +1323,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
             // a short last round (1..15 units) is split evenly -- (3,3,2,2) rather than (4,4,2,0) -- and every wave sweeps the
             // samples with as many tiles as it has units (6-slot ring; a wave without a unit rides along for the planes and the
             // barriers)
-            const int64_t take = head_short ? (rem & 15) : (rem < 16 ? rem : 16);
-            head_short = false;
+            const int64_t take = rem < 16 ? rem : 16;
             const int64_t base = take >> 2, extra = take & 3;
             const int64_t mine = u + wv * base + (wv < extra ? wv : extra);
             const int nv = (int)(base + (wv < extra ? 1 : 0));
