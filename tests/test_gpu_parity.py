@@ -478,7 +478,8 @@ def _full_size_case(gpca, oracle, prec, store):
     M, N, k, seed = 1_000_000, 10_000, 20, 1
     th = gpca.synth_thresholds(M, 3, seed=seed)
     with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA,
-                         storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8) as e:
+                         storage=_lib.STORE_2BIT if store.startswith("2bit") else _lib.STORE_INT8,
+                         digit_planes=4 if store == "2bit4" else 0) as e:      # "2bit4": four digit planes on 2-bit rows (28-bit, as on int8 rows)
         e.synth_genotypes(M, N, seed, th)
         st = e.snp_stats(gpca.QcConfig.none())
         counts, _ = e.snp_qc_detail()
@@ -526,7 +527,7 @@ def _full_size_case(gpca, oracle, prec, store):
     return _FULL[(prec, store)]
 
 
-@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("f32", "int8"), ("f32", "2bit")])
+@pytest.mark.parametrize("prec,store", [("i8", "int8"), ("i8", "2bit"), ("i8", "2bit4"), ("f32", "int8"), ("f32", "2bit")])
 def test_full_size_properties(gpca, oracle, prec, store):
     """BASELINE.json configs[1] at full size on EVERY GEMM path, named explicitly: ("i8", "int8") is the headline path of
     bench.py (k_gq_d / k_gtt_d, LDS-DMA), ("i8", "2bit") the packed kernels (k_gq_2bit / k_gtt_p), ("f32", "int8") the
@@ -538,7 +539,9 @@ def test_full_size_properties(gpca, oracle, prec, store):
     ev, sc2, ld2 = _full_size_case(gpca, oracle, prec, store)
     ev0, sc0, ld0 = _full_size_case(gpca, oracle, "i8", "int8")
     if (prec, store) != ("i8", "int8"):
-        tol = 1e-6 if prec == "i8" else 1e-5      # (i8 on 2-bit rows: three digit planes by default, a 24-bit fixed point per column)
+        # i8 on 2-bit rows: three digit planes by default (a 24-bit fixed point per column): 1e-6; with four planes the packed
+        # kernels multiply the same integers as the int8-resident ones: 1e-8 (only the f32 partials of c may be grouped differently)
+        tol = 1e-8 if store == "2bit4" else (1e-6 if prec == "i8" else 1e-5)
         assert np.max(np.abs(ev[:2] - ev0[:2]) / ev0[:2]) < tol
         assert oracle.max_abs_dpc(sc2, sc0) < tol and oracle.max_abs_dpc(ld2, ld0) < 10 * tol
     if (prec, store) == ("f32", "2bit"):      # same f32 FMA chains on the decoded codes: the same bits
