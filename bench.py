@@ -8,8 +8,10 @@ N = 1  : configs[1] = synthetic 1M SNPs x 10k samples int8, k = 20, fixed seed, 
 N > 1  : SNP-row shards, one rank per GPU (torch.distributed.run), weak scaling: every rank holds
          --snps rows; the N x l sketch is all-reduced with RCCL inside libgpca.so (f64).
 
-One JSON line on rank 0.  `value` is the default (fastest parity-green) path: exact-integer GEMMs, HBM-bound;
-`f32_mfma_path` is the same job on v_mfma_f32_32x32x2_f32 (north_star's MFMA-fp32 roofline).  `roofline` is for the
+One JSON line on rank 0.  `value` is the configuration BASELINE.json names -- int8 genotypes resident in HBM -- on the engine's default
+GEMM path for them: exact-integer GEMMs, HBM-bound.  The same job with the genotypes resident as 2-bit codes (what both command lines
+choose for >= 1 024 samples: less HBM, faster kernels) is `packed_2bit_residency`; `f32_mfma_path` is the same job on
+v_mfma_f32_32x32x2_f32 (north_star's MFMA-fp32 roofline).  `roofline` is for the
 dominant kernel, from HIP events recorded on the engine's own stream inside the timed region; `parity` is
 max|dPC| against the oracle on a small seeded case; `cpu_baseline` is the oracle's f32 restatement ("port")
 timed on this box's host cores on a bounded sample (N = 1 only).
