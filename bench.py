@@ -5,8 +5,10 @@ metric : SNPs x samples / sec through the randomized PCA (gpca_rsvd) at k = 20  
 step   : one gpca_rsvd over the resident int8 genotype matrix (sketch + 2 power iterations + projection +
          small SVD + scores + loadings = 4 passes over G, 12*l flop per genotype -- SURVEY.md 8d)
 N = 1  : configs[1] = synthetic 1M SNPs x 10k samples int8, k = 20, fixed seed, resident in HBM
-N > 1  : SNP-row shards, one rank per GPU (torch.distributed.run), weak scaling: every rank holds
-         --snps rows; the N x l sketch is all-reduced with RCCL inside libgpca.so (f64).
+N > 1  : SNP-row shards, one rank per GPU, weak scaling: every rank holds configs[3]'s per-GPU shard (1.25M SNPs x 100k samples int8,
+         125 GB; 8 ranks = configs[3] itself, 10M x 100k); the N x l sketch is all-reduced with RCCL inside libgpca.so (f64).
+         `python bench.py --gpus N` starts its own N ranks (the parent touches no GPU); under torch.distributed.run the ranks are
+         taken as given.  No torch in either case: genomic_pca_amd/launch.py carries the unique id, the barriers and the max.
 
 One JSON line on rank 0.  `value` is the configuration BASELINE.json names -- int8 genotypes resident in HBM -- on the engine's default
 GEMM path for them: exact-integer GEMMs, HBM-bound.  The same job with the genotypes resident as 2-bit codes (what both command lines
@@ -29,7 +31,12 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
-HBM_ACHIEVABLE_GBS = 6290.0    # MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79 %)" -- reported beside frac, never instead of it
+# What this part's memory system delivers to a read-only nt stream shaped like K1's LDS-DMA fill (8 rows x 128 B per wave instruction):
+# 6.94-6.96 TB/s on the best-placed of ten 10.5 GB buffers (profiles/r3_kbench_place_contig.log, scripts/kbench/kbench_place.hip).  A
+# measured ceiling for the read-bound kernels, printed beside `frac` (which is always against the 8 TB/s spec), never instead of it.
+HBM_STREAM_CEILING_GBS = 6950.0
+HBM_STREAM_CEILING_SOURCE = ("profiles/r3_kbench_place_contig.log: read-only nt stream with K1's fill shape, best-placed 10.5 GB buffer, "
+                             "6.94-6.96 TB/s (scripts/kbench/kbench_place.hip)")
 
 
 def cpu_baseline(N, k, oversample, q, seed, target_s=15.0):
@@ -99,7 +106,7 @@ def parity_check(g, precision, seed):
                 "tolerance": 1e-4}
 
 
-def timed_run(eng, a, k, barrier, dist, torch):
+def timed_run(eng, a, k, barrier, rdzv):
     for _ in range(a.warmup):
         eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
     eng.enable_timings(True)       # HIP events on the engine's own stream (off by default in the library)
@@ -111,17 +118,21 @@ def timed_run(eng, a, k, barrier, dist, torch):
     barrier()
     dt = time.perf_counter() - t0
     timings = eng.timings()
-    if dist is not None:
-        mine = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
-        dist.all_gather(every, mine)
-        per_rank = [float(t.item()) for t in every]
-        dt = max(per_rank)                         # the contract's max over ranks
+    if rdzv is not None:
         ar = timings.get("allreduce")
-        timings["_ranks"] = {"per_rank_ms_per_step_min": min(per_rank) / a.steps * 1e3, "per_rank_ms_per_step_max": max(per_rank) / a.steps * 1e3,
+        mine = {"dt": dt, "allreduce_ms_per_step": (ar["total_ms"] / a.steps) if ar else None,
+                "gemm_ms_per_step": sum(t["total_ms"] for n_, t in timings.items() if n_.startswith("gemm")) / a.steps}
+        every = rdzv.allgather(mine)               # small host objects through the launcher's hub (genomic_pca_amd/launch.py)
+        per_rank = [e_["dt"] for e_ in every]
+        dt = max(per_rank)                         # the contract's max over ranks
+        timings["_ranks"] = {"per_rank_ms_per_step": [t / a.steps * 1e3 for t in per_rank],
+                             "per_rank_ms_per_step_min": min(per_rank) / a.steps * 1e3, "per_rank_ms_per_step_max": max(per_rank) / a.steps * 1e3,
+                             "per_rank_gemm_ms_per_step": [e_["gemm_ms_per_step"] for e_ in every],
+                             "per_rank_allreduce_ms_per_step": [e_["allreduce_ms_per_step"] for e_ in every],
                              "allreduce_ms_per_step_rank0": (ar["total_ms"] / a.steps) if ar else None,
                              "allreduce_launches_per_step": (ar["launches"] / a.steps) if ar else None,
-                             "allreduce_bytes_per_step": (ar["bytes"] / a.steps) if ar else None}
+                             "allreduce_bytes_per_step": (ar["bytes"] / a.steps) if ar else None,
+                             "note": "allreduce_ms spans include the wait for the slowest rank to arrive at the exchange"}
     return dt, timings
 
 
@@ -178,8 +189,8 @@ def roofline_of(timings, precision, steps, storage="int8", planes=4):
                 "digit_planes": planes, "traffic": traffic, "hbm_GBs_algorithmic": gbs, "algorithmic_TFLOPs_equivalent": tflops, **common}
     if precision == "i8":   # exact-integer MFMA needs ~1/10 of the matrix-core time per byte: HBM-bound
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "frac_of_achievable": gbs / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
-                "achievable_peak_source": "MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy (79 % of the 8 TB/s spec)",
+                "frac_of_measured_stream_ceiling": gbs / HBM_STREAM_CEILING_GBS, "measured_stream_ceiling": HBM_STREAM_CEILING_GBS,
+                "measured_stream_ceiling_source": HBM_STREAM_CEILING_SOURCE,
                 "traffic": traffic, "algorithmic_TFLOPs_equivalent": tflops, **common}
     return {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "hbm_GBs_algorithmic": gbs, **common}
@@ -202,7 +213,7 @@ def kernel_rooflines(timings, precision, storage):
             tops = 2.0 * 32 * 4 * (t["bytes"] / t["launches"] * 4) / (ms * 1e-3) / 1e12
             d.update(bound="mfma", achieved=tops, peak=5000.0, unit="TOP/s (int8, executed digit-plane MFMAs)", frac=tops / 5000.0)
         else:
-            d.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, frac_of_achievable=gbs / HBM_ACHIEVABLE_GBS)
+            d.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, frac_of_measured_stream_ceiling=gbs / HBM_STREAM_CEILING_GBS)
         out[name] = d
     return out
 
@@ -286,7 +297,7 @@ def extra_config2_line(g, a, device):
                 "top_eigenvalues": [float(x) for x in e.eigenvalues()[:3]]}
 
 
-def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn=None, steps=None, warmup=None, cache_gb=0.0):
+def streamed_run(g, a, M, N, k, storage, device, snp_offset, rdzv, uid_fn=None, steps=None, warmup=None, cache_gb=0.0):
     """One out-of-core job: stats sweep + `steps` timed gpca_rsvd calls over panels that are regenerated on every sweep."""
     steps = a.steps if steps is None else steps
     warmup = a.warmup if warmup is None else warmup
@@ -304,10 +315,9 @@ def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn
     t_stats = time.perf_counter() - t0
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        eng.synchronize()
+        eng.synchronize()              # = hipStreamSynchronize on the engine's streams: the only GPU work of this process
+        if rdzv is not None:
+            rdzv.barrier()
     for _ in range(warmup):
         eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
     eng.enable_timings(True); eng.reset_timings()
@@ -317,10 +327,8 @@ def streamed_run(g, a, M, N, k, storage, device, snp_offset, dist, torch, uid_fn
         eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if rdzv is not None:
+        dt = rdzv.max(dt)
     tim = eng.timings()
     ev = eng.eigenvalues()
     eng.close()
@@ -347,16 +355,15 @@ def streamed_summary(tim, steps, M, N, l, storage):
             "note": "fills run one panel ahead on a second stream; a sweep's span includes any wait for the generator"}
 
 
-def streamed_main(a, g, rank, world, local_rank, dist, torch):
+def streamed_main(a, g, rank, world, local_rank, rdzv):
     M_local, N, k = a.snps, a.samples, a.components
     l = k + a.oversample
     snp_offset = rank * M_local
     uid_fn = None
-    if dist is not None:
+    if rdzv is not None:
         def uid_fn(eng):
-            uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
-            eng.comm_init(world, rank, uid, snp_offset)
-    dt, tim, ev, t_stats = streamed_run(g, a, M_local, N, k, a.storage, local_rank, snp_offset, dist, torch, uid_fn, cache_gb=a.cache_gb)
+            connect(g, a, eng, rdzv, rank, world, snp_offset)
+    dt, tim, ev, t_stats = streamed_run(g, a, M_local, N, k, a.storage, local_rank, snp_offset, rdzv, uid_fn, cache_gb=a.cache_gb)
     n_cached = tim.pop("_panels_cached")
     if rank == 0:
         M_total = M_local * world
@@ -384,9 +391,29 @@ def streamed_main(a, g, rank, world, local_rank, dist, torch):
                                     "the resident bench line"},
                "streaming": ssum, "snp_stats_s": t_stats, "top_eigenvalues": [float(x) for x in ev[:3]], "cpu_baseline": None}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
+
+
+def workload_name(world, M_local, M_total, N, k, l, a):
+    tail = f"k={k}, l={l}, q={a.power_iters}, seed={a.rfit_seed}, resident in HBM"
+    if world == 1:
+        return f"synthetic {M_total} SNPs x {N} samples int8 genotypes (3 populations, F_ST 0.05), {tail}"
+    what = ("BASELINE.json configs[3]: " if (M_total, N) == (10_000_000, 100_000) else
+            "BASELINE.json configs[3]'s per-GPU shard (1.25M x 100k) on every rank, weak scaling: " if (M_local, N) == (1_250_000, 100_000) else "")
+    return (f"{what}synthetic {M_total} SNPs x {N} samples int8 genotypes (3 populations, Hardy-Weinberg proportions, device generator), SNP rows "
+            f"sharded {M_local} per GPU over {world} GPUs, the N x l sketch and one l x l Gram all-reduced per call, {tail}")
+
+
+def connect(g, a, eng, rdzv, rank, world, snp_offset):
+    """Join this rank's engine to the sharded matrix: RCCL inside libgpca.so (rank 0 draws the unique id, the launcher's hub hands its
+    128 bytes round), or -- `--exchange host`, the rehearsal for boxes with fewer GPUs than ranks -- the host-staged hook over the hub."""
+    if a.exchange == "host":
+        eng.set_allreduce_hook(rdzv.allreduce_hook(), world, rank, snp_offset)
+    else:
+        uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank, rdzv=rdzv)
+        eng.comm_init(world, rank, uid, snp_offset)
 
 
 def main():
@@ -394,8 +421,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--snps", type=int, default=1_000_000, help="SNP rows per GPU")
-    ap.add_argument("--samples", type=int, default=10_000)
+    ap.add_argument("--snps", type=int, default=None, help="SNP rows per GPU (default: 1 000 000 on one GPU = configs[1]; 1 250 000 per rank on "
+                                                           "several = configs[3]'s per-GPU shard)")
+    ap.add_argument("--samples", type=int, default=None, help="default: 10 000 on one GPU, 100 000 per rank on several")
     ap.add_argument("--components", "-k", type=int, default=20)
     ap.add_argument("--oversample", type=int, default=10)
     ap.add_argument("--power-iters", type=int, default=2)
@@ -422,29 +450,42 @@ def main():
     ap.add_argument("--cache-gb", type=float, default=-1.0,
                     help="--streamed: GiB of spare HBM that keep the leading panels resident (gpca_stream_set_cache); -1 = what is free, 0 = none")
     ap.add_argument("--unfused", action="store_true", help="--streamed: 6 passes per call (bit-identical to the resident engine) instead of 4")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
+                    help="N > 1: rccl = ncclAllReduce on the engine's stream inside libgpca.so (the product path); host = the host-staged hook over the "
+                         "launcher's hub, a rehearsal of everything but RCCL for boxes with fewer GPUs than ranks")
+    ap.add_argument("--one-device", action="store_true", help="N > 1 rehearsal: every rank on device 0 (needs --exchange host: RCCL refuses two ranks on one GPU)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: this process becomes the parent of N ranks.  It makes no GPU call and never re-execs; it
+        # hosts the rendezvous hub, starts this same command once per rank (RANK / LOCAL_RANK / WORLD_SIZE in the environment -- the
+        # variables torch.distributed.run would set) and leaves with a non-zero code if any rank does.
+        from genomic_pca_amd import launch
+        codes = launch.run_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                 local_ranks=[0] * a.gpus if a.one_device else None)
+        if any(codes):
+            print(f"bench.py: rank exit codes {codes}", file=sys.stderr, flush=True)
+        sys.exit(launch.exit_code(codes))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and a.gpus > 1:
-        sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-    # One GPU: no second GPU runtime in the process -- libgpca.so is torch-free and so is this harness.  torch is imported only
-    # under torch.distributed.run, where it carries the rendezvous and the max-over-ranks of the timing.
-    dist = torch = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run (also with one rank: same code path)
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    # (after torch on purpose: torch loads its own copy of the HIP runtime by absolute path; libgpca.so, loaded afterwards, binds to
-    #  that copy through its SONAME and the process has ONE runtime -- the other order gives two, and the second to initialise
-    #  sees no device)
+    local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1):
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    # No torch anywhere in this harness: libgpca.so carries its own RCCL exchange, and what the host side of a multi-rank run needs (the
+    # unique id handed round, a barrier on both sides of the timed region, the max over ranks) goes through genomic_pca_amd/launch.py's hub
+    # -- also when torch.distributed.run started the ranks (rank 0 then hosts the hub).  One HIP runtime per process, whatever the launcher.
     import genomic_pca_amd as g
+    from genomic_pca_amd import launch
+    rdzv = launch.from_env()
+    if a.one_device and a.exchange != "host" and world > 1:
+        sys.exit("bench.py: --one-device needs --exchange host (RCCL refuses two ranks on one GPU)")
+    if a.snps is None:
+        a.snps = 1_000_000 if world == 1 else 1_250_000
+    if a.samples is None:
+        a.samples = 10_000 if world == 1 else 100_000
 
     if a.streamed:
-        return streamed_main(a, g, rank, world, local_rank, dist, torch)
+        return streamed_main(a, g, rank, world, local_rank, rdzv)
     M_local, N, k = a.snps, a.samples, a.components
     global DEFAULT_SHAPE
     DEFAULT_SHAPE = (M_local, N, k) == (1_000_000, 10_000, 20)
@@ -458,13 +499,11 @@ def main():
     engines = []
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
         for e_ in engines:          # = hipStreamSynchronize on the engine's streams (the only GPU work of this process)
             e_.synchronize()
+        if rdzv is not None:
+            rdzv.barrier()
 
-    uid = None
     results = {}
     # the extra measurements (f32-MFMA path, 2-bit residency) are single-GPU information: multi-rank runs time the headline only
     extras = not a.no_second_path and world == 1
@@ -472,32 +511,53 @@ def main():
     if a.precision == "i8" and a.storage == "int8" and extras:
         order.append("i8_2bit")
         order.append("i8_2bit_4p")
-    th = g.synth_thresholds(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
+    # one GPU: the Philox generator the oracle restates (gpca_synth_genotypes); several: the fast device generator (one 16-bit uniform per
+    # genotype, SplitMix64 in counter mode), which fills a 125 GB shard in a fraction of a second -- both draw row i by its GLOBAL index
+    big = world > 1 or M_local * N > 4 * 10**10
+    th = (g.synth_thresholds16 if big else g.synth_thresholds)(M_local, 3, seed=a.rfit_seed, snp_offset=snp_offset)
     t_stats = None
+    solo = None
     head_rank_info = None
     extra_errors = {}
 
     def one_path(prec):
-        nonlocal t_stats, head_rank_info, uid
+        nonlocal t_stats, head_rank_info, solo
         packed = prec in ("i8_2bit", "i8_2bit_4p")
         store = g._lib.STORE_2BIT if ((a.storage == "2bit" and prec == a.precision) or packed) else g._lib.STORE_INT8
         planes = 4 if prec == "i8_2bit_4p" else (a.digit_planes if (prec == "i8" and store == g._lib.STORE_2BIT) else 0)
         eng = g.GpcaEngine(device=local_rank, precision=PREC["i8" if packed else prec], storage=store, digit_planes=planes)
         try:
             engines[:] = [eng]
-            eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
+            if big:
+                eng.load_from_source(g.PanelSource.synth16(th, a.rfit_seed, snp_offset=snp_offset), M_local, N)
+            else:
+                eng.synth_genotypes(M_local, N, a.rfit_seed, th, snp_offset=snp_offset)
             t0 = time.perf_counter()
             eng.snp_stats(g.QcConfig.none(), fetch=False)
             if t_stats is None:
                 t_stats = time.perf_counter() - t0
-            if dist is not None:
-                uid = g.distributed.broadcast_unique_id(g.GpcaEngine, rank)
-                eng.comm_init(world, rank, uid, snp_offset)
-            ranks_seen = eng.comm_count_ranks() if dist is not None else 1   # a 1.0 per rank through libgpca's own RCCL communicator
-            dt, timings = timed_run(eng, a, k, barrier, dist, torch)
+            if rdzv is not None:
+                # this rank's shard as a matrix of its own first (no exchange, a few calls): what the same GPU does without peers, measured
+                # in the same process minutes apart -- the weak-scaling reference of this very run
+                eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+                eng.synchronize(); rdzv.barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+                eng.synchronize()
+                solo = rdzv.allgather((time.perf_counter() - t0) / 3)
+                connect(g, a, eng, rdzv, rank, world, snp_offset)
+            ranks_seen = eng.comm_count_ranks() if rdzv is not None else 1   # a 1.0 per rank through libgpca's own communicator (or the hook)
+            dt, timings = timed_run(eng, a, k, barrier, rdzv)
             rank_info = timings.pop("_ranks", None)
             if rank_info is not None:
-                rank_info["ranks_seen_by_rccl"] = ranks_seen
+                rank_info["ranks_seen_by_rccl" if a.exchange == "rccl" else "ranks_seen_by_the_host_hook"] = ranks_seen
+                rank_info["exchange"] = ("ncclAllReduce (RCCL) on the engine's stream inside libgpca.so" if a.exchange == "rccl" else
+                                         "host-staged hook over the launcher's hub (rehearsal: not the product's transport)")
+                rank_info["same_shard_without_exchange_ms_per_step_per_rank"] = [t * 1e3 for t in solo] if solo else None
+                rank_info["exchange_volume_per_step"] = (f"{a.power_iters + 1} x {N} x {32 if l <= 32 else 64} f64 (sketch) + one "
+                                                         f"{32 if l <= 32 else 64}^2 + 16 f64 (Gram + status) + 16 f64 (status), in-place all-reduce")
+                rank_info["launcher"] = "torch.distributed.run (ranks given)" if "GPCA_RDZV" not in os.environ else "bench.py's own (genomic_pca_amd/launch.py)"
             results[prec] = (dt, timings, eng.eigenvalues())
             if prec == a.precision:
                 head_rank_info = rank_info
@@ -526,8 +586,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"synthetic {M_total} SNPs x {N} samples int8 genotypes (3 populations, F_ST 0.05), "
-                                   f"k={k}, l={l}, q={a.power_iters}, seed={a.rfit_seed}, resident in HBM",
+            "config": {"workload": workload_name(world, M_local, M_total, N, k, l, a),
                        "snps_per_gpu": M_local, "samples": N, "k": k, "oversample": a.oversample,
                        "power_iters": a.power_iters, "parallelism": f"snp-row-shards x{world}", "gemm_path": a.precision,
                        "residency": a.storage},
@@ -535,6 +594,14 @@ def main():
             "snp_stats_s": t_stats,
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
+        # SURVEY.md 8(d) counts a call as 4 reads of the matrix (sketch, two fused power iterations, projection) = 4 B per int8 genotype; the
+        # resident engine makes 6 sweeps (K1 and K2 of a power iteration are separate launches: DESIGN.md section 3), so the step-level figure
+        # sits below the per-launch one by that 4/6 and by the share of the call outside the GEMMs
+        per_b = 0.25 if a.storage == "2bit" else 1.0
+        step_bytes = 4.0 * per_b * M_local * N
+        out["roofline"]["step_level"] = {"algorithmic_bytes": step_bytes, "definition": "SURVEY.md 8(d): 4 passes x %.2f B per genotype per call, per GPU" % per_b,
+                                         "achieved_GBs": step_bytes / per_step / 1e9, "frac": step_bytes / per_step / 1e9 / HBM_PEAK_GBS,
+                                         "sweeps_the_engine_makes": 2 + 2 * a.power_iters}
         if head_rank_info is not None:
             out["multi_gpu"] = head_rank_info
         if "f32" in results and a.precision != "f32":
@@ -563,7 +630,7 @@ def main():
             # (not in the default run: its panel launches use the same kernels as the headline and would blur the per-kernel
             #  averages of a rocprofv3 --stats run of this command)  the headline matrix shape again, never resident: 8 panels of 131 072 rows regenerated by the device generator on every sweep
             a2 = argparse.Namespace(**vars(a)); a2.panel_rows = 131072; a2.ring = 3; a2.digit_planes = 0
-            dts, tims, evs, _ = streamed_run(g, a2, M_local, N, k, a.storage, local_rank, 0, None, None, steps=min(a.steps, 3), warmup=1)
+            dts, tims, evs, _ = streamed_run(g, a2, M_local, N, k, a.storage, local_rank, 0, None, steps=min(a.steps, 3), warmup=1)
             tims.pop("_panels_cached")
             out["streamed_panels"] = {"note": "same shape out-of-core (BASELINE.json configs[4] mode at configs[1] size): panels come from the "
                                               "device generator (GPCA_PANEL_SYNTH16; a different synthetic draw than the resident matrix)",
@@ -590,7 +657,7 @@ def main():
             def config5_line():
               a5 = argparse.Namespace(**vars(a)); a5.panel_rows = 0; a5.ring = 3; a5.unfused = False; a5.digit_planes = 0
               M5, N5, k5 = 6_250_000, 500_000, 40
-              dt5, tim5, ev5, t_stats5 = streamed_run(g, a5, M5, N5, k5, "2bit", local_rank, 0, None, None, steps=1, warmup=0, cache_gb=-1.0)
+              dt5, tim5, ev5, t_stats5 = streamed_run(g, a5, M5, N5, k5, "2bit", local_rank, 0, None, steps=1, warmup=0, cache_gb=-1.0)
               n_cached5 = tim5.pop("_panels_cached")
               return {
                 "workload": "BASELINE.json configs[4] per-GPU shard, out of core: 6.25M SNPs x 500k samples (781 GB of 2-bit codes per pass, never "
@@ -625,9 +692,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":

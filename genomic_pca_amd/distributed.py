@@ -29,10 +29,13 @@ def torch_allreduce_hook(group=None):
     return _fn
 
 
-def broadcast_unique_id(engine_cls, rank: int, src: int = 0, group=None) -> bytes:
-    """Rank `src` draws the RCCL unique id (gpca_comm_get_unique_id); everyone receives its 128 bytes."""
-    import torch
+def broadcast_unique_id(engine_cls, rank: int, src: int = 0, group=None, rdzv=None) -> bytes:
+    """Rank `src` draws the RCCL unique id (gpca_comm_get_unique_id); everyone receives its 128 bytes -- through the torch-free
+    rendezvous of genomic_pca_amd.launch when `rdzv` is given (bench.py, the multi-GPU tests), else through torch.distributed."""
+    mine = engine_cls.comm_unique_id() if rank == src else None
+    if rdzv is not None:
+        return rdzv.broadcast(mine, src=src)
     import torch.distributed as dist
-    obj = [engine_cls.comm_unique_id() if rank == src else None]
+    obj = [mine]
     dist.broadcast_object_list(obj, src=src, group=group)
     return obj[0]

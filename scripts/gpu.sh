@@ -1,0 +1,55 @@
+#!/bin/bash
+# The one GPU-box helper (replaces the per-experiment gpu_r3_*.sh launchers).  usage: scripts/gpu.sh <tag> <step> [<step> ...]
+# Steps run in order and the chain stops at the first failure (no GPU step is started after one that failed or timed out).
+#   tests[=<pytest -k expression>]   the -m gpu suite (or a selection)           -> gpurun_out/pytest_<tag>.log
+#   file=<tests/x.py[::test]>        one test file / node id                      -> gpurun_out/pytest_<tag>.log (appended)
+#   smoke                            __graft_entry__.smoke()                      -> gpurun_out/smoke_<tag>.log
+#   bench[=<bench.py arguments>]     python bench.py ...                          -> gpurun_out/bench_<tag>[_n].json
+#   profile                          scripts/gpu_profile.sh <tag>: bench + rocprofv3 stats + PMC passes -> profiles/<tag>_*
+#   timeline                         scripts/call_timeline.py <tag>               -> profiles/<tag>_call_timeline.md
+#   ab=<ENV=a>,<ENV=b>[,reps]        scripts/ab_env.py, both orders               -> gpurun_out/ab_<tag>.log
+#   kbench=<name>[,args]             hipcc scripts/kbench/<name>.hip and run it   -> gpurun_out/kbench_<name>_<tag>.log
+#   py=<script.py>[,args]            python <script> args                         -> gpurun_out/py_<tag>.log (appended)
+tag=$1; shift
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+nb=0
+fault() { if grep -q "Memory access fault" "$@" 2>/dev/null; then echo "GPU FAULT"; exit 1; fi; }
+for step in "$@"; do
+  name=${step%%=*}; arg=""; [ "$name" != "$step" ] && arg=${step#*=}
+  echo "== $step"
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=10 -k "$arg" > gpurun_out/pytest_$tag.log 2>&1
+      else timeout -k 10 1150 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/pytest_$tag.log 2>&1; fi
+      rc=$?; tail -25 gpurun_out/pytest_$tag.log; fault gpurun_out/pytest_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+    file)
+      timeout -k 10 900 python -m pytest $arg -m gpu -x -q --durations=6 >> gpurun_out/pytest_$tag.log 2>&1
+      rc=$?; tail -12 gpurun_out/pytest_$tag.log; fault gpurun_out/pytest_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+    smoke)
+      timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$tag.log 2>&1
+      rc=$?; tail -6 gpurun_out/smoke_$tag.log; fault gpurun_out/smoke_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+    bench)
+      nb=$((nb+1)); out=gpurun_out/bench_$tag; [ $nb -gt 1 ] && out=${out}_$nb
+      timeout -k 10 700 python bench.py $arg > $out.json 2> $out.err
+      rc=$?; [ $rc -ne 0 ] && { tail -8 $out.err; exit $rc; }
+      python scripts/bench_brief.py $out.json ;;
+    profile) bash scripts/gpu_profile.sh $tag || exit 1 ;;
+    timeline) timeout -k 10 300 python scripts/call_timeline.py $tag || exit 1 ;;
+    ab)
+      IFS=, read -r a b reps <<< "$arg"; reps=${reps:-8}
+      timeout -k 10 300 python scripts/ab_env.py "$a" "$b" $reps >> gpurun_out/ab_$tag.log 2>&1 || { tail -5 gpurun_out/ab_$tag.log; exit 1; }
+      timeout -k 10 300 python scripts/ab_env.py "$b" "$a" $reps >> gpurun_out/ab_$tag.log 2>&1 || { tail -5 gpurun_out/ab_$tag.log; exit 1; }
+      tail -12 gpurun_out/ab_$tag.log ;;
+    kbench)
+      IFS=, read -r kb kargs <<< "$arg"
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $KBENCH_FLAGS -o /tmp/$kb scripts/kbench/$kb.hip 2> gpurun_out/kbench_${kb}_build.err || { tail -5 gpurun_out/kbench_${kb}_build.err; exit 1; }
+      timeout -k 10 300 /tmp/$kb $kargs > gpurun_out/kbench_${kb}_$tag.log 2>&1
+      rc=$?; tail -40 gpurun_out/kbench_${kb}_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+    py)
+      IFS=, read -r sc pargs <<< "$arg"
+      timeout -k 10 900 python $sc $pargs >> gpurun_out/py_$tag.log 2>&1
+      rc=$?; tail -30 gpurun_out/py_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+    *) echo "unknown step $step"; exit 2 ;;
+  esac
+done
