@@ -1105,12 +1105,12 @@ constexpr int gqd_q_young_early(int R) { return R == 1 ? 2 : 1; }               
 static_assert(gqd_q_young(4, 0) == 2 && gqd_q_young(4, 1) == 1 && gqd_q_young(4, 2) == 1 && gqd_q_young(4, 3) == 1, "R = 4: vmcnt 24/20/20/20");
 static_assert(gqd_q_young(3, 0) == 2 && gqd_q_young(3, 1) == 2 && gqd_q_young(3, 2) == 1, "R = 3: vmcnt 24/24/20");
 static_assert(gqd_q_young(2, 0) == 3 && gqd_q_young(2, 1) == 2 && gqd_q_young(1, 0) == 5, "R = 2: vmcnt 28/24; R = 1: 36");
-template <int S>
-struct GqdSmemT {
+struct GqdSmem {
     i32x4 q[2][4][kDigits][64];          // digit planes: [slot][step][digit][lane]          32 KiB
-    i32x4 g[4][S][256];                  // genotype units: [wave][slot][piece i][lane]      96 KiB (S = 6) / 112 KiB (S = 7)
+    i32x4 g[4][kGqdSlots][256];          // genotype units: [wave][slot][piece i][lane]      96 KiB
+    float tile[4][32 * 32];              // a wave's 32 x 32 tile of T on its way out        16 KiB
+    float rb[4][2][128];                 // r and b of the wave's rows of the round             4 KiB
 };
-using GqdSmem = GqdSmemT<kGqdSlots>;
 
 template <int NT = 0>
 __device__ __forceinline__ void gqd_dma(uint32_t lds_addr, uint32_t voff, i32x4 rsrc, uint32_t soff) {
@@ -1123,6 +1123,13 @@ __device__ __forceinline__ void gqd_dma(uint32_t lds_addr, uint32_t voff, i32x4 
         asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// 64 consecutive dwords (one per lane) straight into LDS at lds_addr + 4 * lane
+__device__ __forceinline__ void gqd_dma_dword(uint32_t lds_addr, uint32_t voff, i32x4 rsrc, uint32_t soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 template <int N> __device__ __forceinline__ void gqd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // the same with the count chosen by a value that is a constant after unrolling (16 + 4 x plane batches)
@@ -1145,15 +1152,77 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
     return r;
 }
 
-template <int NT, int S, int R = 4>
+// One tile of a K1 epilogue: T = r o (G Q) + b s^T from the exact digit-plane sums, the unit's share of c, the column abs-max, and
+// the tile on its way out through a wave-private 4 KiB of LDS so that it leaves as four 16-byte stores per lane (a lane's 16
+// elements are 16 different rows: written directly they are 16 dword stores with a 64-bit address each).  `rrow` / `brow` hold r
+// and b of row 32 t + c in lane c.  The sched_barrier keeps one tile's accumulators live at a time: without it hipcc read all 256
+// accumulators into VGPRs first, spilled the address arithmetic to scratch and waited (vmcnt(0)) on every reload behind the store it
+// had just issued -- one store round trip per element, ~19 us per round at any N (the per-round cost the shape sweep showed).
+template <int BITS, bool RB_LDS>
+__device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rrow, float brow, const float* rl, const float* bl,
+                                            double qs, float sj, int scale_out,
+                                            float* __restrict__ tile, float* __restrict__ Tout, int64_t ldt, int64_t unit,
+                                            float* __restrict__ cunit, float& amax, int lane_in) {
+    __builtin_amdgcn_sched_barrier(0);
+    // the lane id is made opaque here: everything derived from it (LDS offsets, cross-lane indices, store addresses) is then computed
+    // where it is used instead of being hoisted out of the round loop as ~40 loop-invariant registers that the stage loop's register
+    // pressure sent to scratch
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int c = lane & 31, h = lane >> 5;
+    float ct = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
+        // r and b of that row: from the wave's LDS staging (k_gq_d: DMA-ed at the start of the round, no compiler-visible load whose
+        // wait would drain the DMA queue), or from lane `rin` of registers loaded one row per lane
+        const float ri = RB_LDS ? rl[rin] : __shfl(rrow, rin), bi = RB_LDS ? bl[rin] : __shfl(brow, rin);
+        const float gq = (float)(combine_digits<BITS>(a, e) * qs);
+        const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+        ct = __fmaf_rn(bi, tv, ct);
+        const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
+        amax = fmaxf(amax, fabsf(ov));
+        tile[rin * 32 + c] = ov;
+    }
+    GPCA_STORE_CUNIT(unit)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (one wave's LDS operations execute in order: no barrier)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (lane >> 3) + 8 * i;
+        const float4 v = *reinterpret_cast<const float4*>(tile + rr * 32 + 4 * (lane & 7));
+        *reinterpret_cast<float4*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the tile is free again before the next one is written)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// What a wave does in one round: R tiles starting at row unit `unit0`, `nv` of them real (nv = 0: the wave rides along on the round's
+// first unit for the planes and the barriers and stores nothing).
+struct GqdRound { int64_t unit0; int nv; int R; };
+
+// CHAINED rounds.  The last six refills of a round used to wrap to stage 0 of the same tiles and were thrown away, the ring was
+// drained, and the next round started cold (prologue, first-fill latency).  Now those six refills fetch the first six units of the
+// wave's NEXT round (in that round's own order: stage-major over its R' tiles) and the plane batch issued in the last stage is
+// Q(0) of the next round -- the planes depend on the stage only -- so the issue order across the boundary is the steady state's
+//     ... G'0 G'1 | Q'(0) G'2 G'3 G'4 G'5 |        (= the prologue's order G0 G1 Q0 G2 G3 G4 G5)
+// and the next round starts where a prologue would have left it, with its data landing behind this round's epilogue.  The ring
+// position carries over (`rslot`: unit m + 6 always goes into the slot of unit m).  Nothing is drained at the boundary: the epilogue's
+// stores (and the next round's r / b fetch) are younger than every prefetch, and a counted wait stays correct with MORE operations
+// younger than its target -- it needs at least `count` LOADS younger than the load it waits for (loads complete in order), which the
+// steady-state issue order provides.
+// Needs more than 6 units per round (nstage >= 8); shorter sample axes keep the drained form.
+template <int NT, int R>
 __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
-                                          const int8_t* __restrict__ Qd, GqdSmemT<S>* sm, int wv, int lane, int c, int h,
-                                          int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
+                                          const int8_t* __restrict__ Qd, GqdSmem* sm, int wv, int lane, int c, int h,
+                                          int64_t unit0, int nvalid, bool prologue, bool chain, GqdRound nx, uint32_t& rslot,
+                                          int64_t rows_total, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float* __restrict__ cunit, float& amax) {
-    static_assert(R >= 1 && R <= 4 && (S == 6 || R == 4), "rounds of fewer than 4 tiles are derived for the 6-slot ring");
+    constexpr int S = kGqdSlots;
+    static_assert(R >= 1 && R <= 4, "tiles per wave");
     const int64_t row0 = unit0 * 32;
     const i32x4 rg = gqd_rsrc(G + row0 * ldg);
+    const i32x4 rgn = gqd_rsrc(G + nx.unit0 * 32 * ldg);          // the next round's rows (chain)
     const i32x4 rq = gqd_rsrc(Qd + wv * 1024);
     const uint32_t ld32 = (uint32_t)ldg;
     // row r keeps chunk k at position k ^ ((r >> 1) & 7): with ds_read_b128's lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...)
@@ -1165,13 +1234,21 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     uint32_t toff[R];                                   // wave-uniform byte offset of tile t (tiles past the range: tile 0)
 #pragma unroll
     for (int t = 0; t < R; ++t) toff[t] = (uint32_t)(t < nvalid ? 32 * t : 0) * ld32;
-    // r and b of the round's rows, one row per lane (row 32 t + c), requested before anything else: the epilogue picks them up
-    // with a cross-lane read instead of 32 dependent global loads per tile at the end of the round
-    float rrow[R], brow[R];
+    // r and b of the round's rows (row0 ... row0 + 32 R) go into the wave's LDS staging by DMA, issued before anything else of the
+    // round; the epilogue reads them with ds_read.  (As global loads into registers their first use -- the epilogue -- carried a
+    // compiler-inserted vmcnt wait that knew nothing of the DMAs in flight and drained them.)  Extra DMAs never invalidate a counted
+    // wait: a count stays correct as long as at least that many LOADS are younger than the one waited for.  Rows past the end of
+    // the launch's row range read as zero (num_records).
+    {
+        const uint32_t lds_rb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->rb[wv][0][0];
+        i32x4 rr_ = gqd_rsrc(rv + row0), rb_ = gqd_rsrc(bv + row0);
+        rr_.z = rb_.z = (int)((rows_total - row0) * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the previous round's epilogue has read its r and b
 #pragma unroll
-    for (int t = 0; t < R; ++t) {
-        const int64_t rix = row0 + (t < nvalid ? 32 * t : 0) + c;
-        rrow[t] = rv[rix]; brow[t] = bv[rix];
+        for (int j = 0; j < (R + 1) / 2; ++j) {
+            gqd_dma_dword(lds_rb + 256u * j, qvo >> 2, rr_, 256u * j);
+            gqd_dma_dword(lds_rb + 512u + 256u * j, qvo >> 2, rb_, 256u * j);
+        }
     }
     constexpr uint32_t QCH = kDigits * 1024;
     const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
@@ -1189,12 +1266,12 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
 
-    // fill unit (stage st, tile t) into ring slot `slot`
-#define GQD_ISSUE_G(ST, T, SLOT)                                                                          \
+    // fill one unit (rows of resource RSRC at byte offset SO) into ring slot `slot`
+#define GQD_ISSUE_G(RSRC, SO, SLOT)                                                                       \
     {                                                                                                     \
-        const uint32_t so_ = toff[(T)] + (uint32_t)(ST) * 128u;                                           \
+        const uint32_t so_ = (SO);                                                                        \
         const uint32_t la_ = lds_g + (uint32_t)(SLOT) * 4096u;                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma<NT>(la_ + 1024u * i, (i & 1) ? gvo_o : gvo_e, rg, so_ + 8u * i * ld32); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) gqd_dma<NT>(la_ + 1024u * i, (i & 1) ? gvo_o : gvo_e, RSRC, so_ + 8u * i * ld32); \
     }
 #define GQD_ISSUE_Q(ST, QS)                                                                               \
     {                                                                                                     \
@@ -1202,21 +1279,33 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
             gqd_dma(lds_q + (uint32_t)(((QS) * 4 + j) * kDigits) * 1024u, qvo, rq, ((uint32_t)(ST) * 4u + j) * QCH); \
     }
     // ring of S slots: the unit consumed is re-filled with the unit S ahead, units in the order they are consumed (stage-major,
-    // R tiles per stage; past the last stage the fills wrap to stage 0 and are never read); S - 4 units precede Q(0) in the
-    // prologue so that the steady-state counts hold from the first stage on (S = 6: G0 G1 Q0 G2..G5;  S = 7: G0 G1 G2 Q0 G3..G6)
-    int64_t ist = 0;         // next unit to issue: (stage ist, tile it)
+    // R tiles per stage).  Past the last stage the fills go on with the next round's units (chain) or wrap to stage 0 and are
+    // never read (last round, short sample axes).  S - 4 units precede Q(0) in the prologue so that the steady-state counts hold
+    // from the first stage on (G0 G1 Q0 G2..G5).
+    int64_t ist = 0;         // next unit to issue: (stage ist, tile it) of this round ...
     int it = 0;
+    bool in_next = false;    // ... or (stage pst, tile pt) of the next
+    uint32_t pst = 0; int pt = 0;
 #define GQD_ISSUE_NEXT(SLOT)                                                                              \
     {                                                                                                     \
-        GQD_ISSUE_G(ist, it, SLOT)                                                                        \
-        if (++it == R) { it = 0; ist = ist + 1 < nstage ? ist + 1 : 0; }                                  \
+        if (!in_next) {                                                                                   \
+            GQD_ISSUE_G(rg, toff[it] + (uint32_t)ist * 128u, SLOT)                                        \
+            if (++it == R) { it = 0; if (++ist == nstage) { if (chain) in_next = true; else ist = 0; } }  \
+        } else {                                                                                          \
+            const uint32_t tn_ = (uint32_t)(pt < nx.nv ? 32 * pt : 0) * ld32;                             \
+            GQD_ISSUE_G(rgn, tn_ + pst * 128u, SLOT)                                                      \
+            if (++pt == nx.R) { pt = 0; ++pst; }                                                          \
+        }                                                                                                 \
     }
-    GQD_ISSUE_NEXT(0) GQD_ISSUE_NEXT(1)
-    if constexpr (S == 7) GQD_ISSUE_NEXT(2)
-    GQD_ISSUE_Q(0, 0)
+    if (prologue) {
+        rslot = 0;
+        GQD_ISSUE_NEXT(0) GQD_ISSUE_NEXT(1)
+        GQD_ISSUE_Q(0, 0)
 #pragma unroll
-    for (int sl = S - 4; sl < S; ++sl) GQD_ISSUE_NEXT(sl)
-    uint32_t rslot = 0;      // slot of the unit being consumed
+        for (int sl = S - 4; sl < S; ++sl) GQD_ISSUE_NEXT(sl)
+    } else {                 // the previous round left units 0..5 of this one in flight (slots rslot ...) and Q(0) in plane slot 0
+        ist = S / R; it = S % R;
+    }
     i32x4 gcur, gnxt;
 
     for (int64_t st = 0; st < nstage; ++st) {
@@ -1231,9 +1320,9 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int d = 0; d < kDigits; ++d) q[s4][d] = sm->q[st & 1][s4][d][lane];
-        if (st == 0) {                                   // unit 0 (slot 0) landed with Q(0)
-            gcur = *reinterpret_cast<const i32x4*>(gl + loff[0]);
-            gnxt = *reinterpret_cast<const i32x4*>(gl + loff[1]);
+        if (st == 0) {                                   // unit 0 landed with Q(0)
+            gcur = *reinterpret_cast<const i32x4*>(gl + rslot * 4096u + loff[0]);
+            gnxt = *reinterpret_cast<const i32x4*>(gl + rslot * 4096u + loff[1]);
         }
 #pragma unroll
         for (int t = 0; t < R; ++t) {
@@ -1250,8 +1339,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
                     if (s4 == 2) {
                         // younger than the next unit: S - 2 unit fills + 1 plane batch (2 when a stage start falls in the window)
                         if constexpr (R == 4) {
-                            if (S == 6) { if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>(); }
-                            else { if (t <= 1) gqd_wait_vm<28>(); else gqd_wait_vm<24>(); }
+                            if (t == 0) gqd_wait_vm<24>(); else gqd_wait_vm<20>();
                         } else {
                             if (st < gqd_early_stages(R)) gqd_wait_young(gqd_q_young_early(R));
                             else gqd_wait_young(gqd_q_young(R, t));
@@ -1272,41 +1360,28 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
             rslot = nslot;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // ring and plane slots quiescent before the next round
+    // not chained: ring and plane slots quiescent before the next round's prologue (or the end of the kernel)
+    if (!chain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #undef GQD_ISSUE_NEXT
 #undef GQD_ISSUE_G
 #undef GQD_ISSUE_Q
+    // chained: no drain.  The epilogue's stores are younger than the prefetched fills, which only makes the next round's counted waits
+    // stricter than they need to be for a few stages.
+    float* tile = sm->tile[wv];
 #pragma unroll
-    for (int t = 0; t < R; ++t) {
-        if (t < nvalid) {
-            float ct = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
-                const int64_t row = row0 + 32 * t + rin;
-                const float ri = __shfl(rrow[t], rin), bi = __shfl(brow[t], rin);
-                const float gq = (float)(combine_digits(acc[t], e) * qs);
-                const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
-                ct = __fmaf_rn(bi, tv, ct);
-                const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
-                amax = fmaxf(amax, fabsf(ov));
-                Tout[row * ldt + c] = ov;
-            }
-            GPCA_STORE_CUNIT(unit0 + t)
-        }
-    }
+    for (int t = 0; t < R; ++t)
+        if (t < nvalid) gq_tile_out<7, true>(acc[t], 0.f, 0.f, &sm->rb[wv][0][32 * t], &sm->rb[wv][1][32 * t], qs, sj, scale_out, tile, Tout, ldt, unit0 + t, cunit, amax, lane);
 }
 
-template <int NT, int S>
+template <int NT>
 __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nstage,
                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
                                                   float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt,
-                                                  int short_rounds) {
+                                                  int chain_ok) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
-    GqdSmemT<S>* sm = reinterpret_cast<GqdSmemT<S>*>(gqd_smem);
-    i32x4 (*tds)[4][kDigits][64] = sm->q;
+    GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -1315,38 +1390,36 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
     float amax = 0.f;
     const float sj = sv[c];
     const double qs = qscale[c];
+    asm volatile("" :: "v"(sj), "v"(qs));      // (their wait falls here, before any DMA is in flight, not in the first epilogue)
+    // a round = up to 16 units, four per wave; a short last round (1..15 units) is split evenly -- (3,3,2,2) rather than (4,4,2,0) --
+    // and every wave sweeps the samples with as many tiles as it has units (a wave without a unit rides along)
+    auto round_at = [&](int64_t u) -> GqdRound {
+        const int64_t rem = u1 - u, take = rem < 16 ? rem : 16;
+        const int64_t base = take >> 2, extra = take & 3;
+        const int nv = (int)(base + (wv < extra ? 1 : 0));
+        GqdRound r;
+        r.nv = nv; r.R = nv ? nv : 1;
+        r.unit0 = nv ? u + wv * base + (wv < extra ? wv : extra) : u;
+        return r;
+    };
+    const bool chain_all = chain_ok && nstage > kGqdSlots;    // (more than 6 units in every round, whatever its R: a round's own refills start inside it)
+    bool prologue = true;
+    uint32_t rslot = 0;
     int64_t u = u0;
     while (u < u1) {
-        const int64_t rem = u1 - u;
-        const bool shorter = S == 6 && short_rounds;
-        if (shorter || rem > 8) {           // up to 4 tiles per wave, genotypes by LDS-DMA
-            // a short last round (1..15 units) is split evenly -- (3,3,2,2) rather than (4,4,2,0) -- and every wave sweeps the
-            // samples with as many tiles as it has units (6-slot ring; a wave without a unit rides along for the planes and the
-            // barriers)
-            const int64_t take = rem < 16 ? rem : 16;
-            const int64_t base = take >> 2, extra = take & 3;
-            const int64_t mine = u + wv * base + (wv < extra ? wv : extra);
-            const int nv = (int)(base + (wv < extra ? 1 : 0));
-#define GPCA_GQD_ROUND(RR, UNIT0, NV) gqd_round<NT, S, RR>(G, ldg, nstage, Qd, sm, wv, lane, c, h, (UNIT0), (NV), qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax)
-            if constexpr (S == 6) {
-                if (!shorter || nv == 4) GPCA_GQD_ROUND(4, mine, nv);
-                else if (nv == 3) GPCA_GQD_ROUND(3, mine, 3);
-                else if (nv == 2) GPCA_GQD_ROUND(2, mine, 2);
-                else GPCA_GQD_ROUND(1, nv ? mine : u, nv);
-            } else GPCA_GQD_ROUND(4, mine, nv);
+        const int64_t un = u + (u1 - u < 16 ? u1 - u : 16);
+        const GqdRound cur = round_at(u);
+        const bool chain = chain_all && un < u1;
+        GqdRound nx = cur;
+        if (chain) nx = round_at(un);
+#define GPCA_GQD_ROUND(RR) gqd_round<NT, RR>(G, ldg, nstage, Qd, sm, wv, lane, c, h, cur.unit0, cur.nv, prologue, chain, nx, rslot, units * 32, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax)
+        if (cur.R == 4) GPCA_GQD_ROUND(4);
+        else if (cur.R == 3) GPCA_GQD_ROUND(3);
+        else if (cur.R == 2) GPCA_GQD_ROUND(2);
+        else GPCA_GQD_ROUND(1);
 #undef GPCA_GQD_ROUND
-            u += take;
-        } else if (rem > 4) {    // tails (7-slot ring, GPCA_GQ_SHORT=0): the register-staged rounds
-            const int64_t mine = u + 2 * wv;
-            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
-            u += 8;
-        } else {
-            const int64_t mine = u + wv;
-            const int nv = mine < u1 ? 1 : 0;
-            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
-            u += 4;
-        }
+        prologue = !chain;
+        u = un;
     }
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
     if (h == 0) apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am;
@@ -1358,18 +1431,10 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
     // the hand-counted vmcnt pipeline is only correct for an EVEN number of 128-sample stages (9 stages gave wrong eigenvalues,
     // profiles/r1_kbench_summary.md section 9): refuse any other pitch instead of answering wrongly
     if (!dma_shape_ok(Npad, 256, plan.units * 32, 32) || ldg < Npad) return (int)hipErrorInvalidValue;
-    const int slots = ko.gq_slots;
-    const bool g_dma_nt = ko.dma_nt != 0;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;
-#define GPCA_GQD(NTV, SV)                                                                                                       \
-    {                                                                                                                          \
-        hipLaunchKernelGGL((k_gq_d<NTV, SV>), grid, blk, sizeof(GqdSmemT<SV>), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, \
-                           Tout, cpart, apart, scale_out, ldt, ko.gq_short);                                                   \
-    }
-    if (slots == 7) { if (g_dma_nt) GPCA_GQD(1, 7) else GPCA_GQD(0, 7) }
-    else { if (g_dma_nt) GPCA_GQD(1, 6) else GPCA_GQD(0, 6) }
-#undef GPCA_GQD
+    if (ko.dma_nt) hipLaunchKernelGGL((k_gq_d<1>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain);
+    else hipLaunchKernelGGL((k_gq_d<0>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain);
     return 0;
 }
 
@@ -1856,8 +1921,7 @@ int init_device_kernels_i8() {
     int e = 0;
 #define GPCA_OPT_IN(KERNEL, BYTES) \
     if (e == 0) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));
-    GPCA_OPT_IN((k_gq_d<0, 6>), sizeof(GqdSmemT<6>)) GPCA_OPT_IN((k_gq_d<1, 6>), sizeof(GqdSmemT<6>))
-    GPCA_OPT_IN((k_gq_d<0, 7>), sizeof(GqdSmemT<7>)) GPCA_OPT_IN((k_gq_d<1, 7>), sizeof(GqdSmemT<7>))
+    GPCA_OPT_IN((k_gq_d<0>), sizeof(GqdSmem)) GPCA_OPT_IN((k_gq_d<1>), sizeof(GqdSmem))
     GPCA_OPT_IN((k_gtt_p<kDigits>), sizeof(GtpSmem)) GPCA_OPT_IN((k_gtt_p<3>), sizeof(GtpSmem))
     GPCA_OPT_IN((k_gtt_d<0>), sizeof(GqdSmem)) GPCA_OPT_IN((k_gtt_d<1>), sizeof(GqdSmem))
 #undef GPCA_OPT_IN

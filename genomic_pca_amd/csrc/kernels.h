@@ -17,8 +17,7 @@ struct KernelOpts {
     int stream_nt = 0;   // GPCA_STREAM_NT  : nt loads in the per-wave-plane kernels k_gq_i8 / k_gtt_i8
     int dma_nt = 1;      // GPCA_GQ_DMA_NT  : nt on the LDS-DMA genotype streams (k_gq_d, k_gtt_d)
     int gq_r = 4;        // GPCA_GQ_R       : max tiles per wave in k_gq_x
-    int gq_slots = 6;    // GPCA_GQ_SLOTS   : ring slots per wave in k_gq_d (6 or 7)
-    int gq_short = 1;    // GPCA_GQ_SHORT   : k_gq_d's last round of a workgroup runs with as many tiles per wave as the wave has units (0: four, padded)
+    int gq_chain = 1;    // GPCA_GQ_CHAIN   : k_gq_d prefetches a wave's next round behind the current round's epilogue (0: drain + prologue per round)
     int gtt_xcd = 1;     // GPCA_GTT_XCD    : XCD-aware n-group order in k_gtt_d / k_gtt_p
     int gttx_xcd = 0;    // GPCA_GTTX_XCD   : the same in the register-staged k_gtt_x (measured: no gain there)
 };

@@ -894,11 +894,11 @@ def test_random_shapes_against_the_oracle(gpca, oracle, monkeypatch, case):
 
 @pytest.mark.parametrize("env", [{"GPCA_GQ_DMA": "0"}, {"GPCA_GTT_DMA": "0"}, {"GPCA_GQ_DMA": "0", "GPCA_GTT_DMA": "0"},
                                  {"GPCA_LDS_PLANES": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GTT_WAVES": "64"},
-                                 {"GPCA_GQ_SLOTS": "7", "GPCA_GQ_WAVES": "8"}, {"GPCA_GTT_XCD": "0"}, {"GPCA_GQ_DMA_NT": "0"},
+                                 {"GPCA_GQ_CHAIN": "0", "GPCA_GQ_WAVES": "8"}, {"GPCA_GTT_XCD": "0"}, {"GPCA_GQ_DMA_NT": "0"},
                                  {"GPCA_GQ_DMA": "0", "GPCA_GQ_R": "2"}, {"GPCA_LDS_PLANES": "0", "GPCA_STREAM_NT": "1"},
                                  {"GPCA_GTT_DMA": "0", "GPCA_GTTX_XCD": "1"},
-                                 {"GPCA_GQ_WAVES": "12", "GPCA_GQ_SLOTS": "7"}, {"GPCA_GQ_WAVES": "8", "GPCA_GQ_DMA_NT": "0"},
-                                 {"GPCA_GQ_SHORT": "0"}, {"GPCA_GQ_SHORT": "0", "GPCA_GQ_WAVES": "12"}])
+                                 {"GPCA_GQ_WAVES": "12", "GPCA_GQ_CHAIN": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GQ_DMA_NT": "0"},
+                                 {"GPCA_GQ_CHAIN": "0"}, {"GPCA_GQ_WAVES": "4"}])
 def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     """Register-staged (k_gq_x / k_gtt_x) and per-wave-plane (k_gq_i8 / k_gtt_i8) kernels, and a tiny grid that forces
     full LDS-DMA rounds on a small matrix, against the default configuration: the integer products are exact, so only
@@ -924,7 +924,7 @@ def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     assert oracle.max_abs_dpc(res["alt"][1], R["scores"]) < TOL_PC
 
 
-@pytest.mark.parametrize("N", [200, 1000])
+@pytest.mark.parametrize("N", [200, 1000, 1300])
 @pytest.mark.parametrize("M", [500, 1500, 2500, 3700])
 def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, monkeypatch, M, N):
     """k_gq_d's rounds of fewer than four tiles per wave (R = 3, 2, 1 and waves that only ride along): grids of 1, 2 and 3 workgroups
@@ -937,15 +937,17 @@ def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, 
     th = gpca.synth_thresholds(M, 3, seed=5, fst=0.1)
     G = oracle.synth_genotypes(M, N, 5, th)
     res = {}
+    # (N = 1000 and 1300 are 8 and 12 stages: the rounds of a workgroup are CHAINED there -- the next round's first units and planes
+    #  are fetched behind the current round's epilogue, whatever the two rounds' tile counts; 2 stages keep the drained form)
     for name, env in (("staged", {"GPCA_GQ_DMA": "0"}), ("w4", {"GPCA_GQ_WAVES": "4"}), ("w8", {"GPCA_GQ_WAVES": "8"}), ("w12", {"GPCA_GQ_WAVES": "12"}),
-                      ("default", {})):
+                      ("w4_unchained", {"GPCA_GQ_WAVES": "4", "GPCA_GQ_CHAIN": "0"}), ("default", {})):
         with monkeypatch.context() as mp:
             for key, val in env.items():
                 mp.setenv(key, val)
             with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
                 e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 5, 2, seed=3)
                 res[name] = (e.eigenvalues().copy(), e.scores(f64=True).copy(), e.loadings().copy())
-    for name in ("w4", "w8", "w12", "default"):
+    for name in ("w4", "w8", "w12", "w4_unchained", "default"):
         for a, b in zip(res[name], res["staged"]):
             assert np.array_equal(a, b), name
     st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
