@@ -1094,6 +1094,16 @@ int launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
 //       the stages before gqd_early_stages(R) wait with the smallest count any of them needs (a stricter wait is always safe).
 // ================================================================================================
 constexpr int kGqdSlots = 6;
+#ifndef GPCA_STAMP
+#define GPCA_STAMP 0     // scripts/kbench/kbench_gqd.hip: s_memrealtime stamps (100 MHz) of wave 0 of every workgroup at the round boundaries
+#endif
+#if GPCA_STAMP
+__device__ unsigned long long g_gqd_stamp[1024 * 64];     // [workgroup][slot]: 0 = start, 1 + 2 r = stage loop of round r done, 2 + 2 r = its epilogue done
+__device__ int g_gqd_stamp_n;
+#define GQD_STAMP(SLOT) { if (threadIdx.x == 0 && blockIdx.x < 1024 && (SLOT) < 64) g_gqd_stamp[blockIdx.x * 64 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define GQD_STAMP(SLOT)
+#endif
 // plane batches younger than the fill of unit m + 1 while unit m (tile t = m mod R) is consumed, steady state (m >= 4)
 constexpr int gqd_q_young(int R, int t) {
     int n = 0;
@@ -1214,12 +1224,15 @@ struct GqdRound { int64_t unit0; int nv; int R; };
 template <int NT, int R>
 __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
                                           const int8_t* __restrict__ Qd, GqdSmem* sm, int wv, int lane, int c, int h,
-                                          int64_t unit0, int nvalid, bool prologue, bool chain, GqdRound nx, uint32_t& rslot,
+                                          int64_t unit0, int nvalid, bool prologue, bool chain, GqdRound nx, uint32_t& rslot, int round_ix, uint32_t ph,
                                           int64_t rows_total, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
                                           float* __restrict__ cunit, float& amax) {
     constexpr int S = kGqdSlots;
     static_assert(R >= 1 && R <= 4, "tiles per wave");
+    // the workgroup sweeps the sample axis starting at stage `ph` (and wraps): the integer sums do not depend on the order, and
+    // workgroups that start at different columns do not all ask the memory system for the same column of 131 072 rows at once
+    auto phys = [&](uint32_t st_) -> uint32_t { const uint32_t p_ = st_ + ph; return p_ >= (uint32_t)nstage ? p_ - (uint32_t)nstage : p_; };
     const int64_t row0 = unit0 * 32;
     const i32x4 rg = gqd_rsrc(G + row0 * ldg);
     const i32x4 rgn = gqd_rsrc(G + nx.unit0 * 32 * ldg);          // the next round's rows (chain)
@@ -1276,7 +1289,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
 #define GQD_ISSUE_Q(ST, QS)                                                                               \
     {                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-            gqd_dma(lds_q + (uint32_t)(((QS) * 4 + j) * kDigits) * 1024u, qvo, rq, ((uint32_t)(ST) * 4u + j) * QCH); \
+            gqd_dma(lds_q + (uint32_t)(((QS) * 4 + j) * kDigits) * 1024u, qvo, rq, (phys((uint32_t)(ST)) * 4u + j) * QCH); \
     }
     // ring of S slots: the unit consumed is re-filled with the unit S ahead, units in the order they are consumed (stage-major,
     // R tiles per stage).  Past the last stage the fills go on with the next round's units (chain) or wrap to stage 0 and are
@@ -1289,11 +1302,11 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
 #define GQD_ISSUE_NEXT(SLOT)                                                                              \
     {                                                                                                     \
         if (!in_next) {                                                                                   \
-            GQD_ISSUE_G(rg, toff[it] + (uint32_t)ist * 128u, SLOT)                                        \
+            GQD_ISSUE_G(rg, toff[it] + phys((uint32_t)ist) * 128u, SLOT)                                  \
             if (++it == R) { it = 0; if (++ist == nstage) { if (chain) in_next = true; else ist = 0; } }  \
         } else {                                                                                          \
             const uint32_t tn_ = (uint32_t)(pt < nx.nv ? 32 * pt : 0) * ld32;                             \
-            GQD_ISSUE_G(rgn, tn_ + pst * 128u, SLOT)                                                      \
+            GQD_ISSUE_G(rgn, tn_ + phys(pst) * 128u, SLOT)                                                \
             if (++pt == nx.R) { pt = 0; ++pst; }                                                          \
         }                                                                                                 \
     }
@@ -1362,6 +1375,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     }
     // not chained: ring and plane slots quiescent before the next round's prologue (or the end of the kernel)
     if (!chain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    GQD_STAMP(1 + 2 * round_ix)
 #undef GQD_ISSUE_NEXT
 #undef GQD_ISSUE_G
 #undef GQD_ISSUE_Q
@@ -1371,6 +1385,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
 #pragma unroll
     for (int t = 0; t < R; ++t)
         if (t < nvalid) gq_tile_out<7, true>(acc[t], 0.f, 0.f, &sm->rb[wv][0][32 * t], &sm->rb[wv][1][32 * t], qs, sj, scale_out, tile, Tout, ldt, unit0 + t, cunit, amax, lane);
+    GQD_STAMP(2 + 2 * round_ix)
 }
 
 template <int NT>
@@ -1379,12 +1394,13 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
                                                   const float* __restrict__ rv, const float* __restrict__ bv,
                                                   const float* __restrict__ sv, float* __restrict__ Tout,
                                                   float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt,
-                                                  int chain_ok) {
+                                                  int chain_ok, int phase_mul) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
+    const uint32_t ph = (uint32_t)(((int64_t)(blockIdx.x & 7) * (phase_mul & 0xffff) + (int64_t)(blockIdx.x >> 3) * (phase_mul >> 16)) % nstage);   // this workgroup's first stage: XCD (b % 8) and place in the XCD (b / 8)
     const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
     const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
     float amax = 0.f;
@@ -1405,6 +1421,8 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
     const bool chain_all = chain_ok && nstage > kGqdSlots;    // (more than 6 units in every round, whatever its R: a round's own refills start inside it)
     bool prologue = true;
     uint32_t rslot = 0;
+    int round_ix = 0;
+    GQD_STAMP(0)
     int64_t u = u0;
     while (u < u1) {
         const int64_t un = u + (u1 - u < 16 ? u1 - u : 16);
@@ -1412,7 +1430,7 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
         const bool chain = chain_all && un < u1;
         GqdRound nx = cur;
         if (chain) nx = round_at(un);
-#define GPCA_GQD_ROUND(RR) gqd_round<NT, RR>(G, ldg, nstage, Qd, sm, wv, lane, c, h, cur.unit0, cur.nv, prologue, chain, nx, rslot, units * 32, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax)
+#define GPCA_GQD_ROUND(RR) gqd_round<NT, RR>(G, ldg, nstage, Qd, sm, wv, lane, c, h, cur.unit0, cur.nv, prologue, chain, nx, rslot, round_ix, ph, units * 32, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax)
         if (cur.R == 4) GPCA_GQD_ROUND(4);
         else if (cur.R == 3) GPCA_GQD_ROUND(3);
         else if (cur.R == 2) GPCA_GQD_ROUND(2);
@@ -1420,7 +1438,11 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
 #undef GPCA_GQD_ROUND
         prologue = !chain;
         u = un;
+        ++round_ix;
     }
+#if GPCA_STAMP
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_gqd_stamp_n = round_ix;
+#endif
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
     if (h == 0) apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am;
 }
@@ -1433,8 +1455,15 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
     if (!dma_shape_ok(Npad, 256, plan.units * 32, 32) || ldg < Npad) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
     const int64_t nstage = Npad / 128;
-    if (ko.dma_nt) hipLaunchKernelGGL((k_gq_d<1>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain);
-    else hipLaunchKernelGGL((k_gq_d<0>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain);
+    // Where a workgroup starts its sweep of the sample axis.  In lockstep every workgroup asks for the same 128-byte column of its
+    // rows at the same time (131 072 rows x 128 B, one row pitch apart); with the workgroups of an XCD (b % 8) spread over 8 starting
+    // stages the launch is 3-5 % faster at 10k-40k samples (scripts/kbench/kbench_gqd.hip ab, profiles/r4_kbench_summary.md).  Eight
+    // starting points keep the digit planes of Q an L2 hit -- one sweep of the planes per phase in flight; 16 phases at 40k samples
+    // (5 MB of planes) and any phase at 100k (12.8 MB) measured slower than lockstep, so long sample axes stay in lockstep.
+    int phase = ko.gq_phase;
+    if (phase < 0) phase = (nstage >= 16 && nstage <= 400) ? (int)((nstage / 8) << 16) : 0;
+    if (ko.dma_nt) hipLaunchKernelGGL((k_gq_d<1>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain, phase);
+    else hipLaunchKernelGGL((k_gq_d<0>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain, phase);
     return 0;
 }
 

@@ -101,6 +101,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     h->ko.dma_nt = env_int("GPCA_GQ_DMA_NT", 1) != 0;
     h->ko.gq_r = env_int("GPCA_GQ_R", 4);
     h->ko.gq_chain = env_int("GPCA_GQ_CHAIN", 1) != 0;
+    h->ko.gq_phase = env_int("GPCA_GQ_PHASE", h->ko.gq_phase);
     h->ko.gtt_xcd = env_int("GPCA_GTT_XCD", 1);
     h->ko.gttx_xcd = env_int("GPCA_GTTX_XCD", 0);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {

@@ -17,6 +17,7 @@ struct KernelOpts {
     int stream_nt = 0;   // GPCA_STREAM_NT  : nt loads in the per-wave-plane kernels k_gq_i8 / k_gtt_i8
     int dma_nt = 1;      // GPCA_GQ_DMA_NT  : nt on the LDS-DMA genotype streams (k_gq_d, k_gtt_d)
     int gq_r = 4;        // GPCA_GQ_R       : max tiles per wave in k_gq_x
+    int gq_phase = -1;   // GPCA_GQ_PHASE   : workgroup b of k_gq_d starts its sweep of the sample axis at stage ((b % 8) A + (b / 8) B) mod stages, A = low 16 bits, B = high 16 bits; -1 = the launcher's choice (8 starting points per XCD up to 51k samples)
     int gq_chain = 1;    // GPCA_GQ_CHAIN   : k_gq_d prefetches a wave's next round behind the current round's epilogue (0: drain + prologue per round)
     int gtt_xcd = 1;     // GPCA_GTT_XCD    : XCD-aware n-group order in k_gtt_d / k_gtt_p
     int gttx_xcd = 0;    // GPCA_GTTX_XCD   : the same in the register-staged k_gtt_x (measured: no gain there)

@@ -22,17 +22,17 @@ for step in "$@"; do
     tests)
       if [ -n "$arg" ]; then timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=10 -k "$arg" > gpurun_out/pytest_$tag.log 2>&1
       else timeout -k 10 1150 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/pytest_$tag.log 2>&1; fi
-      rc=$?; tail -25 gpurun_out/pytest_$tag.log; fault gpurun_out/pytest_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+      rc=$?; tail -25 gpurun_out/pytest_$tag.log; fault gpurun_out/pytest_$tag.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
     file)
       timeout -k 10 900 python -m pytest $arg -m gpu -x -q --durations=6 >> gpurun_out/pytest_$tag.log 2>&1
-      rc=$?; tail -12 gpurun_out/pytest_$tag.log; fault gpurun_out/pytest_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+      rc=$?; tail -12 gpurun_out/pytest_$tag.log; fault gpurun_out/pytest_$tag.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
     smoke)
       timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$tag.log 2>&1
-      rc=$?; tail -6 gpurun_out/smoke_$tag.log; fault gpurun_out/smoke_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+      rc=$?; tail -6 gpurun_out/smoke_$tag.log; fault gpurun_out/smoke_$tag.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
     bench)
       nb=$((nb+1)); out=gpurun_out/bench_$tag; [ $nb -gt 1 ] && out=${out}_$nb
       timeout -k 10 700 python bench.py $arg > $out.json 2> $out.err
-      rc=$?; [ $rc -ne 0 ] && { tail -8 $out.err; exit $rc; }
+      rc=$?; if [ $rc -ne 0 ]; then tail -8 $out.err; exit $rc; fi
       python scripts/bench_brief.py $out.json ;;
     profile) bash scripts/gpu_profile.sh $tag || exit 1 ;;
     timeline) timeout -k 10 300 python scripts/call_timeline.py $tag || exit 1 ;;
@@ -44,12 +44,12 @@ for step in "$@"; do
     kbench)
       IFS=, read -r kb kargs <<< "$arg"
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $KBENCH_FLAGS -o /tmp/$kb scripts/kbench/$kb.hip 2> gpurun_out/kbench_${kb}_build.err || { tail -5 gpurun_out/kbench_${kb}_build.err; exit 1; }
-      timeout -k 10 300 /tmp/$kb $kargs > gpurun_out/kbench_${kb}_$tag.log 2>&1
-      rc=$?; tail -40 gpurun_out/kbench_${kb}_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+      timeout -k 10 300 /tmp/$kb $kargs >> gpurun_out/kbench_${kb}_$tag.log 2>&1
+      rc=$?; tail -40 gpurun_out/kbench_${kb}_$tag.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
     py)
       IFS=, read -r sc pargs <<< "$arg"
       timeout -k 10 900 python $sc $pargs >> gpurun_out/py_$tag.log 2>&1
-      rc=$?; tail -30 gpurun_out/py_$tag.log; [ $rc -ne 0 ] && exit $rc ;;
+      rc=$?; tail -30 gpurun_out/py_$tag.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done

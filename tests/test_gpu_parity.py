@@ -940,14 +940,15 @@ def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, 
     # (N = 1000 and 1300 are 8 and 12 stages: the rounds of a workgroup are CHAINED there -- the next round's first units and planes
     #  are fetched behind the current round's epilogue, whatever the two rounds' tile counts; 2 stages keep the drained form)
     for name, env in (("staged", {"GPCA_GQ_DMA": "0"}), ("w4", {"GPCA_GQ_WAVES": "4"}), ("w8", {"GPCA_GQ_WAVES": "8"}), ("w12", {"GPCA_GQ_WAVES": "12"}),
-                      ("w4_unchained", {"GPCA_GQ_WAVES": "4", "GPCA_GQ_CHAIN": "0"}), ("default", {})):
+                      ("w4_unchained", {"GPCA_GQ_WAVES": "4", "GPCA_GQ_CHAIN": "0"}), ("w8_lockstep", {"GPCA_GQ_WAVES": "8", "GPCA_GQ_PHASE": "0"}),
+                      ("w12_phases", {"GPCA_GQ_WAVES": "12", "GPCA_GQ_PHASE": str(3 + (5 << 16))}), ("default", {})):
         with monkeypatch.context() as mp:
             for key, val in env.items():
                 mp.setenv(key, val)
             with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
                 e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 5, 2, seed=3)
                 res[name] = (e.eigenvalues().copy(), e.scores(f64=True).copy(), e.loadings().copy())
-    for name in ("w4", "w8", "w12", "w4_unchained", "default"):
+    for name in ("w4", "w8", "w12", "w4_unchained", "w8_lockstep", "w12_phases", "default"):
         for a, b in zip(res[name], res["staged"]):
             assert np.array_equal(a, b), name
     st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
