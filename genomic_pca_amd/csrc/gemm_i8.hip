@@ -16,6 +16,7 @@
 //                                             B = G^T tile: each lane loads 16 rows x 4 B and transposes the 16x4
 //                                             byte block in registers (32 v_perm_b32) into 4 k-contiguous operands
 #include "kernels.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace gpca {
@@ -316,6 +317,28 @@ Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves) {
     return p;
 }
 
+// flat decomposition (kernels.h): ngroups x S (n-group, stage) pairs cut into `grid` equal consecutive ranges
+Gtt8Plan gtt8_plan_flat(int64_t Mpad, int64_t Npad, int target_waves) {
+    Gtt8Plan p{};
+    p.flat = 1;
+    p.nblocks_n = Npad / 128;
+    p.ngroups = (p.nblocks_n + 3) / 4;
+    p.S = Mpad / 128;
+    const int64_t total = p.S * p.ngroups;
+    int64_t grid = target_waves / 8;                 // the default target (2 048) = 256 workgroups = one per CU of an MI355X
+    if (grid < 1) grid = 1;
+    // a segment's digit-plane sums live in i32 accumulators: at most 2^22 rows (32 768 stages) per workgroup range
+    const int64_t min_grid = (total + 32767) / 32768;
+    if (grid < min_grid) grid = min_grid;
+    if (grid > total) grid = total;
+    p.grid = grid;
+    p.rows_per_wave = ((total + grid - 1) / grid) * 128;      // (rows of the longest range: information only)
+    int64_t W = 1;
+    for (int64_t g = 0; g < p.ngroups; ++g) W = std::max<int64_t>(W, k2_last_wg(p.S, total, grid, g) - k2_first_wg(p.S, total, grid, g) + 1);
+    p.W = (int)W;
+    return p;
+}
+
 struct Gtt8Buf { int g[16]; i32x4 t[kDigits]; };
 
 template <int AUX>
@@ -467,13 +490,22 @@ void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, i
 // SPLIT = 8: the W slices are shared between 8 thread groups of a block (32 consecutive elements each) and folded through LDS --
 // for few samples the one-thread-per-element form leaves a handful of blocks walking W (thousands of) slices one load at a
 // time: 224 us per launch at 1 066 557 x 64 (configs[2]), 30 % of that call.  Same bits either way: the partial sums are integers.
+// how many of Ypart's W slices hold a partial tile for the elements of sample n: all of them (slice form), or the segments of the
+// workgroups whose ranges meet n's n-group (flat form, kernels.h)
+struct K2Fold { int W; int flat; int64_t S, total, grid; };
+static inline K2Fold k2_fold(const Gtt8Plan& p) { return K2Fold{p.W, p.flat, p.S, p.S * p.ngroups, p.grid}; }
+__device__ __forceinline__ int k2_slices_of(const K2Fold& f, int64_t n) {
+    if (!f.flat) return f.W;
+    const int64_t g = n >> 9;                        // n-group = 4 waves x 128 samples
+    return (int)(k2_last_wg(f.S, f.total, f.grid, g) - k2_first_wg(f.S, f.total, f.grid, g) + 1);
+}
 template <int SPLIT>
-__device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart, int W, int64_t stride, int64_t total, int64_t& e, bool& live) {
+__device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart, const K2Fold& f, int64_t stride, int64_t total, int64_t& e, bool& live) {
     if (SPLIT == 1) {
         e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         live = e < total;
         double s = 0.0;
-        if (live) for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
+        if (live) { const int W = k2_slices_of(f, e >> 5); for (int w = 0; w < W; ++w) s += Ypart[w * stride + e]; }
         return s;
     }
     __shared__ double part[256];
@@ -481,7 +513,7 @@ __device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart
     e = (int64_t)blockIdx.x * 32 + le;
     live = e < total;
     double s = 0.0;
-    if (live) for (int w = grp; w < W; w += 8) s += Ypart[w * stride + e];
+    if (live) { const int W = k2_slices_of(f, e >> 5); for (int w = grp; w < W; w += 8) s += Ypart[w * stride + e]; }
     part[threadIdx.x] = s;
     __syncthreads();
     if (grp != 0) { live = false; return 0.0; }
@@ -490,31 +522,32 @@ __device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart
     return s;
 }
 template <int SPLIT>
-__global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
+__global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, K2Fold f, int64_t Npad, int64_t N,
                                                      const double* __restrict__ cvec, const double* __restrict__ tscale,
                                                      double* __restrict__ Y, int64_t ldy) {
     int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
+    const double s = reduce_slices<SPLIT>(Ypart, f, Npad * 32, N * 32, e, live);
     if (!live) return;
     const int j = (int)(e & 31);
     Y[(e >> 5) * ldy + j] = fma(tscale[j], s, cvec[j]);   // one rounding, the same in k_finish_y_i8
 }
 // one thread per element while that still fills the chip (>= 1024 blocks), 8 threads per element below
 static inline bool reduce_split(int64_t total) { return total < (int64_t)256 * 1024; }
-void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
+void launch_reduce_y_i8(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, const double* c,
                         const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
-    if (reduce_split(total)) hipLaunchKernelGGL(k_reduce_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
-    else hipLaunchKernelGGL(k_reduce_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
+    const K2Fold f = k2_fold(plan);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_reduce_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, f, Npad, N, c, tscale, Y, ldy);
+    else hipLaunchKernelGGL(k_reduce_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, f, Npad, N, c, tscale, Y, ldy);
 }
 
 // Streamed panels: the integer partial sums of every panel are added into Yint (exact in f64 while |sum| < 2^53, so the
 // order of the panels does not matter) and scaled once at the end -- the same value, bit for bit, as the one-launch reduce.
 template <int SPLIT>
-__global__ __launch_bounds__(256) void k_accum_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
+__global__ __launch_bounds__(256) void k_accum_y_i8(const double* __restrict__ Ypart, K2Fold f, int64_t Npad, int64_t N,
                                                     double* __restrict__ Yint, int first) {
     int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
+    const double s = reduce_slices<SPLIT>(Ypart, f, Npad * 32, N * 32, e, live);
     if (!live) return;
     Yint[e] = first ? s : Yint[e] + s;
 }
@@ -525,10 +558,11 @@ __global__ __launch_bounds__(256) void k_finish_y_i8(const double* __restrict__ 
     const int j = (int)(e & 31);
     Y[(e >> 5) * ldy + j] = fma(tscale[j], Yint[e], cvec[j]);
 }
-void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first) {
+void launch_accum_y_i8(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, double* Yint, int first) {
     const int64_t total = N * 32;
-    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
-    else hipLaunchKernelGGL(k_accum_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
+    const K2Fold f = k2_fold(plan);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, f, Npad, N, Yint, first);
+    else hipLaunchKernelGGL(k_accum_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, f, Npad, N, Yint, first);
 }
 void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
@@ -537,10 +571,10 @@ void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const dou
 // Fused streamed power iteration: every panel quantises its rows of T' against its OWN column maximum, so its integer sums carry
 // their own scale: Yacc[n][j] (+)= tscale_p[j] * sum_w Ypart[w][n][j]  (exact integer sum, one fma per panel, fixed panel order).
 template <int SPLIT>
-__global__ __launch_bounds__(256) void k_accum_y_scaled(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
+__global__ __launch_bounds__(256) void k_accum_y_scaled(const double* __restrict__ Ypart, K2Fold f, int64_t Npad, int64_t N,
                                                         const double* __restrict__ tscale, double* __restrict__ Yacc, int first) {
     int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
+    const double s = reduce_slices<SPLIT>(Ypart, f, Npad * 32, N * 32, e, live);
     if (!live) return;
     Yacc[e] = fma(tscale[e & 31], s, first ? 0.0 : Yacc[e]);
 }
@@ -550,10 +584,11 @@ __global__ __launch_bounds__(256) void k_finish_y_sum(const double* __restrict__
     if (e >= N * 32) return;
     Y[(e >> 5) * ldy + (e & 31)] = cvec[e & 31] + Yacc[e];
 }
-void launch_accum_y_scaled(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first) {
+void launch_accum_y_scaled(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first) {
     const int64_t total = N * 32;
-    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_scaled<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
-    else hipLaunchKernelGGL(k_accum_y_scaled<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
+    const K2Fold f = k2_fold(plan);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_scaled<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, f, Npad, N, tscale, Yacc, first);
+    else hipLaunchKernelGGL(k_accum_y_scaled<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, f, Npad, N, tscale, Yacc, first);
 }
 void launch_finish_y_sum(hipStream_t st, const double* Yacc, int64_t N, const double* c, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
@@ -1489,9 +1524,12 @@ __device__ __forceinline__ void gttx_load_g(GttXG<PACKED>& b, __amdgpu_buffer_rs
     for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ldr, PACKED ? 0 : GPCA_GTTX_AUX);
 }
 // decode micro-step m (0..15) of the next block's operands
-template <bool PACKED>
+// ABL (scripts/kbench/kbench_gtd.hip only; 0 in the product): bit0 no transpose (the dwords as loaded are the operands), bit1 the T' planes
+// are fetched once, bit2 no genotype refills, bit3 no MFMA, bit4 no Ypart stores
+template <bool PACKED, int ABL = 0>
 __device__ __forceinline__ void gttx_decode_step(const GttXG<PACKED>& bn, Gtt2Ops& on, unsigned (&x)[4], unsigned (&y)[4], int m, unsigned bsh) {
     const int w = m >> 2, ph = m & 3;
+    if (ABL & 1) { on.bt[ph][w] = (int)bn.g[4 * w + ph]; return; }
     if (PACKED) {
         if (ph == 0) x[w] = ((bn.g[4 * w] >> bsh) & 0xffu) | (((bn.g[4 * w + 1] >> bsh) & 0xffu) << 8) |
                             (((bn.g[4 * w + 2] >> bsh) & 0xffu) << 16) | ((bn.g[4 * w + 3] >> bsh) << 24);
@@ -1521,7 +1559,7 @@ __device__ __forceinline__ void gttx_decode(const GttXG<PACKED>& b, Gtt2Ops& o, 
 struct GttXT { i32x4 t[kDigits]; };
 // the 16 MFMAs of the current block; after each one a micro-step of the next block's decode, and (first four slots) the
 // LDS reads of the next block's digit operands
-template <bool PACKED, int ND = kDigits>
+template <bool PACKED, int ND = kDigits, int ABL = 0>
 __device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i32x16 (&acc)[4][kDigits],
                                            const GttXG<PACKED>& gn, Gtt2Ops& on, GttXT& tn, const i32x4* lds_next, unsigned bsh) {
     unsigned x[4], y[4];
@@ -1529,10 +1567,11 @@ __device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i
     for (int d = 0; d < kDigits; ++d)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (d < ND) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tc.t[d], oc.bt[t], acc[t][d], 0, 0, 0);   // (three-plane mode: the last four slots carry only decode work)
+            if (ABL & 8) { if (d < ND) acc[t][d][0] ^= tc.t[d][t] ^ oc.bt[t][d]; }
+            else if (d < ND) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tc.t[d], oc.bt[t], acc[t][d], 0, 0, 0);   // (three-plane mode: the last four slots carry only decode work)
             const int m = d * 4 + t;
             if (m < ND) tn.t[m] = lds_next[m * 64];
-            gttx_decode_step<PACKED>(gn, on, x, y, m, bsh);
+            gttx_decode_step<PACKED, ABL>(gn, on, x, y, m, bsh);
             __builtin_amdgcn_sched_barrier(0);
         }
 }
@@ -1685,32 +1724,35 @@ __device__ __forceinline__ void gtd_read_g(GttXG<false>& b, const char* unit) {
     for (int i = 0; i < 16; ++i) b.g[i] = *reinterpret_cast<const unsigned*>(unit + i * 128);
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Mpad, int64_t Npad,
-                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t ngroups, int64_t rows_per_wave, int xcd_remap) {
-    extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
-    GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    // workgroup b runs on XCD b % 8: give the workgroups of one XCD consecutive virtual ids, so that the n-groups that
-    // share a row chunk (and its T' planes) run behind one L2
+#if GPCA_STAMP
+__device__ unsigned long long g_gtd_stamp[2 * 4096];      // s_memrealtime at the start and at the end of every workgroup of k_gtt_d
+#endif
+// this workgroup's consecutive range of the flat (n-group, stage) order (kernels.h): at most two segments when ngroups <= grid
+struct K2Range { int64_t a, b, S, total, v; };
+__device__ __forceinline__ K2Range k2_range(int64_t S, int64_t ngroups, int xcd_remap) {
+    // workgroup b runs on XCD b % 8: give the workgroups of one XCD consecutive virtual ids, so that the ranges that share an n-group's
+    // rows (and the T' planes of those rows) run behind one L2
     int64_t vb = blockIdx.x;
     if (xcd_remap) {
         const int64_t q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
         vb = x * q + (x < r ? x : r) + blockIdx.x / 8;
     }
-    const int64_t ngroup = vb % ngroups;
-    const int64_t wchunk = vb / ngroups;
-    const int64_t nblock = ngroup * 4 + wv;
-    int64_t n0 = nblock * 128;
+    K2Range k;
+    k.S = S; k.total = S * ngroups; k.v = vb;
+    k.a = (vb * k.total) / gridDim.x; k.b = ((vb + 1) * k.total) / gridDim.x;
+    return k;
+}
+
+// one segment: stages [s0, s0 + nstage) of n-group g -> partial tile `slice` of that n-group
+template <int NT, int ABL>
+__device__ __forceinline__ void gtd_segment(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Npad, const int8_t* __restrict__ Td,
+                                            double* __restrict__ Ypart, GqdSmem* sm, int wv, int lane, int c, int h,
+                                            int64_t g, int64_t s0, int64_t nstage, int64_t slice) {
+    int64_t n0 = (g * 4 + wv) * 128;
     const bool live = n0 < Npad;          // a dead wave (ragged last group) still moves planes and joins the barriers
     if (!live) n0 = 0;
-    const int64_t m_begin = wchunk * rows_per_wave;
-    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
-    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
-    const int64_t nstage = kblocks >> 2;
+    const int64_t m_begin = s0 * 128;
+    const int64_t kblocks = nstage * 4;
 
     i32x16 acc[4][kDigits];
 #pragma unroll
@@ -1759,9 +1801,9 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
         gqd_wait_vm<W>();                                                                                \
         gtd_read_g(GR, gl + s2_ * 4096u);                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
-        gttx_phase<false>(TC, OC, acc, GN, ON, TN, &tds[(TSLOT)][(TBLK)][0][lane], 0u);                  \
+        gttx_phase<false, kDigits, ABL>(TC, OC, acc, GN, ON, TN, &tds[(TSLOT)][(TBLK)][0][lane], 0u);    \
         __builtin_amdgcn_sched_barrier(0);                                                               \
-        gtd_issue_g<NT>(gp, ldr, ib, kblocks, lds_g + s1 * 4096u, gvo);                                  \
+        if (!(ABL & 4)) gtd_issue_g<NT>(gp, ldr, ib, kblocks, lds_g + s1 * 4096u, gvo);                  \
         ++ib; s1 = s2_;                                                                                  \
     }
     for (int64_t st = 0; st < nstage; ++st) {
@@ -1770,13 +1812,14 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
         GTD_PHASE(TB, OB, GA, OA, TA, GB, 20, slot, 2)
         GTD_PHASE(TA, OA, GB, OB, TB, GA, 20, slot, 3)
         asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");   // T'(st+1) visible; everyone is done with T'(st)
-        gtd_issue_t(tp, st + 2, nstage, lds_t + (uint32_t)slot * 4u * TKB, tvo);
+        if (!(ABL & 2)) gtd_issue_t(tp, st + 2, nstage, lds_t + (uint32_t)slot * 4u * TKB, tvo);
         GTD_PHASE(TB, OB, GA, OA, TA, GB, 24, slot ^ 1, 0)
     }
 #undef GTD_PHASE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after this workgroup's LDS is released
-    if (!live) return;
-    double* yp = Ypart + (wchunk * Npad) * 32;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after this segment (next prologue, or the LDS is released)
+    if (!live || ((ABL & 16) && acc[0][0][0] != 0x7fffffff)) return;
+    // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h, col = c -> sample n0 + 4c + t.  Exact integers as f64.
+    double* yp = Ypart + (slice * Npad) * 32;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int64_t n = n0 + 4 * c + t;
@@ -1788,6 +1831,33 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
             *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
         }
     }
+}
+
+template <int NT, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Npad,
+                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
+                                                   int64_t S, int64_t ngroups, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
+    GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+#if GPCA_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtd_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const K2Range k = k2_range(S, ngroups, xcd_remap);
+    int64_t a = k.a;
+    bool first = true;
+    while (a < k.b) {
+        const int64_t g = a / S, s0 = a - g * S;
+        const int64_t len = (S - s0 < k.b - a) ? S - s0 : k.b - a;
+        if (!first) asm volatile("s_barrier" ::: "memory");     // every wave has left the previous segment: the plane slots are free
+        gtd_segment<NT, ABL>(Gb, ldr, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, len, k.v - k2_first_wg(S, k.total, gridDim.x, g));
+        a += len; first = false;
+    }
+#if GPCA_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtd_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ================================================================================================
@@ -1804,26 +1874,11 @@ struct GtpStage { i32x4 t[4][kDigits][64]; char g[4][4096]; };     // 16 KiB of 
 struct GtpSmem { GtpStage stg[4]; };
 
 template <int ND>
-__global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Mpad, int64_t Npad,
-                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t ngroups, int64_t rows_per_wave, int xcd_remap) {
-    extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
-    GtpSmem* sm = reinterpret_cast<GtpSmem*>(gqd_smem);
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    int64_t vb = blockIdx.x;           // XCD-aware order: the n-groups of a row chunk (same T' planes) behind one L2
-    if (xcd_remap) {
-        const int64_t q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
-        vb = x * q + (x < r ? x : r) + blockIdx.x / 8;
-    }
-    const int64_t ngroup = vb % ngroups;
-    const int64_t wchunk = vb / ngroups;
-    const int64_t n0 = (ngroup * 4 + wv) * 128;          // Npad is a multiple of 1024 in packed mode: every wave is live
-    const int64_t m_begin = wchunk * rows_per_wave;
-    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
-    const int64_t kblocks = (m_end - m_begin) >> 5;      // multiple of 4
-    const int64_t nstage = kblocks >> 2;
+__device__ __forceinline__ void gtp_segment(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Npad, const int8_t* __restrict__ Td,
+                                            double* __restrict__ Ypart, GtpSmem* sm, int wv, int lane, int c, int h,
+                                            int64_t g, int64_t s0, int64_t nstage, int64_t slice) {
+    const int64_t n0 = (g * 4 + wv) * 128;               // Npad is a multiple of 1024 in packed mode: every wave is live
+    const int64_t m_begin = s0 * 128;
 
     i32x16 acc[4][kDigits];
 #pragma unroll
@@ -1834,7 +1889,7 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
             for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
 
     constexpr uint32_t TKB = kDigits * 1024;
-    const uint8_t* gp = G2 + m_begin * ld2 + ngroup * 128;         // the n-group's 128-byte column of the row chunk
+    const uint8_t* gp = G2 + m_begin * ld2 + g * 128;              // the n-group's 128-byte column of the row range
     const int8_t* tp = Td + (m_begin >> 5) * TKB + wv * 1024;      // this wave's plane
     const uint32_t gvo = (uint32_t)(8 * wv + (lane >> 3)) * (uint32_t)ld2 + 16u * (uint32_t)(lane & 7);
     const uint32_t tvo = (uint32_t)(lane * 16);
@@ -1884,19 +1939,19 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
         __builtin_amdgcn_sched_barrier(0);                                                               \
     }
     for (int64_t st = 0; st < nstage; ++st) {
-        const uint32_t s0 = (uint32_t)(st & 3), sn = (uint32_t)((st + 1) & 3);
+        const uint32_t q0 = (uint32_t)(st & 3), qn = (uint32_t)((st + 1) & 3);
         if (st > 0) {
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage st+1 landed; everyone is done with stage st-1
             issue_stage(st + 3, (uint32_t)((st + 3) & 3));
         }
-        GTP_PHASE(TA, OA, GB, OB, TB, GA, s0, 1, s0, 2)
-        GTP_PHASE(TB, OB, GA, OA, TA, GB, s0, 2, s0, 3)
-        GTP_PHASE(TA, OA, GB, OB, TB, GA, s0, 3, sn, 0)
-        GTP_PHASE(TB, OB, GA, OA, TA, GB, sn, 0, sn, 1)
+        GTP_PHASE(TA, OA, GB, OB, TB, GA, q0, 1, q0, 2)
+        GTP_PHASE(TB, OB, GA, OA, TA, GB, q0, 2, q0, 3)
+        GTP_PHASE(TA, OA, GB, OB, TB, GA, q0, 3, qn, 0)
+        GTP_PHASE(TB, OB, GA, OA, TA, GB, qn, 0, qn, 1)
     }
 #undef GTP_PHASE
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // no DMA may land after this workgroup's LDS is released
-    double* yp = Ypart + (wchunk * Npad) * 32;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // no DMA may land after this segment; every wave has left the ring
+    double* yp = Ypart + (slice * Npad) * 32;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int64_t n = n0 + 4 * c + t;
@@ -1910,27 +1965,42 @@ __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2
     }
 }
 
+template <int ND>
+__global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Npad,
+                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
+                                                   int64_t S, int64_t ngroups, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
+    GtpSmem* sm = reinterpret_cast<GtpSmem*>(gqd_smem);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const K2Range k = k2_range(S, ngroups, xcd_remap);
+    int64_t a = k.a;
+    while (a < k.b) {
+        const int64_t g = a / S, s0 = a - g * S;
+        const int64_t len = (S - s0 < k.b - a) ? S - s0 : k.b - a;
+        gtp_segment<ND>(G2, ld2, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, len, k.v - k2_first_wg(S, k.total, gridDim.x, g));
+        a += len;
+    }
+}
+
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, int nd, const KernelOpts& ko) {
     // stages of 128 SNP rows, 1 024-sample row padding of the packed store (its DMA pieces are whole 128-byte lines of codes)
-    if (!dma_shape_ok(Npad, kSamplePad2bit, Mpad, kGQRowsPerWave) || ld2 * 4 < Npad) return (int)hipErrorInvalidValue;
-    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    if (!plan.flat || plan.S * 128 != Mpad || !dma_shape_ok(Npad, kSamplePad2bit, Mpad, kGQRowsPerWave) || ld2 * 4 < Npad) return (int)hipErrorInvalidValue;
     const int remap = ko.gtt_xcd;
-    if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
-                                    plan.rows_per_wave, remap);
-    else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
-                            plan.rows_per_wave, remap);
+    if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
+    else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
     return 0;
 }
 
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, const KernelOpts& ko) {
-    if (!dma_shape_ok(Npad, 256, Mpad, kGQRowsPerWave) || ldg < Npad) return (int)hipErrorInvalidValue;   // 128-row stages, 256-sample pitch
-    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
+    if (!plan.flat || plan.S * 128 != Mpad || !dma_shape_ok(Npad, 256, Mpad, kGQRowsPerWave) || ldg < Npad) return (int)hipErrorInvalidValue;   // 128-row stages, 256-sample pitch
     const dim3 grid((unsigned)plan.grid), blk(256);
     const int remap = ko.gtt_xcd;   // measured 5.10 -> 5.00 ms per step
-    if (ko.dma_nt) hipLaunchKernelGGL(k_gtt_d<1>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
-    else hipLaunchKernelGGL(k_gtt_d<0>, grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
+    if (ko.dma_nt) hipLaunchKernelGGL((k_gtt_d<1>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
+    else hipLaunchKernelGGL((k_gtt_d<0>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
     return 0;
 }
 

@@ -1,0 +1,83 @@
+// Where a launch of the int8-resident K2 (k_gtt_d: Y^T tiles = T'^T G by LDS-DMA) spends its time.  The product source compiled with
+// GPCA_STAMP=1 and the kernel instantiated with ablation bits (gemm_i8.hip, ABL): bit0 no byte transpose, bit1 T' planes fetched once,
+// bit2 no genotype refills (no HBM stream), bit3 no MFMA, bit4 no Ypart stores.  All variants run round-robin in ONE process (run-to-run
+// noise of these kernels is +-2 %).  Not product code.
+//   hipcc --offload-arch=gfx950 -O3 -DGPCA_STAMP=1 -o kbench_gtd kbench_gtd.hip && ./kbench_gtd [M N reps W]
+#ifndef GPCA_STAMP
+#define GPCA_STAMP 1
+#endif
+#include "../../genomic_pca_amd/csrc/gemm_i8.hip"
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+__global__ void k_fill(uint32_t* p, int64_t n, uint32_t seed, uint32_t mask) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+        p[i] = x & mask;
+    }
+}
+template <int ABL>
+static void launch(const int8_t* G, int64_t ld8, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Yp, const gpca::Gtt8Plan& plan, int remap) {
+    hipLaunchKernelGGL((gpca::k_gtt_d<1, ABL>), dim3((unsigned)plan.grid), dim3(256), sizeof(gpca::GqdSmem), 0, (const uint8_t*)G, ld8, Npad, Td, Yp, plan.S,
+                       plan.ngroups, remap);
+}
+template <int ABL>
+static int opt_in() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gpca::k_gtt_d<1, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(gpca::GqdSmem));
+}
+int main(int argc, char** argv) {
+    const int64_t M = argc > 1 ? atoll(argv[1]) : 1000064, N = argc > 2 ? atoll(argv[2]) : 10000;
+    const int reps = argc > 3 ? atoi(argv[3]) : 4;
+    const int target = argc > 4 ? atoi(argv[4]) : 2048;
+    const int64_t Npad = (N + 255) / 256 * 256, ld8 = ((Npad / 256) % 2 == 0) ? Npad + 256 : Npad, Mpad = (M + 127) / 128 * 128;
+    int8_t* G; int8_t* Td; double* Yp;
+    const gpca::Gtt8Plan plan = gpca::gtt8_plan_flat(Mpad, Npad, target);
+    CK(hipMalloc(&G, Mpad * ld8)); CK(hipMalloc(&Td, Mpad * 32 * 4)); CK(hipMalloc(&Yp, (size_t)(plan.W + 2) * Npad * 32 * 8));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G, Mpad * ld8 / 4, 1u, 0x01010101u);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)Td, Mpad * 32, 2u, 0x3f3f3f3fu);
+    if (opt_in<0>() || opt_in<1>() || opt_in<2>() || opt_in<4>() || opt_in<8>() || opt_in<9>() || opt_in<16>() || opt_in<12>() || opt_in<7>()) { printf("LDS opt-in failed\n"); return 1; }
+    struct V { const char* name; void (*fn)(const int8_t*, int64_t, int64_t, int64_t, const int8_t*, double*, const gpca::Gtt8Plan&, int); int remap; };
+    const V vs[] = {{"full kernel", launch<0>, 1}, {"no XCD remap", launch<0>, 0}, {"no byte transpose", launch<1>, 1}, {"T' planes fetched once", launch<2>, 1},
+                    {"no genotype refills (no HBM stream)", launch<4>, 1}, {"no MFMA", launch<8>, 1}, {"no MFMA, no transpose", launch<9>, 1},
+                    {"no Ypart stores", launch<16>, 1}, {"no refills, no MFMA (LDS reads + decode only)", launch<12>, 1},
+                    {"no transpose, planes once, no refills (MFMA + LDS reads)", launch<7>, 1}};
+    const int nv = (int)(sizeof vs / sizeof vs[0]);
+    std::vector<std::vector<double>> ms(nv);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int it = 0; it < 10; ++it) vs[0].fn(G, ld8, Mpad, Npad, Td, Yp, plan, 1);
+    CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < reps; ++rep)
+        for (int v = 0; v < nv; ++v) {
+            vs[v].fn(G, ld8, Mpad, Npad, Td, Yp, plan, vs[v].remap);
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 10; ++it) vs[v].fn(G, ld8, Mpad, Npad, Td, Yp, plan, vs[v].remap);
+            (void)hipEventRecord(e1); CK(hipEventSynchronize(e1));
+            float t; (void)hipEventElapsedTime(&t, e0, e1);
+            ms[v].push_back(t / 10);
+        }
+    printf("k_gtt_d %lld x %lld (pitch %lld): %lld workgroups, flat ranges of <= %lld stages over %lld n-groups x %lld stages (<= %d partial tiles per n-group); %d x 10 launches per variant, round-robin\n",
+           (long long)M, (long long)N, (long long)ld8, (long long)plan.grid, (long long)(plan.rows_per_wave / 128), (long long)plan.ngroups, (long long)plan.S, plan.W, reps);
+    for (int v = 0; v < nv; ++v) {
+        std::vector<double> x = ms[v]; std::sort(x.begin(), x.end());
+        double m = 0; for (double y : x) m += y; m /= x.size();
+        printf("  %-58s mean %.4f ms (min %.4f max %.4f) = %.2f TB/s of genotype bytes\n", vs[v].name, m, x.front(), x.back(), (double)M * N / (m * 1e-3) / 1e12);
+    }
+    // the full kernel once more for its stamps: spans of the workgroups, and when the second batch (grid > 256 CUs) starts
+    vs[0].fn(G, ld8, Mpad, Npad, Td, Yp, plan, 1);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(2 * 4096);
+    CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(gpca::g_gtd_stamp), st.size() * 8));
+    const int nb = (int)std::min<int64_t>(plan.grid, 4096);
+    unsigned long long s0 = ~0ull, e1x = 0;
+    for (int b = 0; b < nb; ++b) { s0 = std::min(s0, st[2 * b]); e1x = std::max(e1x, st[2 * b + 1]); }
+    std::vector<double> dur, start, end;
+    for (int b = 0; b < nb; ++b) { dur.push_back((st[2 * b + 1] - st[2 * b]) * 0.01); start.push_back((st[2 * b] - s0) * 0.01); end.push_back((st[2 * b + 1] - s0) * 0.01); }
+    std::vector<double> d2 = dur, s2 = start, e2 = end;
+    std::sort(d2.begin(), d2.end()); std::sort(s2.begin(), s2.end()); std::sort(e2.begin(), e2.end());
+    printf("  workgroup spans: min %.1f median %.1f max %.1f us; launch (first start -> last end) %.1f us\n", d2.front(), d2[nb / 2], d2.back(), (e1x - s0) * 0.01);
+    printf("  start times: 256th workgroup %.1f us, 257th %.1f us, last %.1f us; end times: first %.1f, median %.1f, last %.1f us\n", s2[std::min(255, nb - 1)],
+           nb > 256 ? s2[256] : -1.0, s2.back(), e2.front(), e2[nb / 2], e2.back());
+    return 0;
+}
