@@ -298,7 +298,7 @@ int launch_gq_n(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
 // K2
 // ------------------------------------------------------------------------------------------------
 Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves) {
-    Gtt8Plan p;
+    Gtt8Plan p{};
     p.nblocks_n = Npad / 128;
     int64_t W = target_waves / p.nblocks_n;
     if (W < 1) W = 1;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G,
 
 // K2 for at most 256 samples (int8 rows): plan = gtt8_plan_narrow; every wave owns a row chunk of its own
 Gtt8Plan gtt8_plan_narrow(int64_t Mpad, int64_t N, int target_waves) {
-    Gtt8Plan p;
+    Gtt8Plan p{};
     p.nblocks_n = (N + 127) / 128;                      // 128-sample blocks that hold samples: 1 or 2
     int64_t W = target_waves / p.nblocks_n;
     if (W < 1) W = 1;
