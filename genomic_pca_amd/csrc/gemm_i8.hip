@@ -317,25 +317,34 @@ Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves) {
     return p;
 }
 
-// flat decomposition (kernels.h): ngroups x S (n-group, stage) pairs cut into `grid` equal consecutive ranges
-Gtt8Plan gtt8_plan_flat(int64_t Mpad, int64_t Npad, int target_waves) {
+// several consecutive (row chunk, n-group) tasks per workgroup (kernels.h): W row chunks such that one batch of `grid0` workgroups
+// covers the tasks evenly.  Cost model per candidate W, relative to the bytes of one sweep: batch fill (tasks rounded up to whole
+// workgroup loads), ~3 stages of prologue / drain / tile store per task, the fold's read of W partial tiles, and 2 % when a row chunk's
+// T' planes (16 KiB per stage) outgrow the share of an XCD's L2 they can expect to keep.
+Gtt8Plan gtt8_plan_batched(int64_t Mpad, int64_t Npad, int target_waves) {
     Gtt8Plan p{};
-    p.flat = 1;
     p.nblocks_n = Npad / 128;
     p.ngroups = (p.nblocks_n + 3) / 4;
     p.S = Mpad / 128;
-    const int64_t total = p.S * p.ngroups;
-    int64_t grid = target_waves / 8;                 // the default target (2 048) = 256 workgroups = one per CU of an MI355X
-    if (grid < 1) grid = 1;
-    // a segment's digit-plane sums live in i32 accumulators: at most 2^22 rows (32 768 stages) per workgroup range
-    const int64_t min_grid = (total + 32767) / 32768;
-    if (grid < min_grid) grid = min_grid;
-    if (grid > total) grid = total;
-    p.grid = grid;
-    p.rows_per_wave = ((total + grid - 1) / grid) * 128;      // (rows of the longest range: information only)
-    int64_t W = 1;
-    for (int64_t g = 0; g < p.ngroups; ++g) W = std::max<int64_t>(W, k2_last_wg(p.S, total, grid, g) - k2_first_wg(p.S, total, grid, g) + 1);
-    p.W = (int)W;
+    int64_t grid0 = target_waves / 8;                // the default target (2 048) = 256 workgroups = one per CU of an MI355X
+    if (grid0 < 1) grid0 = 1;
+    // a task's digit-plane sums live in i32 accumulators: at most 2^22 rows (32 768 stages) per task
+    const int64_t wmin = std::max<int64_t>(1, (p.S + 32767) / 32768), wmax = std::min<int64_t>(p.S, 1024);
+    double best = 1e300;
+    int64_t bestW = wmin;
+    for (int64_t W = wmin; W <= std::max(wmin, wmax); ++W) {
+        const int64_t T = W * p.ngroups, k = (T + grid0 - 1) / grid0;
+        double f = (double)(k * grid0) / (double)T;                                      // batch fill: k tasks per workgroup against T / grid0
+        f *= 1.0 + 3.0 * (double)W / (double)p.S;                                        // per-task prologue / drain / store
+        f += (double)W * 256.0 / (double)Mpad;                                           // the fold reads W x Npad x 256 B against Mpad x Npad
+        if ((double)p.S / (double)W * 16384.0 > 3.0 * 1048576.0) f += 0.02;               // T' planes of a row chunk vs L2
+        if (f < best - 1e-12) { best = f; bestW = W; }
+    }
+    p.W = (int)bestW;
+    const int64_t T = bestW * p.ngroups;
+    p.tasks_per_wg = (int)((T + grid0 - 1) / grid0);
+    p.grid = (T + p.tasks_per_wg - 1) / p.tasks_per_wg;
+    p.rows_per_wave = ((p.S + bestW - 1) / bestW) * 128;      // rows of the longest task
     return p;
 }
 
@@ -490,22 +499,13 @@ void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, i
 // SPLIT = 8: the W slices are shared between 8 thread groups of a block (32 consecutive elements each) and folded through LDS --
 // for few samples the one-thread-per-element form leaves a handful of blocks walking W (thousands of) slices one load at a
 // time: 224 us per launch at 1 066 557 x 64 (configs[2]), 30 % of that call.  Same bits either way: the partial sums are integers.
-// how many of Ypart's W slices hold a partial tile for the elements of sample n: all of them (slice form), or the segments of the
-// workgroups whose ranges meet n's n-group (flat form, kernels.h)
-struct K2Fold { int W; int flat; int64_t S, total, grid; };
-static inline K2Fold k2_fold(const Gtt8Plan& p) { return K2Fold{p.W, p.flat, p.S, p.S * p.ngroups, p.grid}; }
-__device__ __forceinline__ int k2_slices_of(const K2Fold& f, int64_t n) {
-    if (!f.flat) return f.W;
-    const int64_t g = n >> 9;                        // n-group = 4 waves x 128 samples
-    return (int)(k2_last_wg(f.S, f.total, f.grid, g) - k2_first_wg(f.S, f.total, f.grid, g) + 1);
-}
 template <int SPLIT>
-__device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart, const K2Fold& f, int64_t stride, int64_t total, int64_t& e, bool& live) {
+__device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart, int W, int64_t stride, int64_t total, int64_t& e, bool& live) {
     if (SPLIT == 1) {
         e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         live = e < total;
         double s = 0.0;
-        if (live) { const int W = k2_slices_of(f, e >> 5); for (int w = 0; w < W; ++w) s += Ypart[w * stride + e]; }
+        if (live) for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
         return s;
     }
     __shared__ double part[256];
@@ -513,7 +513,7 @@ __device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart
     e = (int64_t)blockIdx.x * 32 + le;
     live = e < total;
     double s = 0.0;
-    if (live) { const int W = k2_slices_of(f, e >> 5); for (int w = grp; w < W; w += 8) s += Ypart[w * stride + e]; }
+    if (live) for (int w = grp; w < W; w += 8) s += Ypart[w * stride + e];
     part[threadIdx.x] = s;
     __syncthreads();
     if (grp != 0) { live = false; return 0.0; }
@@ -522,32 +522,31 @@ __device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart
     return s;
 }
 template <int SPLIT>
-__global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, K2Fold f, int64_t Npad, int64_t N,
+__global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
                                                      const double* __restrict__ cvec, const double* __restrict__ tscale,
                                                      double* __restrict__ Y, int64_t ldy) {
     int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, f, Npad * 32, N * 32, e, live);
+    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
     if (!live) return;
     const int j = (int)(e & 31);
     Y[(e >> 5) * ldy + j] = fma(tscale[j], s, cvec[j]);   // one rounding, the same in k_finish_y_i8
 }
 // one thread per element while that still fills the chip (>= 1024 blocks), 8 threads per element below
 static inline bool reduce_split(int64_t total) { return total < (int64_t)256 * 1024; }
-void launch_reduce_y_i8(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, const double* c,
+void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
                         const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
-    const K2Fold f = k2_fold(plan);
-    if (reduce_split(total)) hipLaunchKernelGGL(k_reduce_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, f, Npad, N, c, tscale, Y, ldy);
-    else hipLaunchKernelGGL(k_reduce_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, f, Npad, N, c, tscale, Y, ldy);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_reduce_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
+    else hipLaunchKernelGGL(k_reduce_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
 }
 
 // Streamed panels: the integer partial sums of every panel are added into Yint (exact in f64 while |sum| < 2^53, so the
 // order of the panels does not matter) and scaled once at the end -- the same value, bit for bit, as the one-launch reduce.
 template <int SPLIT>
-__global__ __launch_bounds__(256) void k_accum_y_i8(const double* __restrict__ Ypart, K2Fold f, int64_t Npad, int64_t N,
+__global__ __launch_bounds__(256) void k_accum_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
                                                     double* __restrict__ Yint, int first) {
     int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, f, Npad * 32, N * 32, e, live);
+    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
     if (!live) return;
     Yint[e] = first ? s : Yint[e] + s;
 }
@@ -558,11 +557,10 @@ __global__ __launch_bounds__(256) void k_finish_y_i8(const double* __restrict__ 
     const int j = (int)(e & 31);
     Y[(e >> 5) * ldy + j] = fma(tscale[j], Yint[e], cvec[j]);
 }
-void launch_accum_y_i8(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, double* Yint, int first) {
+void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first) {
     const int64_t total = N * 32;
-    const K2Fold f = k2_fold(plan);
-    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, f, Npad, N, Yint, first);
-    else hipLaunchKernelGGL(k_accum_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, f, Npad, N, Yint, first);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
+    else hipLaunchKernelGGL(k_accum_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
 }
 void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
@@ -571,10 +569,10 @@ void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const dou
 // Fused streamed power iteration: every panel quantises its rows of T' against its OWN column maximum, so its integer sums carry
 // their own scale: Yacc[n][j] (+)= tscale_p[j] * sum_w Ypart[w][n][j]  (exact integer sum, one fma per panel, fixed panel order).
 template <int SPLIT>
-__global__ __launch_bounds__(256) void k_accum_y_scaled(const double* __restrict__ Ypart, K2Fold f, int64_t Npad, int64_t N,
+__global__ __launch_bounds__(256) void k_accum_y_scaled(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
                                                         const double* __restrict__ tscale, double* __restrict__ Yacc, int first) {
     int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, f, Npad * 32, N * 32, e, live);
+    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
     if (!live) return;
     Yacc[e] = fma(tscale[e & 31], s, first ? 0.0 : Yacc[e]);
 }
@@ -584,11 +582,10 @@ __global__ __launch_bounds__(256) void k_finish_y_sum(const double* __restrict__
     if (e >= N * 32) return;
     Y[(e >> 5) * ldy + (e & 31)] = cvec[e & 31] + Yacc[e];
 }
-void launch_accum_y_scaled(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first) {
+void launch_accum_y_scaled(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first) {
     const int64_t total = N * 32;
-    const K2Fold f = k2_fold(plan);
-    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_scaled<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, f, Npad, N, tscale, Yacc, first);
-    else hipLaunchKernelGGL(k_accum_y_scaled<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, f, Npad, N, tscale, Yacc, first);
+    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_scaled<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
+    else hipLaunchKernelGGL(k_accum_y_scaled<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
 }
 void launch_finish_y_sum(hipStream_t st, const double* Yacc, int64_t N, const double* c, double* Y, int64_t ldy) {
     const int64_t total = N * 32;
@@ -1727,20 +1724,15 @@ __device__ __forceinline__ void gtd_read_g(GttXG<false>& b, const char* unit) {
 #if GPCA_STAMP
 __device__ unsigned long long g_gtd_stamp[2 * 4096];      // s_memrealtime at the start and at the end of every workgroup of k_gtt_d
 #endif
-// this workgroup's consecutive range of the flat (n-group, stage) order (kernels.h): at most two segments when ngroups <= grid
-struct K2Range { int64_t a, b, S, total, v; };
-__device__ __forceinline__ K2Range k2_range(int64_t S, int64_t ngroups, int xcd_remap) {
-    // workgroup b runs on XCD b % 8: give the workgroups of one XCD consecutive virtual ids, so that the ranges that share an n-group's
-    // rows (and the T' planes of those rows) run behind one L2
+// this workgroup's virtual id: workgroup b runs on XCD b % 8; the workgroups of one XCD get consecutive virtual ids, so that the
+// workgroups that share a row chunk (and its T' planes) run behind one L2
+__device__ __forceinline__ int64_t k2_virtual_wg(int xcd_remap) {
     int64_t vb = blockIdx.x;
     if (xcd_remap) {
         const int64_t q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
         vb = x * q + (x < r ? x : r) + blockIdx.x / 8;
     }
-    K2Range k;
-    k.S = S; k.total = S * ngroups; k.v = vb;
-    k.a = (vb * k.total) / gridDim.x; k.b = ((vb + 1) * k.total) / gridDim.x;
-    return k;
+    return vb;
 }
 
 // one segment: stages [s0, s0 + nstage) of n-group g -> partial tile `slice` of that n-group
@@ -1836,7 +1828,7 @@ __device__ __forceinline__ void gtd_segment(const uint8_t* __restrict__ Gb, int6
 template <int NT, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Npad,
                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t S, int64_t ngroups, int xcd_remap) {
+                                                   int64_t S, int64_t ngroups, int W, int tasks_per_wg, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
     const int lane = threadIdx.x & 63;
@@ -1845,15 +1837,14 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
 #if GPCA_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtd_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const K2Range k = k2_range(S, ngroups, xcd_remap);
-    int64_t a = k.a;
-    bool first = true;
-    while (a < k.b) {
-        const int64_t g = a / S, s0 = a - g * S;
-        const int64_t len = (S - s0 < k.b - a) ? S - s0 : k.b - a;
-        if (!first) asm volatile("s_barrier" ::: "memory");     // every wave has left the previous segment: the plane slots are free
-        gtd_segment<NT, ABL>(Gb, ldr, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, len, k.v - k2_first_wg(S, k.total, gridDim.x, g));
-        a += len; first = false;
+    const int64_t t0 = k2_virtual_wg(xcd_remap) * tasks_per_wg;
+    for (int i = 0; i < tasks_per_wg; ++i) {
+        const int64_t t = t0 + i;                              // task = (row chunk, n-group), n-group fastest
+        if (t >= (int64_t)W * ngroups) break;
+        const int64_t wch = t / ngroups, g = t - wch * ngroups;
+        const int64_t s0 = (wch * S) / W, s1 = ((wch + 1) * S) / W;
+        if (i) asm volatile("s_barrier" ::: "memory");          // every wave has left the previous task: the plane slots are free
+        gtd_segment<NT, ABL>(Gb, ldr, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, s1 - s0, wch);
     }
 #if GPCA_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtd_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1968,39 +1959,39 @@ __device__ __forceinline__ void gtp_segment(const uint8_t* __restrict__ G2, int6
 template <int ND>
 __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Npad,
                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t S, int64_t ngroups, int xcd_remap) {
+                                                   int64_t S, int64_t ngroups, int W, int tasks_per_wg, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GtpSmem* sm = reinterpret_cast<GtpSmem*>(gqd_smem);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const K2Range k = k2_range(S, ngroups, xcd_remap);
-    int64_t a = k.a;
-    while (a < k.b) {
-        const int64_t g = a / S, s0 = a - g * S;
-        const int64_t len = (S - s0 < k.b - a) ? S - s0 : k.b - a;
-        gtp_segment<ND>(G2, ld2, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, len, k.v - k2_first_wg(S, k.total, gridDim.x, g));
-        a += len;
+    const int64_t t0 = k2_virtual_wg(xcd_remap) * tasks_per_wg;
+    for (int i = 0; i < tasks_per_wg; ++i) {
+        const int64_t t = t0 + i;
+        if (t >= (int64_t)W * ngroups) break;
+        const int64_t wch = t / ngroups, g = t - wch * ngroups;
+        const int64_t s0 = (wch * S) / W, s1 = ((wch + 1) * S) / W;
+        gtp_segment<ND>(G2, ld2, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, s1 - s0, wch);       // (ends with a workgroup barrier)
     }
 }
 
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, int nd, const KernelOpts& ko) {
     // stages of 128 SNP rows, 1 024-sample row padding of the packed store (its DMA pieces are whole 128-byte lines of codes)
-    if (!plan.flat || plan.S * 128 != Mpad || !dma_shape_ok(Npad, kSamplePad2bit, Mpad, kGQRowsPerWave) || ld2 * 4 < Npad) return (int)hipErrorInvalidValue;
+    if (plan.tasks_per_wg < 1 || plan.S * 128 != Mpad || !dma_shape_ok(Npad, kSamplePad2bit, Mpad, kGQRowsPerWave) || ld2 * 4 < Npad) return (int)hipErrorInvalidValue;
     const int remap = ko.gtt_xcd;
-    if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
-    else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
+    if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
+    else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
     return 0;
 }
 
 int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, const KernelOpts& ko) {
-    if (!plan.flat || plan.S * 128 != Mpad || !dma_shape_ok(Npad, 256, Mpad, kGQRowsPerWave) || ldg < Npad) return (int)hipErrorInvalidValue;   // 128-row stages, 256-sample pitch
+    if (plan.tasks_per_wg < 1 || plan.S * 128 != Mpad || !dma_shape_ok(Npad, 256, Mpad, kGQRowsPerWave) || ldg < Npad) return (int)hipErrorInvalidValue;   // 128-row stages, 256-sample pitch
     const dim3 grid((unsigned)plan.grid), blk(256);
     const int remap = ko.gtt_xcd;   // measured 5.10 -> 5.00 ms per step
-    if (ko.dma_nt) hipLaunchKernelGGL((k_gtt_d<1>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
-    else hipLaunchKernelGGL((k_gtt_d<0>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, remap);
+    if (ko.dma_nt) hipLaunchKernelGGL((k_gtt_d<1>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
+    else hipLaunchKernelGGL((k_gtt_d<0>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
     return 0;
 }
 

@@ -136,15 +136,15 @@ static int stage_sum_c(gpca_handle* h, int64_t parts) {
 static inline bool narrow_shape(const gpca_handle* h) {
     return h->narrow_ok && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_INT8 && h->N <= kNarrowSamples;
 }
-// the DMA kernels (k_gtt_d on int8 rows, k_gtt_p on 2-bit rows) take the flat decomposition: one workgroup per CU, equal ranges
-static inline bool k2_flat(const gpca_handle* h) {
+// the DMA kernels (k_gtt_d on int8 rows, k_gtt_p on 2-bit rows) take several consecutive tasks per workgroup: one batch of workgroups per launch
+static inline bool k2_batched(const gpca_handle* h) {
     const bool packed = h->storage == GPCA_STORE_2BIT;
     if (narrow_shape(h)) return false;
     return packed ? ((h->lds_planes && h->gtt_dma) || h->nd == 3) : (h->lds_planes && h->gtt_dma);      // (the choices of k2_panel)
 }
 static inline Gtt8Plan k2_plan(const gpca_handle* h, int64_t rows_pad) {
     return narrow_shape(h) ? gtt8_plan_narrow(rows_pad, h->N, std::min(h->gtt_waves_target, 1024)) :   // (one wave per SIMD: k_gtt_i8 holds 1 workgroup per CU)
-           k2_flat(h) ? gtt8_plan_flat(rows_pad, h->ldg, h->gtt_waves_target) : gtt8_plan(rows_pad, h->ldg, h->gtt_waves_target);
+           k2_batched(h) ? gtt8_plan_batched(rows_pad, h->ldg, h->gtt_waves_target) : gtt8_plan(rows_pad, h->ldg, h->gtt_waves_target);
 }
 
 static inline GqPlan k1_plan(const gpca_handle* h, int64_t rows_pad) { return gq_plan(rows_pad, h->gq_waves_target); }
@@ -196,8 +196,8 @@ static int stage_AtT_local(gpca_handle* h, bool planes_ready = false) {
                         ScopedTimer t(h, "gemm_GtT", 2.0 * elems * h->l / halves, by, nullptr, !streamed);
                         CHK(k2_panel(h, pv, h->dTd + hf * td_half, plan));
                     }
-                    if (streamed) launch_accum_y_i8(h->st, h->dYpart64, plan, h->ldg, h->N, h->d_yint + hf * yint_half, pv.index == 0);
-                    else launch_reduce_y_i8(h->st, h->dYpart64, plan, h->ldg, h->N, h->d_c + 32 * hf, h->d_tscale + 32 * hf, h->dY + 32 * hf, L);
+                    if (streamed) launch_accum_y_i8(h->st, h->dYpart64, plan.W, h->ldg, h->N, h->d_yint + hf * yint_half, pv.index == 0);
+                    else launch_reduce_y_i8(h->st, h->dYpart64, plan.W, h->ldg, h->N, h->d_c + 32 * hf, h->d_tscale + 32 * hf, h->dY + 32 * hf, L);
                     HIPCHK(hipGetLastError());
                 }
                 return GPCA_OK;
@@ -334,7 +334,7 @@ static int stage_power_fused(gpca_handle* h) {
             }
             for (int hf = 0; hf < halves; ++hf) {
                 CHK(k2_panel(h, pv, h->dTd + hf * td_half, plan2));
-                launch_accum_y_scaled(h->st, h->dYpart64, plan2, h->ldg, h->N, h->d_tscale + 32 * hf, h->d_yint + hf * yint_half, pv.index == 0);
+                launch_accum_y_scaled(h->st, h->dYpart64, plan2.W, h->ldg, h->N, h->d_tscale + 32 * hf, h->d_yint + hf * yint_half, pv.index == 0);
                 HIPCHK(hipGetLastError());
             }
             return GPCA_OK;
@@ -417,8 +417,9 @@ static int ensure_workspace(gpca_handle* h) {
         h->plan8 = k2_plan(h, gemm_rows);
         CHK(ensure(h, h->dQd, h->cap_Qd, (size_t)Npad * 32 * kDigits * (size_t)(L / 32)));
         CHK(ensure(h, h->dTd, h->cap_Td, (size_t)h->Mpad * 32 * kDigits * (size_t)(L / 32)));
-        // (flat decomposition: a shorter last panel of a stream can give an n-group one segment more than the full panels have)
-        const int64_t yslices = h->plan8.flat ? (h->plan8.grid + h->plan8.ngroups - 1) / h->plan8.ngroups + 2 : h->plan8.W;
+        // (streamed: a shorter last panel may be cut into more row chunks than the full panels: the plan of every panel size is asked)
+        int64_t yslices = h->plan8.W;
+        if (h->sm.on && h->M % h->sm.panel_rows) yslices = std::max<int64_t>(yslices, k2_plan(h, round_up(h->M % h->sm.panel_rows, kGQRowsPerWave)).W);
         CHK(ensure(h, h->dYpart64, h->cap_Ypart64, (size_t)yslices * (size_t)Npad * 32));
         CHK(ensure(h, h->d_apart, h->cap_apart, (size_t)h->gqplan.waves * 32 * (size_t)(L / 32)));
         if (h->sm.on) CHK(ensure(h, h->d_yint, h->cap_yint, (size_t)N * 32 * (size_t)(L / 32)));

@@ -153,30 +153,16 @@ constexpr int kDigits = 4;   // signed base-128 digits of the skinny operand
 void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
                   const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
                   int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
-// K2 work decomposition.  Slice form (the simple kernels, narrow shapes): grid = n-groups x W row slices of rows_per_wave rows, every
-// n-group has W partial tiles in Ypart[W][Npad][32].  FLAT form (k_gtt_d, k_gtt_p): the ngroups x S (n-group, 128-row stage) pairs in
-// n-group-major order are cut into `grid` equal consecutive ranges, one per workgroup (grid = the CUs the launch fills: every workgroup
-// runs once and they all end together -- the slice form ran 500 workgroups on 256 CUs at configs[1], 392 at configs[3]'s shard, i.e. a
-// second, part-empty batch: 6 % and 14 % of the launch).  A range that crosses an n-group boundary is two segments; n-group g's partial
-// tiles are the segments of workgroups k2_first_wg(g) ... k2_last_wg(g), slice index = workgroup - k2_first_wg(g), W = the most any
-// n-group has.  The folds (k_reduce_y_i8 ...) recompute the count per n-group with the same two functions.
-struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; int flat; int64_t S; int64_t ngroups; };
-__host__ __device__ inline int64_t k2_first_wg(int64_t S, int64_t total, int64_t grid, int64_t g) {    // smallest v with range end ((v+1) total / grid) beyond g S
-    const int64_t x = g * S;
-    int64_t v = (x * grid) / total;
-    if (v > 0) --v;
-    while (((v + 1) * total) / grid <= x) ++v;
-    return v;
-}
-__host__ __device__ inline int64_t k2_last_wg(int64_t S, int64_t total, int64_t grid, int64_t g) {     // largest v with range start (v total / grid) before (g+1) S
-    const int64_t y = (g + 1) * S;
-    int64_t v = (y * grid) / total + 1;
-    if (v > grid - 1) v = grid - 1;
-    while ((v * total) / grid >= y) --v;
-    return v;
-}
+// K2 work decomposition: tasks = (row chunk, n-group) pairs -- an n-group is the 4 x 128 samples of a workgroup's four waves, a row chunk
+// one of W near-equal ranges of the 128-row stages -- and every n-group ends with W partial tiles in Ypart[W][Npad][32].
+// Simple kernels / narrow shapes: one task per workgroup (grid = tasks).  The DMA kernels (k_gtt_d, k_gtt_p) take `tasks_per_wg`
+// CONSECUTIVE tasks per workgroup, n-group fastest, so that a launch is one batch of workgroups that end together: one task per
+// workgroup ran 500 workgroups on 256 CUs at configs[1] and 392 at configs[3]'s shard -- a second, part-empty batch, 6 % and 14 % of
+// the launch.  gtt8_plan_batched picks W (stages per task against per-task prologues, the fold's traffic and the L2 footprint of a
+// row chunk's T' planes, which the workgroups of an XCD share).
+struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; int tasks_per_wg; int64_t S; int64_t ngroups; };
 Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves);
-Gtt8Plan gtt8_plan_flat(int64_t Mpad, int64_t Npad, int target_waves);
+Gtt8Plan gtt8_plan_batched(int64_t Mpad, int64_t Npad, int target_waves);
 void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
                    double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko = KernelOpts());
 // narrow matrices (N <= 256 samples, int8 rows): every wave owns its own row range, Q's digit planes stay in registers (K1) /
@@ -188,12 +174,12 @@ void launch_gtt_n(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, in
 int launch_gq_n(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                 int scale_out, int64_t ldt = 32);
-void launch_reduce_y_i8(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, const double* c,
+void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
                         const double* tscale, double* Y, int64_t ldy = 32);
-void launch_accum_y_i8(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, double* Yint, int first);
+void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first);
 void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy = 32);
 void launch_absmax_fold(hipStream_t st, const double* apart, int64_t P, double* run);
-void launch_accum_y_scaled(hipStream_t st, const double* Ypart, const Gtt8Plan& plan, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first);
+void launch_accum_y_scaled(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first);
 void launch_finish_y_sum(hipStream_t st, const double* Yacc, int64_t N, const double* c, double* Y, int64_t ldy = 32);
 int64_t absmax_num_parts(int64_t rows);
 // X [rows][32] row-major -> digit planes Xd [rows_pad/32][kDigits][64][16 B]; scale[j] = colmax_j / S, inv = 1/scale

@@ -21,7 +21,7 @@ __global__ void k_fill(uint32_t* p, int64_t n, uint32_t seed, uint32_t mask) {
 template <int ABL>
 static void launch(const int8_t* G, int64_t ld8, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Yp, const gpca::Gtt8Plan& plan, int remap) {
     hipLaunchKernelGGL((gpca::k_gtt_d<1, ABL>), dim3((unsigned)plan.grid), dim3(256), sizeof(gpca::GqdSmem), 0, (const uint8_t*)G, ld8, Npad, Td, Yp, plan.S,
-                       plan.ngroups, remap);
+                       plan.ngroups, plan.W, plan.tasks_per_wg, remap);
 }
 template <int ABL>
 static int opt_in() {
@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     const int target = argc > 4 ? atoi(argv[4]) : 2048;
     const int64_t Npad = (N + 255) / 256 * 256, ld8 = ((Npad / 256) % 2 == 0) ? Npad + 256 : Npad, Mpad = (M + 127) / 128 * 128;
     int8_t* G; int8_t* Td; double* Yp;
-    const gpca::Gtt8Plan plan = gpca::gtt8_plan_flat(Mpad, Npad, target);
+    const gpca::Gtt8Plan plan = gpca::gtt8_plan_batched(Mpad, Npad, target);
     CK(hipMalloc(&G, Mpad * ld8)); CK(hipMalloc(&Td, Mpad * 32 * 4)); CK(hipMalloc(&Yp, (size_t)(plan.W + 2) * Npad * 32 * 8));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G, Mpad * ld8 / 4, 1u, 0x01010101u);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)Td, Mpad * 32, 2u, 0x3f3f3f3fu);
@@ -57,8 +57,8 @@ int main(int argc, char** argv) {
             float t; (void)hipEventElapsedTime(&t, e0, e1);
             ms[v].push_back(t / 10);
         }
-    printf("k_gtt_d %lld x %lld (pitch %lld): %lld workgroups, flat ranges of <= %lld stages over %lld n-groups x %lld stages (<= %d partial tiles per n-group); %d x 10 launches per variant, round-robin\n",
-           (long long)M, (long long)N, (long long)ld8, (long long)plan.grid, (long long)(plan.rows_per_wave / 128), (long long)plan.ngroups, (long long)plan.S, plan.W, reps);
+    printf("k_gtt_d %lld x %lld (pitch %lld): %lld workgroups x %d tasks of <= %lld stages (%lld n-groups x %d row chunks of %lld stages); %d x 10 launches per variant, round-robin\n",
+           (long long)M, (long long)N, (long long)ld8, (long long)plan.grid, plan.tasks_per_wg, (long long)(plan.rows_per_wave / 128), (long long)plan.ngroups, plan.W, (long long)plan.S, reps);
     for (int v = 0; v < nv; ++v) {
         std::vector<double> x = ms[v]; std::sort(x.begin(), x.end());
         double m = 0; for (double y : x) m += y; m /= x.size();
