@@ -340,11 +340,13 @@ Gtt8Plan gtt8_plan_batched(int64_t Mpad, int64_t Npad, int target_waves) {
         if ((double)p.S / (double)W * 16384.0 > 3.0 * 1048576.0) f += 0.02;               // T' planes of a row chunk vs L2
         if (f < best - 1e-12) { best = f; bestW = W; }
     }
-    p.W = (int)bestW;
-    const int64_t T = bestW * p.ngroups;
+    p.C = (p.S + bestW - 1) / bestW;                  // stages per row chunk (the last chunk may be shorter)
+    p.W = (int)((p.S + p.C - 1) / p.C);
+    const int64_t T = (int64_t)p.W * p.ngroups;
     p.tasks_per_wg = (int)((T + grid0 - 1) / grid0);
     p.grid = (T + p.tasks_per_wg - 1) / p.tasks_per_wg;
-    p.rows_per_wave = ((p.S + bestW - 1) / bestW) * 128;      // rows of the longest task
+    p.strided = 1;
+    p.rows_per_wave = p.C * 128;                      // rows of a full task
     return p;
 }
 
@@ -1556,16 +1558,20 @@ __device__ __forceinline__ void gttx_decode(const GttXG<PACKED>& b, Gtt2Ops& o, 
 struct GttXT { i32x4 t[kDigits]; };
 // the 16 MFMAs of the current block; after each one a micro-step of the next block's decode, and (first four slots) the
 // LDS reads of the next block's digit operands
-template <bool PACKED, int ND = kDigits, int ABL = 0>
+// ZERO: the first block of a task -- the sums start from the MFMA's constant-zero C operand instead of from zeroed registers, so that
+// nothing of the accumulators is live across a task boundary of the chained k_gtt_d (hipcc otherwise carried the 256 registers through
+// the task loop's phi nodes, shuffled them between AGPRs at every boundary and sent four of them to scratch)
+template <bool PACKED, int ND = kDigits, int ABL = 0, bool ZERO = false>
 __device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i32x16 (&acc)[4][kDigits],
                                            const GttXG<PACKED>& gn, Gtt2Ops& on, GttXT& tn, const i32x4* lds_next, unsigned bsh) {
     unsigned x[4], y[4];
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int d = 0; d < kDigits; ++d)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (ABL & 8) { if (d < ND) acc[t][d][0] ^= tc.t[d][t] ^ oc.bt[t][d]; }
-            else if (d < ND) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tc.t[d], oc.bt[t], acc[t][d], 0, 0, 0);   // (three-plane mode: the last four slots carry only decode work)
+            if (ABL & 8) { if (d < ND) { if (ZERO) acc[t][d] = zero16; acc[t][d][0] ^= tc.t[d][t] ^ oc.bt[t][d]; } }
+            else if (d < ND) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tc.t[d], oc.bt[t], ZERO ? zero16 : acc[t][d], 0, 0, 0);   // (three-plane mode: the last four slots carry only decode work)
             const int m = d * 4 + t;
             if (m < ND) tn.t[m] = lds_next[m * 64];
             gttx_decode_step<PACKED, ABL>(gn, on, x, y, m, bsh);
@@ -1735,100 +1741,64 @@ __device__ __forceinline__ int64_t k2_virtual_wg(int xcd_remap) {
     return vb;
 }
 
-// one segment: stages [s0, s0 + nstage) of n-group g -> partial tile `slice` of that n-group
-template <int NT, int ABL>
-__device__ __forceinline__ void gtd_segment(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Npad, const int8_t* __restrict__ Td,
-                                            double* __restrict__ Ypart, GqdSmem* sm, int wv, int lane, int c, int h,
-                                            int64_t g, int64_t s0, int64_t nstage, int64_t slice) {
-    int64_t n0 = (g * 4 + wv) * 128;
-    const bool live = n0 < Npad;          // a dead wave (ragged last group) still moves planes and joins the barriers
-    if (!live) n0 = 0;
-    const int64_t m_begin = s0 * 128;
-    const int64_t kblocks = nstage * 4;
+// A workgroup's tasks run as ONE pipeline (chained, like k_gq_d's rounds).  The blocks of task i + 1 follow the blocks of task i in the
+// ring -- the last refills of a task used to wrap to its own block 0 and were thrown away, now they fetch the next task's first
+// blocks -- and the T' planes two stages ahead are the next task's stages 0 and 1, so the issue order across the boundary is the steady
+// state's and the registers (the dwords of blocks b + 1 and b + 2, the operands of block b) already hold the next task's first blocks
+// when a task ends.  At the boundary only the accumulators change hands: the finished task's tile goes to Ypart (stores younger than
+// every load in flight: the counted waits only get stricter) and the sums restart.  A boundary used to cost a chip-wide drain and a
+// cold prologue (every workgroup reaches it at the same time): ~25 us per task in the decomposition A/B of kbench_gtd.
+struct GtdTask { const uint8_t* gp; const int8_t* tp; int64_t kblocks; int64_t n0; int64_t slice; bool live; };
 
-    i32x16 acc[4][kDigits];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
-
-    constexpr uint32_t TKB = kDigits * 1024;
-    const uint8_t* gp = Gb + m_begin * ldr + n0;
-    const int8_t* tp = Td + (m_begin >> 5) * TKB + wv * 1024;    // this wave's plane
-    const uint32_t gvo = (uint32_t)(lane >> 3) * (uint32_t)ldr + 16u * (uint32_t)(lane & 7);
-    const uint32_t tvo = (uint32_t)(lane * 16);
-    const uint32_t lds_t = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
-    const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (kGqdSlots * 4096u);
-    const char* gl = reinterpret_cast<const char*>(&sm->g[wv][0][0]) + (16 * h) * 128 + 4 * c;   // this lane's dword column
-    i32x4 (*tds)[4][kDigits][64] = sm->q;
-
-    GttXG<false> GA, GB;
-    Gtt2Ops OA, OB;
-    GttXT TA, TB;
-    gtd_issue_g<NT>(gp, ldr, 0, kblocks, lds_g + 0u * 4096u, gvo);
-    gtd_issue_g<NT>(gp, ldr, 1, kblocks, lds_g + 1u * 4096u, gvo);
-    gtd_issue_t(tp, 0, nstage, lds_t, tvo);
-    gtd_issue_g<NT>(gp, ldr, 2, kblocks, lds_g + 2u * 4096u, gvo);
-    gtd_issue_g<NT>(gp, ldr, 3, kblocks, lds_g + 3u * 4096u, gvo);
-    gtd_issue_g<NT>(gp, ldr, 4, kblocks, lds_g + 4u * 4096u, gvo);
-    gtd_issue_g<NT>(gp, ldr, 5, kblocks, lds_g + 5u * 4096u, gvo);
-    gtd_issue_t(tp, 1, nstage, lds_t + 4u * TKB, tvo);
-    asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");      // G0, G1 and every wave's plane of T'(0) landed
-    gtd_read_g(GA, gl);
-    gtd_read_g(GB, gl + 4096);
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) TA.t[d] = tds[0][0][d][lane];
-    gttx_decode<false>(GA, OA, 0u);
-    asm volatile("" :: "v"(GB.g[15]));
-    gtd_issue_g<NT>(gp, ldr, 6, kblocks, lds_g + 0u * 4096u, gvo);
-    uint32_t s1 = 1;            // ring slot of block b + 1 (re-filled at the end of phase b)
-    int64_t ib = 7;             // block that goes into it
-
-    // one phase: TC/OC = operands of block b; GN (registers of block b+1) -> ON, TN; GR receives block b+2
-#define GTD_PHASE(TC, OC, GN, ON, TN, GR, W, TSLOT, TBLK)                                                  \
-    {                                                                                                    \
-        const uint32_t s2_ = s1 == kGqdSlots - 1 ? 0u : s1 + 1u;                                         \
-        gqd_wait_vm<W>();                                                                                \
-        gtd_read_g(GR, gl + s2_ * 4096u);                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        gttx_phase<false, kDigits, ABL>(TC, OC, acc, GN, ON, TN, &tds[(TSLOT)][(TBLK)][0][lane], 0u);    \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        if (!(ABL & 4)) gtd_issue_g<NT>(gp, ldr, ib, kblocks, lds_g + s1 * 4096u, gvo);                  \
-        ++ib; s1 = s2_;                                                                                  \
-    }
-    for (int64_t st = 0; st < nstage; ++st) {
-        const int slot = (int)(st & 1);
-        GTD_PHASE(TA, OA, GB, OB, TB, GA, 20, slot, 1)
-        GTD_PHASE(TB, OB, GA, OA, TA, GB, 20, slot, 2)
-        GTD_PHASE(TA, OA, GB, OB, TB, GA, 20, slot, 3)
-        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");   // T'(st+1) visible; everyone is done with T'(st)
-        if (!(ABL & 2)) gtd_issue_t(tp, st + 2, nstage, lds_t + (uint32_t)slot * 4u * TKB, tvo);
-        GTD_PHASE(TB, OB, GA, OA, TA, GB, 24, slot ^ 1, 0)
-    }
-#undef GTD_PHASE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after this segment (next prologue, or the LDS is released)
-    if (!live || ((ABL & 16) && acc[0][0][0] != 0x7fffffff)) return;
-    // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h, col = c -> sample n0 + 4c + t.  Exact integers as f64.
-    double* yp = Ypart + (slice * Npad) * 32;
+// a wave's four 32 x 32 tiles of exact integer sums -> Ypart[slice][n0 + 4 c + t][j] as f64.  D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h,
+// col = c -> sample n0 + 4c + t.  The lane id is made opaque so that the address arithmetic is done here, per task, instead of being
+// hoisted out of the task loop into registers that the stage loop's pressure sends to scratch (their reloads carried vmcnt(0) waits
+// that drained the DMA queue at every task boundary).
+template <int BITS>
+__device__ __forceinline__ void gtt_tiles_out(const i32x16 (&acc)[4][kDigits], double* __restrict__ Ypart, int64_t slice, int64_t Npad, int64_t n0) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned all = ~0u;
+    asm volatile("" : "+s"(all));                     // (opaque mask: the lane id is recomputed HERE -- hoisted out of the task loop it would be kept across the stage loop, i.e. spilled)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
+    const int c = lane & 31, h = lane >> 5;
+    double* yp = Ypart + (slice * Npad + n0 + 4 * c) * 32 + 4 * h;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int64_t n = n0 + 4 * c + t;
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int j = (e & 3) + 8 * (e >> 2);
             double2 o;
-            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
-            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
+            o.x = combine_digits<BITS>(acc[t], e); o.y = combine_digits<BITS>(acc[t], e + 1);
+            *reinterpret_cast<double2*>(yp + t * 32 + j) = o;
+            if (e == 6) __builtin_amdgcn_sched_barrier(0);       // (half a tile's accumulators live at a time)
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+// the walk over a workgroup's tasks: task = (row chunk, n-group), n-group fastest; workgroup v takes tasks v, v + grid, v + 2 grid ...
+// (strided): at any time the workgroups of an XCD (consecutive v) are on the n-groups of the same one or two row chunks and fetch those
+// rows' T' planes from HBM once (consecutive tasks per workgroup spread an XCD over 6 row chunks: 15 MB of planes against 4 MB of L2,
+// + 4.6 % at configs[1]).  Row chunk w = stages [w C, min(S, (w + 1) C)).  Stepping from a task to the next is additions only: a
+// division inside the pipeline costs VALU registers the stage loop does not have.
+struct K2Walk {
+    int64_t wch, g, wch_step, g_step, ngroups;
+    int ntask;
+    __device__ __forceinline__ void init(int64_t vwg, int64_t T, int64_t ngroups_, int tasks_per_wg, int strided) {
+        ngroups = ngroups_;
+        const int64_t t_first = strided ? vwg : vwg * tasks_per_wg, t_step = strided ? (int64_t)gridDim.x : 1;
+        ntask = 0;
+        if (t_first < T) { const int64_t left = (T - 1 - t_first) / t_step + 1; ntask = (int)(left < tasks_per_wg ? left : tasks_per_wg); }
+        wch = t_first / ngroups; g = t_first - wch * ngroups;
+        wch_step = t_step / ngroups; g_step = t_step - wch_step * ngroups;
+    }
+    __device__ __forceinline__ void advance() { wch += wch_step; g += g_step; if (g >= ngroups) { g -= ngroups; ++wch; } }
+};
 
 template <int NT, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Npad,
                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t S, int64_t ngroups, int W, int tasks_per_wg, int xcd_remap) {
+                                                   int64_t S, int64_t C, int64_t ngroups, int W, int tasks_per_wg, int strided, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
     const int lane = threadIdx.x & 63;
@@ -1837,15 +1807,103 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
 #if GPCA_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtd_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int64_t t0 = k2_virtual_wg(xcd_remap) * tasks_per_wg;
-    for (int i = 0; i < tasks_per_wg; ++i) {
-        const int64_t t = t0 + i;                              // task = (row chunk, n-group), n-group fastest
-        if (t >= (int64_t)W * ngroups) break;
-        const int64_t wch = t / ngroups, g = t - wch * ngroups;
-        const int64_t s0 = (wch * S) / W, s1 = ((wch + 1) * S) / W;
-        if (i) asm volatile("s_barrier" ::: "memory");          // every wave has left the previous task: the plane slots are free
-        gtd_segment<NT, ABL>(Gb, ldr, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, s1 - s0, wch);
+    constexpr uint32_t TKB = kDigits * 1024;
+    K2Walk cw;
+    cw.init(k2_virtual_wg(xcd_remap), (int64_t)W * ngroups, ngroups, tasks_per_wg, strided);
+    const int ntask = cw.ntask;
+    if (ntask == 0) return;
+    auto task_of = [&](const K2Walk& w) -> GtdTask {
+        const int64_t s0 = w.wch * C, s1 = (s0 + C < S) ? s0 + C : S;
+        GtdTask k;
+        k.n0 = (w.g * 4 + wv) * 128;
+        k.live = k.n0 < Npad;             // a dead wave (ragged last n-group) still moves planes and joins the barriers
+        if (!k.live) k.n0 = 0;
+        k.gp = Gb + (s0 * 128) * ldr + k.n0;
+        k.tp = Td + (s0 * 4) * TKB + wv * 1024;                 // this wave's plane
+        k.kblocks = (s1 - s0) * 4;
+        k.slice = w.wch;
+        return k;
+    };
+
+    const uint32_t gvo = (uint32_t)(lane >> 3) * (uint32_t)ldr + 16u * (uint32_t)(lane & 7);
+    const uint32_t tvo = (uint32_t)(lane * 16);
+    const uint32_t lds_t = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->q[0][0][0][0] + (uint32_t)wv * 1024u;
+    const uint32_t lds_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sm->g[0][0][0] + (uint32_t)wv * (kGqdSlots * 4096u);
+    const char* gl = reinterpret_cast<const char*>(&sm->g[wv][0][0]) + (16 * h) * 128 + 4 * c;   // this lane's dword column
+    i32x4 (*tds)[4][kDigits][64] = sm->q;
+
+    // issue cursors: the next block / the next stage of T' planes to fetch, walking the workgroup's tasks in order (past the last task
+    // they re-read its first blocks, which are never used)
+    K2Walk gw = cw, tw = cw;
+    int gi = 0; GtdTask gk = task_of(gw); int64_t gblk = 0;
+    int ti = 0; GtdTask tk = gk; int64_t tst = 0;
+    auto issue_g = [&](uint32_t slot) {
+        const i32x4 rg = gqd_rsrc(gk.gp + gblk * 32 * ldr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot's last LDS reads have returned
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gqd_dma<NT>(lds_g + slot * 4096u + 1024u * i, gvo, rg, 8u * i * (uint32_t)ldr);
+        if (++gblk == gk.kblocks) { gblk = 0; if (gi + 1 < ntask) { ++gi; gw.advance(); gk = task_of(gw); } }
+    };
+    auto issue_t = [&](uint32_t tslot) {
+        const i32x4 rt = gqd_rsrc(tk.tp + tst * 4 * TKB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gqd_dma<0>(lds_t + tslot * 4u * TKB + (uint32_t)(j * kDigits) * 1024u, tvo, rt, j * TKB);
+        if (++tst == (tk.kblocks >> 2)) { tst = 0; if (ti + 1 < ntask) { ++ti; tw.advance(); tk = task_of(tw); } }
+    };
+
+    i32x16 acc[4][kDigits];
+    GttXG<false> GA, GB;
+    Gtt2Ops OA, OB;
+    GttXT TA, TB;
+    // prologue (once per workgroup): G0 G1 T'0 G2 G3 G4 G5 T'1, blocks 0 and 1 into registers, then G6: the steady-state counts hold
+    issue_g(0); issue_g(1);
+    issue_t(0);
+    issue_g(2); issue_g(3); issue_g(4); issue_g(5);
+    issue_t(1);
+    asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");      // G0, G1 and every wave's plane of T'(0) landed
+    gtd_read_g(GA, gl);
+    gtd_read_g(GB, gl + 4096);
+#pragma unroll
+    for (int d = 0; d < kDigits; ++d) TA.t[d] = tds[0][0][d][lane];
+    gttx_decode<false>(GA, OA, 0u);
+    asm volatile("" :: "v"(GB.g[15]));
+    issue_g(0);
+    uint32_t s1 = 1;            // ring slot of block b + 1 (re-filled at the end of phase b)
+    uint32_t slot = 0;          // plane slot of the current stage (alternates over the workgroup's stages, across tasks)
+
+    // one phase: TC/OC = operands of block b; GN (registers of block b+1) -> ON, TN; GR receives block b+2
+#define GTD_PHASE(TC, OC, GN, ON, TN, GR, WV, TSLOT, TBLK, ZERO)                                           \
+    {                                                                                                    \
+        const uint32_t s2_ = s1 == kGqdSlots - 1 ? 0u : s1 + 1u;                                         \
+        gqd_wait_vm<WV>();                                                                               \
+        gtd_read_g(GR, gl + s2_ * 4096u);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        gttx_phase<false, kDigits, ABL, ZERO>(TC, OC, acc, GN, ON, TN, &tds[(TSLOT)][(TBLK)][0][lane], 0u); \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (!(ABL & 4)) issue_g(s1);                                                                     \
+        s1 = s2_;                                                                                        \
     }
+#define GTD_STAGE(ZERO)                                                                                  \
+    {                                                                                                    \
+        GTD_PHASE(TA, OA, GB, OB, TB, GA, 20, slot, 1, ZERO)                                             \
+        GTD_PHASE(TB, OB, GA, OA, TA, GB, 20, slot, 2, false)                                            \
+        GTD_PHASE(TA, OA, GB, OB, TB, GA, 20, slot, 3, false)                                            \
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");   /* T' of the next stage visible; everyone is done with this stage's */ \
+        if (!(ABL & 2)) issue_t(slot);                                                                   \
+        GTD_PHASE(TB, OB, GA, OA, TA, GB, 24, slot ^ 1u, 0, false)                                       \
+        slot ^= 1u;                                                                                      \
+    }
+    for (int i = 0; i < ntask; ++i) {
+        if (i) cw.advance();
+        const GtdTask k = task_of(cw);
+        const int64_t nstage = k.kblocks >> 2;
+        GTD_STAGE(true)                                        // the task's first block starts the sums (C = 0)
+        for (int64_t st = 1; st < nstage; ++st) GTD_STAGE(false)
+        if (k.live && !((ABL & 16) && acc[0][0][0] != 0x7fffffff)) gtt_tiles_out<7>(acc, Ypart, k.slice, Npad, k.n0);
+    }
+#undef GTD_STAGE
+#undef GTD_PHASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may land after this workgroup's LDS is released
 #if GPCA_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_gtd_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1959,19 +2017,18 @@ __device__ __forceinline__ void gtp_segment(const uint8_t* __restrict__ G2, int6
 template <int ND>
 __global__ __launch_bounds__(256, 1) void k_gtt_p(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Npad,
                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t S, int64_t ngroups, int W, int tasks_per_wg, int xcd_remap) {
+                                                   int64_t S, int64_t C, int64_t ngroups, int W, int tasks_per_wg, int strided, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GtpSmem* sm = reinterpret_cast<GtpSmem*>(gqd_smem);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int64_t t0 = k2_virtual_wg(xcd_remap) * tasks_per_wg;
-    for (int i = 0; i < tasks_per_wg; ++i) {
-        const int64_t t = t0 + i;
-        if (t >= (int64_t)W * ngroups) break;
-        const int64_t wch = t / ngroups, g = t - wch * ngroups;
-        const int64_t s0 = (wch * S) / W, s1 = ((wch + 1) * S) / W;
-        gtp_segment<ND>(G2, ld2, Npad, Td, Ypart, sm, wv, lane, c, h, g, s0, s1 - s0, wch);       // (ends with a workgroup barrier)
+    K2Walk cw;
+    cw.init(k2_virtual_wg(xcd_remap), (int64_t)W * ngroups, ngroups, tasks_per_wg, strided);     // (see k_gtt_d)
+    for (int i = 0; i < cw.ntask; ++i) {
+        if (i) cw.advance();
+        const int64_t s0 = cw.wch * C, s1 = (s0 + C < S) ? s0 + C : S;
+        gtp_segment<ND>(G2, ld2, Npad, Td, Ypart, sm, wv, lane, c, h, cw.g, s0, s1 - s0, cw.wch);       // (ends with a workgroup barrier)
     }
 }
 
@@ -1980,8 +2037,8 @@ int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, i
     // stages of 128 SNP rows, 1 024-sample row padding of the packed store (its DMA pieces are whole 128-byte lines of codes)
     if (plan.tasks_per_wg < 1 || plan.S * 128 != Mpad || !dma_shape_ok(Npad, kSamplePad2bit, Mpad, kGQRowsPerWave) || ld2 * 4 < Npad) return (int)hipErrorInvalidValue;
     const int remap = ko.gtt_xcd;
-    if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
-    else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
+    if (nd == 3) hipLaunchKernelGGL(k_gtt_p<3>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
+    else hipLaunchKernelGGL(k_gtt_p<kDigits>, dim3((unsigned)plan.grid), dim3(256), sizeof(GtpSmem), st, G2, ld2, Npad, Td, Ypart, plan.S, plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
     return 0;
 }
 
@@ -1990,8 +2047,8 @@ int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int
     if (plan.tasks_per_wg < 1 || plan.S * 128 != Mpad || !dma_shape_ok(Npad, 256, Mpad, kGQRowsPerWave) || ldg < Npad) return (int)hipErrorInvalidValue;   // 128-row stages, 256-sample pitch
     const dim3 grid((unsigned)plan.grid), blk(256);
     const int remap = ko.gtt_xcd;   // measured 5.10 -> 5.00 ms per step
-    if (ko.dma_nt) hipLaunchKernelGGL((k_gtt_d<1>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
-    else hipLaunchKernelGGL((k_gtt_d<0>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.ngroups, plan.W, plan.tasks_per_wg, remap);
+    if (ko.dma_nt) hipLaunchKernelGGL((k_gtt_d<1>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
+    else hipLaunchKernelGGL((k_gtt_d<0>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
     return 0;
 }
 

@@ -160,7 +160,7 @@ void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& pl
 // workgroup ran 500 workgroups on 256 CUs at configs[1] and 392 at configs[3]'s shard -- a second, part-empty batch, 6 % and 14 % of
 // the launch.  gtt8_plan_batched picks W (stages per task against per-task prologues, the fold's traffic and the L2 footprint of a
 // row chunk's T' planes, which the workgroups of an XCD share).
-struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; int tasks_per_wg; int64_t S; int64_t ngroups; };
+struct Gtt8Plan { int64_t nblocks_n; int W; int64_t rows_per_wave; int64_t grid; int tasks_per_wg; int64_t S; int64_t ngroups; int strided; int64_t C; };
 Gtt8Plan gtt8_plan(int64_t Mpad, int64_t Npad, int target_waves);
 Gtt8Plan gtt8_plan_batched(int64_t Mpad, int64_t Npad, int target_waves);
 void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,

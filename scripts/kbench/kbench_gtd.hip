@@ -21,13 +21,66 @@ __global__ void k_fill(uint32_t* p, int64_t n, uint32_t seed, uint32_t mask) {
 template <int ABL>
 static void launch(const int8_t* G, int64_t ld8, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Yp, const gpca::Gtt8Plan& plan, int remap) {
     hipLaunchKernelGGL((gpca::k_gtt_d<1, ABL>), dim3((unsigned)plan.grid), dim3(256), sizeof(gpca::GqdSmem), 0, (const uint8_t*)G, ld8, Npad, Td, Yp, plan.S,
-                       plan.ngroups, plan.W, plan.tasks_per_wg, remap);
+                       plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
 }
 template <int ABL>
 static int opt_in() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gpca::k_gtt_d<1, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(gpca::GqdSmem));
 }
+// decomposition A/B in one process:  kbench_gtd plans M N reps W [W ...]   W = 0: gtt8_plan_batched's choice; W > 0: that many row chunks,
+// tasks spread evenly over <= 256 workgroups (workgroup v takes tasks v, v + grid, ...; 1000 + W: consecutive tasks instead); W < 0: the slice form of rounds 1-3 (one task per workgroup, gtt8_plan's W)
+static int plans_main(int argc, char** argv) {
+    const int64_t M = atoll(argv[2]), N = atoll(argv[3]);
+    const int reps = atoi(argv[4]);
+    const int64_t Npad = (N + 255) / 256 * 256, ld8 = ((Npad / 256) % 2 == 0) ? Npad + 256 : Npad, Mpad = (M + 127) / 128 * 128;
+    std::vector<gpca::Gtt8Plan> plans;
+    std::vector<std::string> names;
+    int maxW = 1;
+    for (int i = 5; i < argc; ++i) {
+        const int W = atoi(argv[i]);
+        gpca::Gtt8Plan p = gpca::gtt8_plan_batched(Mpad, Npad, 2048);
+        char nm[96];
+        if (W < 0) {
+            const gpca::Gtt8Plan o = gpca::gtt8_plan(Mpad, Npad, 2048);
+            p.C = (p.S + o.W - 1) / o.W; p.W = (int)((p.S + p.C - 1) / p.C); p.tasks_per_wg = 1; p.grid = (int64_t)p.W * p.ngroups;
+            snprintf(nm, sizeof nm, "slice form: W %d, %lld workgroups x 1 task", p.W, (long long)p.grid);
+        } else {
+            const int Wr = W >= 1000 ? W - 1000 : W;
+            if (Wr > 0) { p.C = (p.S + Wr - 1) / Wr; p.W = (int)((p.S + p.C - 1) / p.C); const int64_t T = (int64_t)p.W * p.ngroups; p.tasks_per_wg = (int)((T + 255) / 256); p.grid = (T + p.tasks_per_wg - 1) / p.tasks_per_wg; }
+            p.strided = W >= 1000 ? 0 : 1;
+            snprintf(nm, sizeof nm, "%s%s W %d, %lld workgroups x %d tasks of %lld stages", W ? "batched" : "batched (auto)", p.strided ? " strided" : " consecutive", p.W, (long long)p.grid, p.tasks_per_wg, (long long)(p.S / p.W));
+        }
+        plans.push_back(p); names.push_back(nm); maxW = std::max(maxW, p.W);
+    }
+    int8_t* G; int8_t* Td; double* Yp;
+    CK(hipMalloc(&G, Mpad * ld8)); CK(hipMalloc(&Td, Mpad * 32 * 4)); CK(hipMalloc(&Yp, (size_t)maxW * Npad * 32 * 8));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G, Mpad * ld8 / 4, 1u, 0x01010101u);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)Td, Mpad * 32, 2u, 0x3f3f3f3fu);
+    if (opt_in<0>()) { printf("LDS opt-in failed\n"); return 1; }
+    std::vector<std::vector<double>> ms(plans.size());
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int it = 0; it < 10; ++it) launch<0>(G, ld8, Mpad, Npad, Td, Yp, plans[0], 1);
+    CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < reps; ++rep)
+        for (size_t v = 0; v < plans.size(); ++v) {
+            launch<0>(G, ld8, Mpad, Npad, Td, Yp, plans[v], 1);
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 10; ++it) launch<0>(G, ld8, Mpad, Npad, Td, Yp, plans[v], 1);
+            (void)hipEventRecord(e1); CK(hipEventSynchronize(e1));
+            float t; (void)hipEventElapsedTime(&t, e0, e1);
+            ms[v].push_back(t / 10);
+        }
+    printf("k_gtt_d %lld x %lld: decompositions, %d x 10 launches each, round-robin (the fold of the W partial tiles is NOT in these times: W x %lld x 256 B per launch)\n",
+           (long long)M, (long long)N, reps, (long long)Npad);
+    for (size_t v = 0; v < plans.size(); ++v) {
+        std::vector<double> x = ms[v]; std::sort(x.begin(), x.end());
+        double m = 0; for (double y : x) m += y; m /= x.size();
+        printf("  %-62s mean %.4f ms (min %.4f max %.4f) = %.2f TB/s\n", names[v].c_str(), m, x.front(), x.back(), (double)M * N / (m * 1e-3) / 1e12);
+    }
+    return 0;
+}
 int main(int argc, char** argv) {
+    if (argc > 5 && std::string(argv[1]) == "plans") return plans_main(argc, argv);
     const int64_t M = argc > 1 ? atoll(argv[1]) : 1000064, N = argc > 2 ? atoll(argv[2]) : 10000;
     const int reps = argc > 3 ? atoi(argv[3]) : 4;
     const int target = argc > 4 ? atoi(argv[4]) : 2048;
