@@ -25,6 +25,10 @@ PREC_F32_MFMA = 0
 PREC_I8_EXACT = 1
 STORE_INT8 = 0
 STORE_2BIT = 1
+CFG_SIMPLE_KERNELS = 1     # gpca_config.reserved[0] flags (include/gpca.h)
+CFG_NO_COMPACT = 2
+CFG_NO_NARROW = 4
+CFG_NO_SPIN_SYNC = 8
 
 
 class GpcaLibraryError(RuntimeError):

@@ -1,4 +1,5 @@
-// Exact-integer variants of the two tall-skinny products on v_mfma_i32_32x32x32_i8 (GPCA_PREC_I8_EXACT).
+// Exact-integer variants of the two tall-skinny products on v_mfma_i32_32x32x32_i8 (GPCA_PREC_I8_EXACT): the kernels the engine runs
+// by default.  (The register-only reference kernels: gemm_i8_simple.hip; folds and quantisation: fold_quantize_i8.hip.)
 //
 // The dosage bytes 0/1/2 ARE the int8 MFMA operand -- no conversion instruction at all -- and the skinny f32/f64
 // operand X (Q or T') is split per column into kDigits = 4 signed base-128 digits of a fixed-point value
@@ -10,183 +11,11 @@
 // 16 x 64-cycle f32 MFMAs -> ~10x less matrix-core time per byte, so both kernels are HBM-bound
 // (1 B per genotype per pass; roofline = 8 TB/s).
 //
-//   K1  k_gq_i8 :  T = r o (G Q) + b s^T      A = G tile (32 SNPs x 32 samples: 16 B per lane straight from the row),
-//                                             B = digit plane of Q (blocked [chunk][d][lane][16 B])
-//   K2  k_gtt_i8:  Y^T tiles = T'^T G         A = digit plane of T' (blocked [k-block][d][lane][16 B]),
-//                                             B = G^T tile: each lane loads 16 rows x 4 B and transposes the 16x4
-//                                             byte block in registers (32 v_perm_b32) into 4 k-contiguous operands
-#include "kernels.h"
-#include <algorithm>
-#include <cstdlib>
+//   K1  T = r o (G Q) + b s^T     k_gq_d (int8 rows, LDS-DMA, chained rounds), k_gq_n (<= 256 samples), k_gq_2bit (2-bit rows)
+//   K2  Y^T tiles = T'^T G        k_gtt_d (int8 rows, LDS-DMA, chained tasks), k_gtt_p (2-bit rows, cooperative LDS-DMA)
+#include "gemm_i8_common.h"
 
 namespace gpca {
-
-// Kernel switches travel in KernelOpts (kernels.h), read from the environment once per handle at gpca_create:
-//   stream_nt : cache policy of the once-read genotype stream of the per-wave-plane kernels (0 = default, 1 = non-temporal)
-//   dma_nt    : the LDS-DMA genotype streams are full-line pieces read once per pass -> non-temporal by default (measured
-//               1.82 -> 1.71 ms per pass; GPCA_GQ_DMA_NT=0 restores the default cache policy)
-
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-#define GPCA_RSRC_FLAGS 0x00020000
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc8(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, GPCA_RSRC_FLAGS);
-}
-
-// BITS = 7: four signed base-128 digits (28-bit fixed point, the default);  BITS = 8: three signed base-256 digits (24-bit,
-// the packed kernels' fast mode -- plane 3 is all zero and its accumulators are never touched)
-// c = b^T T is summed per 32-row unit (fixed order: 16 rows per lane half, then the two halves), one partial per unit at
-// cunit[unit][32]: whichever wave of whichever launch computes a unit writes the same bits, so resident, sharded and
-// streamed-panel runs agree on c exactly
-#define GPCA_STORE_CUNIT(UNIT) { const float co_ = ct + __shfl_xor(ct, 32); if (h == 0) cunit[(int64_t)(UNIT) * 32 + c] = co_; }
-
-// Shapes the hand-counted DMA pipelines were derived for: sample pitch a multiple of `npad_mult`, row count a multiple of `rows_mult`.
-// The launchers refuse anything else (hipErrorInvalidValue -> GPCA_ERR_HIP with the kernel's name) rather than compute garbage.
-static inline bool dma_shape_ok(int64_t Npad, int64_t npad_mult, int64_t rows, int64_t rows_mult) {
-    return Npad > 0 && Npad % npad_mult == 0 && rows > 0 && rows % rows_mult == 0;
-}
-
-template <int BITS = 7>
-__device__ __forceinline__ double combine_digits(const i32x16 (&a)[kDigits], int e) {
-    // exact: each |a| < 2^31, weights are powers of two, total < 2^53
-    if (BITS == 8) return (double)a[0][e] + 256.0 * (double)a[1][e] + 65536.0 * (double)a[2][e];
-    return (double)a[0][e] + 128.0 * (double)a[1][e] + 16384.0 * (double)a[2][e] + 2097152.0 * (double)a[3][e];
-}
-
-// ask the scheduler for N x { 1 MFMA, V VALU } so that the next step's decode issues in the shadow of the MFMAs
-template <int N, int V>
-__device__ __forceinline__ void interleave_mfma_valu() {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);   // VALU
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1
-// ------------------------------------------------------------------------------------------------
-// G is loaded a 128-sample super-chunk at a time: the four 32-byte pieces of a row's 128-byte line are requested
-// back to back (one L1 miss + three hits) instead of one per compute phase (four L2->L1 line fills, which made
-// the L2->L1 path, not HBM, the limit: 3.7 TB/s).  Q digit planes (L2-resident, full-line reads) ride a 4-stage ring.
-template <int R>
-struct Gq8G { i32x4 g[4][R]; };
-struct Gq8Q { i32x4 q[kDigits]; };
-
-template <int R, int AUX>
-__device__ __forceinline__ void gq8_load_g(Gq8G<R>& b, __amdgpu_buffer_rsrc_t rg, const uint32_t (&gvo)[R], uint32_t s0) {
-#pragma unroll
-    for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b.g[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[t], s0 + 32u * j, AUX);
-}
-template <int ND = kDigits>
-__device__ __forceinline__ void gq8_load_q(Gq8Q& b, __amdgpu_buffer_rsrc_t rq, uint32_t qvo, uint32_t qoff) {
-#pragma unroll
-    for (int d = 0; d < ND; ++d) b.q[d] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, qoff + d * 1024, 0);
-}
-template <int R>
-__device__ __forceinline__ void gq8_compute(const i32x4 (&g)[R], const Gq8Q& q, i32x16 (&acc)[R][kDigits]) {
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-        for (int t = 0; t < R; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(g[t], q.q[d], acc[t][d], 0, 0, 0);
-}
-
-template <int R, int AUX>
-__device__ __forceinline__ void gq8_group(const int8_t* __restrict__ G, int64_t ldg, int64_t nsuper,
-                                          const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
-                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float* __restrict__ cunit, int64_t row0, int c, int h, int lane) {
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
-    uint32_t gvo[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)((32 * t + c) * ldg + 16 * h);
-    const uint32_t qvo = (uint32_t)(lane * 16);
-    constexpr uint32_t QCH = kDigits * 1024;   // bytes of digit planes per 32-sample chunk
-
-    i32x16 acc[R][kDigits];
-#pragma unroll
-    for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
-
-    // nsuper (128-sample super-chunks) is even: samples are padded to a multiple of 256
-    Gq8G<R> GA, GB;
-    Gq8Q Q0, Q1, Q2, Q3;
-    {
-        const __amdgpu_buffer_rsrc_t rq0 = make_rsrc8(Qd);
-        gq8_load_g<R, AUX>(GA, rg, gvo, 0u);
-        gq8_load_q(Q0, rq0, qvo, 0u); gq8_load_q(Q1, rq0, qvo, QCH); gq8_load_q(Q2, rq0, qvo, 2 * QCH);
-    }
-#define GQ8_PHASE(GCUR, J, QCUR, QNEXT, QNEXT_OFF)                         \
-    gq8_load_q(QNEXT, rq, qvo, (QNEXT_OFF));                                \
-    __builtin_amdgcn_sched_barrier(0);                                      \
-    gq8_compute<R>(GCUR.g[J], QCUR, acc);                                   \
-    __builtin_amdgcn_sched_barrier(0);
-    for (int64_t sc = 0; sc < nsuper; sc += 2) {
-        const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd + sc * 4 * QCH);
-        const uint32_t s0 = (uint32_t)(sc * 128);
-        const uint32_t more = (sc + 2 < nsuper) ? 1u : 0u;   // the last trip re-loads its own data (unused)
-        gq8_load_g<R, AUX>(GB, rg, gvo, s0 + 128u);
-        GQ8_PHASE(GA, 0, Q0, Q3, 3 * QCH)
-        GQ8_PHASE(GA, 1, Q1, Q0, 4 * QCH)
-        GQ8_PHASE(GA, 2, Q2, Q1, 5 * QCH)
-        GQ8_PHASE(GA, 3, Q3, Q2, 6 * QCH)
-        gq8_load_g<R, AUX>(GA, rg, gvo, s0 + 256u * more);
-        GQ8_PHASE(GB, 0, Q0, Q3, 7 * QCH)
-        GQ8_PHASE(GB, 1, Q1, Q0, 8 * QCH * more)
-        GQ8_PHASE(GB, 2, Q2, Q1, 8 * QCH * more + QCH)
-        GQ8_PHASE(GB, 3, Q3, Q2, 8 * QCH * more + 2 * QCH)
-    }
-#undef GQ8_PHASE
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-        float ct = 0.f;     // this tile's share of c = b^T T: one partial per 32-row unit, so c does not depend on the grid partition
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float ri = rv[row], bi = bv[row];
-            const float gq = (float)(combine_digits(acc[t], e) * qs);
-            const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
-            ct = __fmaf_rn(bi, tv, ct);
-            Tout[row * ldt + c] = scale_out ? __fmul_rn(ri, tv) : tv;
-        }
-        GPCA_STORE_CUNIT(row0 / 32 + t)
-    }
-}
-
-template <int AUX>
-__global__ __launch_bounds__(256, 1) void k_gq_i8(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nsuper,
-                                                   const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
-                                                   const float* __restrict__ rv, const float* __restrict__ bv,
-                                                   const float* __restrict__ sv, float* __restrict__ Tout,
-                                                   float* __restrict__ cpart, int scale_out, int64_t ldt) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t waves = (int64_t)gridDim.x * 4;
-    int64_t u = (units * wave) / waves;
-    const int64_t u_end = (units * (wave + 1)) / waves;
-    const float sj = sv[c];
-    const double qs = qscale[c];
-    for (; u + 4 <= u_end; u += 4) gq8_group<4, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, u * 32, c, h, lane);
-    if (u + 2 <= u_end) { gq8_group<2, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, u * 32, c, h, lane); u += 2; }
-    if (u + 1 <= u_end) { gq8_group<1, AUX>(G, ldg, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, u * 32, c, h, lane); u += 1; }
-}
-
-void launch_gq_i8(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t N, const int8_t* Qd,
-                  const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
-                  int scale_out, int64_t ldt, const KernelOpts& ko) {
-    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
-    const int64_t nsuper = (N + 255) / 256 * 2;   // 128-sample super-chunks, even count (= Npad / 128)
-    if (ko.stream_nt) hipLaunchKernelGGL((k_gq_i8<2>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
-    else hipLaunchKernelGGL((k_gq_i8<0>), grid, blk, 0, st, G, ldg, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, scale_out, ldt);
-}
 
 // K1 for at most 256 samples (configs[2]'s shape class: 1 066 557 SNPs x 64 samples).  The wide kernels sweep rows padded to 256
 // samples in 128-sample stages and spend most of a launch on padding and per-round prologues (0.5 TB/s at N = 64).  Here the
@@ -350,265 +179,7 @@ Gtt8Plan gtt8_plan_batched(int64_t Mpad, int64_t Npad, int target_waves) {
     return p;
 }
 
-struct Gtt8Buf { int g[16]; i32x4 t[kDigits]; };
-
-template <int AUX>
-__device__ __forceinline__ void gtt8_load(Gtt8Buf& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off, uint32_t ldg,
-                                          __amdgpu_buffer_rsrc_t rt, uint32_t tvo, uint32_t toff) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) b.g[i] = __builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ldg, AUX);
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) b.t[d] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, toff + d * 1024, 0);
-}
-
-// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi: 4..7, lo: 0..3}
-__device__ __forceinline__ int permb(int hi, int lo, unsigned sel) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, sel); }
-
-__device__ __forceinline__ void gtt8_compute(const Gtt8Buf& b, i32x16 (&acc)[4][kDigits]) {
-    // 16 rows x 4 samples of bytes -> 4 operands of 16 k-contiguous bytes (operand t = sample byte t of rows 0..15)
-    i32x4 bt[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const int r0 = b.g[4 * w], r1 = b.g[4 * w + 1], r2 = b.g[4 * w + 2], r3 = b.g[4 * w + 3];
-        const int x0 = permb(r1, r0, 0x05010400u), x1 = permb(r1, r0, 0x07030602u);   // [r0.b0 r1.b0 r0.b1 r1.b1], [..b2 ..b3]
-        const int y0 = permb(r3, r2, 0x05010400u), y1 = permb(r3, r2, 0x07030602u);
-        bt[0][w] = permb(y0, x0, 0x05040100u);   // [r0.b0 r1.b0 r2.b0 r3.b0]
-        bt[1][w] = permb(y0, x0, 0x07060302u);   // byte 1 of rows 4w..4w+3
-        bt[2][w] = permb(y1, x1, 0x05040100u);
-        bt[3][w] = permb(y1, x1, 0x07060302u);
-    }
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.t[d], bt[t], acc[t][d], 0, 0, 0);
-}
-
-// NARROW (at most 256 samples, configs[2]'s shape class): a row has one or two 128-sample blocks, so the four waves of a workgroup
-// take four different ROW chunks (`ngroups` then holds the number of 128-sample blocks that hold samples, 1 or 2) instead of four
-// adjacent sample blocks of one row chunk -- three of which would be padding.
-template <int AUX, bool NARROW = false>
-__global__ __launch_bounds__(256, 1) void k_gtt_i8(const int8_t* __restrict__ G, int64_t ldg, int64_t Mpad, int64_t Npad,
-                                                    const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                    int64_t ngroups, int64_t rows_per_wave) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    // (an XCD-aware block -> (row chunk, n-group) remap was measured: no gain -- the skinny operand is already
-    //  L2/MALL-served -- and its padded grid broke the all-blocks-resident property, so the plain mapping stays)
-    int64_t wchunk, nblock;
-    if (NARROW) {
-        const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
-        nblock = wave % ngroups; wchunk = wave / ngroups;
-        if (wchunk * rows_per_wave >= Mpad) return;
-    } else {
-        const int64_t ngroup = blockIdx.x % ngroups;
-        wchunk = blockIdx.x / ngroups;
-        nblock = ngroup * 4 + wv;
-    }
-    const int64_t n0 = nblock * 128;
-    if (n0 >= Npad) return;
-    const int64_t m_begin = wchunk * rows_per_wave;
-    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
-    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
-
-    i32x16 acc[4][kDigits];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
-
-    const uint32_t gvo = (uint32_t)(16 * h * ldg + 4 * c);
-    const uint32_t tvo = (uint32_t)(lane * 16);
-    constexpr uint32_t TKB = kDigits * 1024;                // bytes of digit planes per 32-row k-block
-    const int8_t* gp = G + m_begin * ldg + n0;
-    const int8_t* tp = Td + (m_begin >> 5) * TKB;
-    // 4-stage register ring over 32-row k-blocks (kblocks is a multiple of 4): 3 blocks in flight per wave
-    Gtt8Buf B0, B1, B2, B3;
-    {
-        const __amdgpu_buffer_rsrc_t rg0 = make_rsrc8(gp), rt0 = make_rsrc8(tp);
-        gtt8_load<AUX>(B0, rg0, gvo, 0u, (uint32_t)ldg, rt0, tvo, 0u);
-        gtt8_load<AUX>(B1, rg0, gvo, 32u * (uint32_t)ldg, (uint32_t)ldg, rt0, tvo, TKB);
-        gtt8_load<AUX>(B2, rg0, gvo, 64u * (uint32_t)ldg, (uint32_t)ldg, rt0, tvo, 2 * TKB);
-    }
-    for (int64_t kb = 0; kb < kblocks; kb += 4) {
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc8(gp + kb * 32 * ldg);   // re-based every trip: offsets stay < 256 * ldg
-        const __amdgpu_buffer_rsrc_t rt = make_rsrc8(tp + kb * TKB);
-        const uint32_t more = (kb + 4 < kblocks) ? 1u : 0u;
-        const uint32_t L32 = 32u * (uint32_t)ldg;
-        gtt8_load<AUX>(B3, rg, gvo, 3u * L32, (uint32_t)ldg, rt, tvo, 3 * TKB);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt8_compute(B0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt8_load<AUX>(B0, rg, gvo, 4u * L32 * more, (uint32_t)ldg, rt, tvo, 4 * TKB * more);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt8_compute(B1, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt8_load<AUX>(B1, rg, gvo, (4u * more + 1u) * L32, (uint32_t)ldg, rt, tvo, (4 * more + 1) * TKB);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt8_compute(B2, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt8_load<AUX>(B2, rg, gvo, (4u * more + 2u) * L32, (uint32_t)ldg, rt, tvo, (4 * more + 2) * TKB);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt8_compute(B3, acc);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // D[j][col]: j = (reg&3) + 8*(reg>>2) + 4*h, col = c -> sample n0 + 4c + t.  Exact integers as f64.
-    double* yp = Ypart + (wchunk * Npad) * 32;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int64_t n = n0 + 4 * c + t;
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
-            double2 o;
-            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
-            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
-        }
-    }
-}
-
-// K2 for at most 256 samples (int8 rows): plan = gtt8_plan_narrow; every wave owns a row chunk of its own
-Gtt8Plan gtt8_plan_narrow(int64_t Mpad, int64_t N, int target_waves) {
-    Gtt8Plan p{};
-    p.nblocks_n = (N + 127) / 128;                      // 128-sample blocks that hold samples: 1 or 2
-    int64_t W = target_waves / p.nblocks_n;
-    if (W < 1) W = 1;
-    const int64_t maxW = Mpad / 128;
-    if (W > maxW) W = maxW;
-    int64_t rpw = (Mpad + W - 1) / W;
-    rpw = (rpw + 127) / 128 * 128;
-    W = (Mpad + rpw - 1) / rpw;
-    p.W = (int)W;
-    p.rows_per_wave = rpw;
-    p.grid = (W * p.nblocks_n + 3) / 4;
-    return p;
-}
-void launch_gtt_n(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                  double* Ypart, const Gtt8Plan& plan) {
-    hipLaunchKernelGGL((k_gtt_i8<2, true>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, plan.nblocks_n, plan.rows_per_wave);
-}
-
-void launch_gtt_i8(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                   double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko) {
-    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
-    if (ko.stream_nt) hipLaunchKernelGGL((k_gtt_i8<2>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
-    else hipLaunchKernelGGL((k_gtt_i8<0>), dim3((unsigned)plan.grid), dim3(256), 0, st, G, ldg, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave);
-}
-
-// Y[n][j] = c[j] + tscale[j] * sum_w Ypart[w][n][j]    (the integer sum is exact and order-independent)
-// SPLIT = 8: the W slices are shared between 8 thread groups of a block (32 consecutive elements each) and folded through LDS --
-// for few samples the one-thread-per-element form leaves a handful of blocks walking W (thousands of) slices one load at a
-// time: 224 us per launch at 1 066 557 x 64 (configs[2]), 30 % of that call.  Same bits either way: the partial sums are integers.
-template <int SPLIT>
-__device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart, int W, int64_t stride, int64_t total, int64_t& e, bool& live) {
-    if (SPLIT == 1) {
-        e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        live = e < total;
-        double s = 0.0;
-        if (live) for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
-        return s;
-    }
-    __shared__ double part[256];
-    const int grp = threadIdx.x >> 5, le = threadIdx.x & 31;
-    e = (int64_t)blockIdx.x * 32 + le;
-    live = e < total;
-    double s = 0.0;
-    if (live) for (int w = grp; w < W; w += 8) s += Ypart[w * stride + e];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (grp != 0) { live = false; return 0.0; }
-#pragma unroll
-    for (int g = 1; g < 8; ++g) s += part[g * 32 + le];
-    return s;
-}
-template <int SPLIT>
-__global__ __launch_bounds__(256) void k_reduce_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
-                                                     const double* __restrict__ cvec, const double* __restrict__ tscale,
-                                                     double* __restrict__ Y, int64_t ldy) {
-    int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
-    if (!live) return;
-    const int j = (int)(e & 31);
-    Y[(e >> 5) * ldy + j] = fma(tscale[j], s, cvec[j]);   // one rounding, the same in k_finish_y_i8
-}
-// one thread per element while that still fills the chip (>= 1024 blocks), 8 threads per element below
-static inline bool reduce_split(int64_t total) { return total < (int64_t)256 * 1024; }
-void launch_reduce_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* c,
-                        const double* tscale, double* Y, int64_t ldy) {
-    const int64_t total = N * 32;
-    if (reduce_split(total)) hipLaunchKernelGGL(k_reduce_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
-    else hipLaunchKernelGGL(k_reduce_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, c, tscale, Y, ldy);
-}
-
-// Streamed panels: the integer partial sums of every panel are added into Yint (exact in f64 while |sum| < 2^53, so the
-// order of the panels does not matter) and scaled once at the end -- the same value, bit for bit, as the one-launch reduce.
-template <int SPLIT>
-__global__ __launch_bounds__(256) void k_accum_y_i8(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
-                                                    double* __restrict__ Yint, int first) {
-    int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
-    if (!live) return;
-    Yint[e] = first ? s : Yint[e] + s;
-}
-__global__ __launch_bounds__(256) void k_finish_y_i8(const double* __restrict__ Yint, int64_t N, const double* __restrict__ cvec,
-                                                     const double* __restrict__ tscale, double* __restrict__ Y, int64_t ldy) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * 32) return;
-    const int j = (int)(e & 31);
-    Y[(e >> 5) * ldy + j] = fma(tscale[j], Yint[e], cvec[j]);
-}
-void launch_accum_y_i8(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, double* Yint, int first) {
-    const int64_t total = N * 32;
-    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_i8<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
-    else hipLaunchKernelGGL(k_accum_y_i8<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, Yint, first);
-}
-void launch_finish_y_i8(hipStream_t st, const double* Yint, int64_t N, const double* c, const double* tscale, double* Y, int64_t ldy) {
-    const int64_t total = N * 32;
-    hipLaunchKernelGGL(k_finish_y_i8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Yint, N, c, tscale, Y, ldy);
-}
-// Fused streamed power iteration: every panel quantises its rows of T' against its OWN column maximum, so its integer sums carry
-// their own scale: Yacc[n][j] (+)= tscale_p[j] * sum_w Ypart[w][n][j]  (exact integer sum, one fma per panel, fixed panel order).
-template <int SPLIT>
-__global__ __launch_bounds__(256) void k_accum_y_scaled(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
-                                                        const double* __restrict__ tscale, double* __restrict__ Yacc, int first) {
-    int64_t e; bool live;
-    const double s = reduce_slices<SPLIT>(Ypart, W, Npad * 32, N * 32, e, live);
-    if (!live) return;
-    Yacc[e] = fma(tscale[e & 31], s, first ? 0.0 : Yacc[e]);
-}
-__global__ __launch_bounds__(256) void k_finish_y_sum(const double* __restrict__ Yacc, int64_t N, const double* __restrict__ cvec,
-                                                      double* __restrict__ Y, int64_t ldy) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * 32) return;
-    Y[(e >> 5) * ldy + (e & 31)] = cvec[e & 31] + Yacc[e];
-}
-void launch_accum_y_scaled(hipStream_t st, const double* Ypart, int W, int64_t Npad, int64_t N, const double* tscale, double* Yacc, int first) {
-    const int64_t total = N * 32;
-    if (reduce_split(total)) hipLaunchKernelGGL(k_accum_y_scaled<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
-    else hipLaunchKernelGGL(k_accum_y_scaled<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ypart, W, Npad, N, tscale, Yacc, first);
-}
-void launch_finish_y_sum(hipStream_t st, const double* Yacc, int64_t N, const double* c, double* Y, int64_t ldy) {
-    const int64_t total = N * 32;
-    hipLaunchKernelGGL(k_finish_y_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Yacc, N, c, Y, ldy);
-}
-// run[c] = max(run[c], max_p apart[p][c]): the column abs-max of T' over the panels seen so far (max is exact in any order)
-__global__ __launch_bounds__(1024) void k_absmax_fold(const double* __restrict__ apart, int64_t P, double* __restrict__ run) {
-    __shared__ double red[1024];
-    const int cc = threadIdx.x & 31, pg = threadIdx.x >> 5;
-    double a = 0.0;
-    for (int64_t p = pg; p < P; p += 32) { const double v = apart[p * 32 + cc]; a = v > a ? v : a; }
-    red[threadIdx.x] = a;
-    __syncthreads();
-    if (pg != 0) return;
-    for (int g = 1; g < 32; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
-    const double r = run[cc];
-    run[cc] = a > r ? a : r;
-}
-void launch_absmax_fold(hipStream_t st, const double* apart, int64_t P, double* run) {
-    hipLaunchKernelGGL(k_absmax_fold, dim3(1), dim3(1024), 0, st, apart, P, run);
-}
+// (the slice-form plan of the narrow K2, gtt8_plan_narrow, lives with that kernel in gemm_i8_simple.hip)
 
 // ================================================================================================
 // 2-bit resident genotypes (GPCA_STORE_2BIT): the same two products with the dosage codes decoded in the prologue.
@@ -807,291 +378,6 @@ void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan
     const int64_t nsuper = Npad / 512;   // Npad is a multiple of 1024 in 2-bit mode -> even
     if (nd == 3) hipLaunchKernelGGL(k_gq_2bit<3>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
     else hipLaunchKernelGGL(k_gq_2bit<kDigits>, grid, blk, 0, st, G2, ld2, plan.units, nsuper, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt);
-}
-
-// ---- K2, packed.  Lane (c, h) loads ONE byte (4 samples) from each of its 16 SNP rows; the four waves of a workgroup
-// cover 128 adjacent bytes of every row.  Four rows are OR-ed into a dword, and operand t is (x >> 2t) & 0x03030303.
-struct Gtt2Buf { unsigned g[16]; i32x4 t[kDigits]; };
-
-// (one-byte loads made the address unit the bottleneck -- 16 buffer_load_ubyte per 32-row block cost ~2700 cycles;
-//  lanes 4j..4j+3 now load the same dword and each extracts its byte)
-__device__ __forceinline__ void gtt2_load(Gtt2Buf& b, __amdgpu_buffer_rsrc_t rg, uint32_t gvo, uint32_t row_off, uint32_t ld2,
-                                          __amdgpu_buffer_rsrc_t rt, uint32_t tvo, uint32_t toff) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) b.g[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, gvo, row_off + (uint32_t)i * ld2, 0);
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) b.t[d] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, toff + d * 1024, 0);
-}
-struct Gtt2Ops { i32x4 bt[4]; };
-__device__ __forceinline__ unsigned gtt2_quad(const Gtt2Buf& b, int w, unsigned bsh) {
-    // this lane's byte (bit offset bsh = 8 * (c & 3)) of rows 4w..4w+3 -> one dword
-    return ((b.g[4 * w] >> bsh) & 0xffu) | (((b.g[4 * w + 1] >> bsh) & 0xffu) << 8) |
-           (((b.g[4 * w + 2] >> bsh) & 0xffu) << 16) | ((b.g[4 * w + 3] >> bsh) << 24);
-}
-__device__ __forceinline__ void gtt2_decode(const Gtt2Buf& b, Gtt2Ops& o, unsigned bsh) {
-    unsigned x[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) x[w] = gtt2_quad(b, w, bsh);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) o.bt[t][w] = (int)((x[w] >> (2 * t)) & 0x03030303u);
-}
-// 16 int8 MFMAs of block k, each followed by one of 16 micro-steps of block k+1's decode (per row quad w: combine 4 byte
-// loads into a dword, then the four shift/mask operands); sched_barrier(0) pins the interleave.
-__device__ __forceinline__ void gtt2_mfma_decode(const Gtt2Buf& b, const Gtt2Ops& o, i32x16 (&acc)[4][kDigits],
-                                                 const Gtt2Buf& bn, Gtt2Ops& on, unsigned bsh) {
-    unsigned x[4];
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.t[d], o.bt[t], acc[t][d], 0, 0, 0);
-            const int m = d * 4 + t, w = m >> 2, ph = m & 3;
-            if (ph == 0) x[w] = gtt2_quad(bn, w, bsh);
-            if (ph == 1) { on.bt[0][w] = (int)(x[w] & 0x03030303u); on.bt[1][w] = (int)((x[w] >> 2) & 0x03030303u); }
-            if (ph == 2) on.bt[2][w] = (int)((x[w] >> 4) & 0x03030303u);
-            if (ph == 3) on.bt[3][w] = (int)((x[w] >> 6) & 0x03030303u);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-}
-
-__global__ __launch_bounds__(256, 1) void k_gtt_2bit(const uint8_t* __restrict__ G2, int64_t ld2, int64_t Mpad, int64_t Npad,
-                                                      const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                      int64_t ngroups, int64_t rows_per_wave) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t ngroup = blockIdx.x % ngroups;
-    const int64_t wchunk = blockIdx.x / ngroups;
-    const int64_t nblock = ngroup * 4 + wv;
-    const int64_t n0 = nblock * 128;
-    if (n0 >= Npad) return;
-    const int64_t m_begin = wchunk * rows_per_wave;
-    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
-    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
-
-    i32x16 acc[4][kDigits];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
-
-    const uint32_t gvo = (uint32_t)(16 * h * ld2 + (c & ~3));   // the dword holding this lane's byte
-    const unsigned bsh = 8u * (unsigned)(c & 3);
-    const uint32_t tvo = (uint32_t)(lane * 16);
-    constexpr uint32_t TKB = kDigits * 1024;
-    const uint8_t* gp = G2 + m_begin * ld2 + (n0 >> 2);
-    const int8_t* tp = Td + (m_begin >> 5) * TKB;
-    Gtt2Buf B0, B1, B2, B3;
-    Gtt2Ops OA, OB;
-    {
-        const __amdgpu_buffer_rsrc_t rg0 = make_rsrc8(gp), rt0 = make_rsrc8(tp);
-        gtt2_load(B0, rg0, gvo, 0u, (uint32_t)ld2, rt0, tvo, 0u);
-        gtt2_load(B1, rg0, gvo, 32u * (uint32_t)ld2, (uint32_t)ld2, rt0, tvo, TKB);
-        gtt2_load(B2, rg0, gvo, 64u * (uint32_t)ld2, (uint32_t)ld2, rt0, tvo, 2 * TKB);
-    }
-    gtt2_decode(B0, OA, bsh);
-    // phase k: load block k+3; the 16 int8 MFMAs of block k and the decode (OR + shift/mask, VALU) of block k+1 share one
-    // scheduling region so that they interleave; operand sets alternate OA / OB
-    for (int64_t kb = 0; kb < kblocks; kb += 4) {
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc8(gp + kb * 32 * ld2);
-        const __amdgpu_buffer_rsrc_t rt = make_rsrc8(tp + kb * TKB);
-        const uint32_t more = (kb + 4 < kblocks) ? 1u : 0u;
-        const uint32_t L32 = 32u * (uint32_t)ld2;
-        gtt2_load(B3, rg, gvo, 3u * L32, (uint32_t)ld2, rt, tvo, 3 * TKB);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt2_mfma_decode(B0, OA, acc, B1, OB, bsh);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt2_load(B0, rg, gvo, 4u * L32 * more, (uint32_t)ld2, rt, tvo, 4 * TKB * more);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt2_mfma_decode(B1, OB, acc, B2, OA, bsh);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt2_load(B1, rg, gvo, (4u * more + 1u) * L32, (uint32_t)ld2, rt, tvo, (4 * more + 1) * TKB);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt2_mfma_decode(B2, OA, acc, B3, OB, bsh);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt2_load(B2, rg, gvo, (4u * more + 2u) * L32, (uint32_t)ld2, rt, tvo, (4 * more + 2) * TKB);
-        __builtin_amdgcn_sched_barrier(0);
-        gtt2_mfma_decode(B3, OB, acc, B0, OA, bsh);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    double* yp = Ypart + (wchunk * Npad) * 32;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int64_t n = n0 + 4 * c + t;
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
-            double2 o;
-            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
-            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
-        }
-    }
-}
-
-void launch_gtt_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                     double* Ypart, const Gtt8Plan& plan) {
-    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
-    hipLaunchKernelGGL(k_gtt_2bit, dim3((unsigned)plan.grid), dim3(256), 0, st, G2, ld2, Mpad, Npad, Td, Ypart, ngroups,
-                       plan.rows_per_wave);
-}
-
-// ================================================================================================
-// K1 with the digit planes of Q shared through LDS (int8-resident genotypes).
-// A workgroup owns a contiguous range of 32-row units and walks it in rounds of 4 waves x R tiles; inside a round all
-// four waves sweep the sample axis together, so one fetch of the planes serves the workgroup: wave w brings plane
-// d = w of each 128-sample stage (4 MFMA steps, 16 KiB) into a double-buffered LDS slot, everyone reads its operands
-// back with ds_read_b128.  Tiles past the end of the range recompute a valid tile and skip the store.
-// ================================================================================================
-template <int R>
-__device__ __forceinline__ void gqx_phase(const i32x4 (&g)[R], const Gq8Q& qc, i32x16 (&acc)[R][kDigits], Gq8Q& qn,
-                                          const i32x4* lds_next) {
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) {
-        qn.q[d] = lds_next[d * 64];
-#pragma unroll
-        for (int t = 0; t < R; ++t) acc[t][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(g[t], qc.q[d], acc[t][d], 0, 0, 0);
-    }
-}
-
-template <int R>
-__device__ __forceinline__ void gqx_round(const int8_t* __restrict__ G, int64_t ldg, int64_t nstage,
-                                          const int8_t* __restrict__ Qd, i32x4 (*tds)[4][kDigits][64], int wv, int lane, int c,
-                                          int h, int64_t unit0, int nvalid, double qs, const float* __restrict__ rv,
-                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float* __restrict__ cunit, float& amax) {
-    const int64_t row0 = unit0 * 32;
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G + row0 * ldg);
-    uint32_t gvo[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)(((t < nvalid ? 32 * t : 0) + c) * ldg + 16 * h);
-    constexpr uint32_t QCH = kDigits * 1024;
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc8(Qd + wv * 1024);    // this wave's plane
-    const uint32_t qvo = (uint32_t)(lane * 16);
-
-    i32x16 acc[R][kDigits];
-#pragma unroll
-    for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
-
-    Gq8G<R> GA, GB;
-    Gq8Q QA, QB;
-    i32x4 PL0[4], PL1[4];
-    gq8_load_g<R, 0>(GA, rg, gvo, 0u);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) PL0[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, j * QCH, 0);
-    {
-        const uint32_t s1 = nstage > 1 ? 4u : 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (s1 + j) * QCH, 0);
-    }
-    __syncthreads();                       // the previous round's last LDS reads are done
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tds[0][j][wv][lane] = PL0[j];
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) QA.q[d] = tds[0][0][d][lane];
-
-#define GQX_STAGE(GCUR, GNXT, ST, SLOT)                                                                  \
-    {                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) tds[(SLOT) ^ 1][j][wv][lane] = PL1[j];             \
-        const uint32_t s2_ = ((ST) + 2 < nstage) ? (uint32_t)((ST) + 2) : 0u;                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
-            PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, qvo, (s2_ * 4u + j) * QCH, 0);            \
-        const uint32_t g1_ = ((ST) + 1 < nstage) ? (uint32_t)((ST) + 1) : 0u;                            \
-        gq8_load_g<R, 0>(GNXT, rg, gvo, g1_ * 128u);                                                     \
-        const i32x4* cur_ = &tds[(SLOT)][0][0][lane];                                                    \
-        const i32x4* nxt_ = &tds[(SLOT) ^ 1][0][0][lane];                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        gqx_phase<R>(GCUR.g[0], QA, acc, QB, cur_ + 1 * kDigits * 64);                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        gqx_phase<R>(GCUR.g[1], QB, acc, QA, cur_ + 2 * kDigits * 64);                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        gqx_phase<R>(GCUR.g[2], QA, acc, QB, cur_ + 3 * kDigits * 64);                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        __syncthreads();                                                                                 \
-        gqx_phase<R>(GCUR.g[3], QB, acc, QA, nxt_);                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-    }
-    for (int64_t st = 0; st < nstage; st += 2) {     // nstage (128-sample stages) is even
-        GQX_STAGE(GA, GB, st, 0)
-        GQX_STAGE(GB, GA, st + 1, 1)
-    }
-#undef GQX_STAGE
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-        if (t < nvalid) {
-            float ct = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float ri = rv[row], bi = bv[row];
-                const float gq = (float)(combine_digits(acc[t], e) * qs);
-                const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
-                ct = __fmaf_rn(bi, tv, ct);
-                const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
-                amax = fmaxf(amax, fabsf(ov));
-                Tout[row * ldt + c] = ov;
-            }
-            GPCA_STORE_CUNIT(unit0 + t)
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void k_gq_x(const int8_t* __restrict__ G, int64_t ldg, int64_t units, int64_t nstage,
-                                                  const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
-                                                  const float* __restrict__ rv, const float* __restrict__ bv,
-                                                  const float* __restrict__ sv, float* __restrict__ Tout,
-                                                  float* __restrict__ cpart, double* __restrict__ apart, int scale_out,
-                                                  int rmax, int64_t ldt) {
-    __shared__ i32x4 tds[2][4][kDigits][64];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t u0 = (units * (int64_t)blockIdx.x) / gridDim.x;          // this workgroup's range of 32-row units
-    const int64_t u1 = (units * ((int64_t)blockIdx.x + 1)) / gridDim.x;
-    float amax = 0.f;
-    const float sj = sv[c];
-    const double qs = qscale[c];
-    int64_t u = u0;
-    while (u < u1) {
-        const int64_t rem = u1 - u;
-        if (rem > 8 && rmax >= 4) {           // 4 tiles per wave
-            const int64_t mine = u + 4 * wv;
-            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 4 ? 4 : u1 - mine));
-            gqx_round<4>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
-            u += 16;
-        } else if (rem > 4 && rmax >= 2) {    // 2 tiles per wave
-            const int64_t mine = u + 2 * wv;
-            const int nv = (int)(mine >= u1 ? 0 : (u1 - mine > 2 ? 2 : u1 - mine));
-            gqx_round<2>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
-            u += 8;
-        } else {                 // 1 tile per wave
-            const int64_t mine = u + wv;
-            const int nv = mine < u1 ? 1 : 0;
-            gqx_round<1>(G, ldg, nstage, Qd, tds, wv, lane, c, h, nv ? mine : u, nv, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax);
-            u += 4;
-        }
-    }
-    const float am = fmaxf(amax, __shfl_xor(amax, 32));   // column abs-max of this wave's output rows (for the digit scale)
-    if (h == 0) apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am;
-}
-
-int launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
-                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                 int scale_out, int64_t ldt, const KernelOpts& ko) {
-    if (!dma_shape_ok(Npad, 256, plan.units * 32, 32)) return (int)hipErrorInvalidValue;
-    const dim3 grid((unsigned)(plan.waves / 4)), blk(256);
-    const int64_t nstage = Npad / 128;    // even (checked above): the plane slots alternate per stage
-    const int rmax = ko.gq_r;
-    hipLaunchKernelGGL(k_gq_x, grid, blk, 0, st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, rmax, ldt);
-    return 0;
 }
 
 // ================================================================================================
@@ -1496,17 +782,15 @@ int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan
     // (5 MB of planes) and any phase at 100k (12.8 MB) measured slower than lockstep, so long sample axes stay in lockstep.
     int phase = ko.gq_phase;
     if (phase < 0) phase = (nstage >= 16 && nstage <= 400) ? (int)((nstage / 8) << 16) : 0;
-    if (ko.dma_nt) hipLaunchKernelGGL((k_gq_d<1>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain, phase);
-    else hipLaunchKernelGGL((k_gq_d<0>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain, phase);
+    hipLaunchKernelGGL((k_gq_d<1>), grid, blk, sizeof(GqdSmem), st, G, ldg, plan.units, nstage, Qd, qscale, r, b, s, Tout, cpart, apart, scale_out, ldt, ko.gq_chain, phase);      // (genotype DMAs non-temporal: every line is read once per pass; measured 1.82 -> 1.71 ms per pass)
     return 0;
 }
 
 // ================================================================================================
-// K2 with the digit planes of T' shared through LDS (int8-resident and packed genotypes).
-// The four waves of a workgroup own four adjacent 128-sample blocks and the SAME row range, so they consume the
-// same planes.  Wave w fetches plane d = w (1 KiB per 32-row block) into registers and writes it to a double-buffered
-// LDS stage of 4 blocks (16 KiB); everyone reads its operands back with conflict-free ds_read_b128.  L2 -> CU traffic
-// for the planes drops 4x (it equalled the int8 genotype traffic and was 4x the packed one).  One barrier per stage.
+// K2 building blocks shared by the two DMA kernels (k_gtt_d on int8 rows, k_gtt_p on 2-bit rows): the four waves of a workgroup own
+// four adjacent 128-sample blocks and the SAME row range, so they consume the same digit planes of T' -- wave w brings plane w of a
+// stage into LDS, everyone reads its operands back with conflict-free ds_read_b128 -- and a block's operands are decoded (byte
+// transpose / 2-bit spread) in micro-steps pinned between the MFMAs of the block before.
 // ================================================================================================
 template <bool PACKED>
 struct GttXG { unsigned g[16]; };
@@ -1577,115 +861,6 @@ __device__ __forceinline__ void gttx_phase(const GttXT& tc, const Gtt2Ops& oc, i
             gttx_decode_step<PACKED, ABL>(gn, on, x, y, m, bsh);
             __builtin_amdgcn_sched_barrier(0);
         }
-}
-
-template <bool PACKED>
-__global__ __launch_bounds__(256, 1) void k_gtt_x(const uint8_t* __restrict__ Gb, int64_t ldr, int64_t Mpad, int64_t Npad,
-                                                   const int8_t* __restrict__ Td, double* __restrict__ Ypart,
-                                                   int64_t ngroups, int64_t rows_per_wave, int xcd_remap) {
-    __shared__ i32x4 tds[2][4][kDigits][64];   // [slot][block in stage][plane][lane]: 2 x 16 KiB
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    // workgroup b runs on XCD b % 8 (round-robin dispatch).  With the remap the workgroups of one XCD take CONSECUTIVE
-    // virtual ids, so the n-groups that share a row chunk -- and therefore the same digit planes of T' -- sit behind one
-    // L2 and fetch those planes from HBM once instead of once per XCD.
-    int64_t vb = blockIdx.x;
-    if (xcd_remap) {
-        const int64_t q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
-        vb = x * q + (x < r ? x : r) + blockIdx.x / 8;
-    }
-    const int64_t ngroup = vb % ngroups;
-    const int64_t wchunk = vb / ngroups;
-    const int64_t nblock = ngroup * 4 + wv;
-    int64_t n0 = nblock * 128;
-    const bool live = n0 < Npad;          // a dead wave (ragged last group) still loads planes and joins the barriers
-    if (!live) n0 = 0;
-    const int64_t m_begin = wchunk * rows_per_wave;
-    const int64_t m_end = (m_begin + rows_per_wave < Mpad) ? m_begin + rows_per_wave : Mpad;
-    const int64_t kblocks = (m_end - m_begin) >> 5;   // multiple of 4
-    const int64_t nstage = kblocks >> 2;
-
-    i32x16 acc[4][kDigits];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][d][e] = 0;
-
-    const uint32_t gvo = PACKED ? (uint32_t)(16 * h * ldr + (c & ~3)) : (uint32_t)(16 * h * ldr + 4 * c);
-    const unsigned bsh = 8u * (unsigned)(c & 3);
-    const uint8_t* gp = Gb + m_begin * ldr + (PACKED ? (n0 >> 2) : n0);
-    constexpr uint32_t TKB = kDigits * 1024;
-    const int8_t* tp = Td + (m_begin >> 5) * TKB + wv * 1024;    // this wave's plane
-    const uint32_t tvo = (uint32_t)(lane * 16);
-    const uint32_t L32 = 32u * (uint32_t)ldr;
-
-    GttXG<PACKED> B0, B1, B2, B3;
-    Gtt2Ops OA, OB;
-    GttXT TA, TB;
-    i32x4 PL0[4], PL1[4];     // plane w of stages s+1 / s+2 on their way to LDS
-    {
-        const __amdgpu_buffer_rsrc_t rg0 = make_rsrc8(gp), rt0 = make_rsrc8(tp);
-        gttx_load_g<PACKED>(B0, rg0, gvo, 0u, (uint32_t)ldr);
-        gttx_load_g<PACKED>(B1, rg0, gvo, L32, (uint32_t)ldr);
-        gttx_load_g<PACKED>(B2, rg0, gvo, 2u * L32, (uint32_t)ldr);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) PL0[j] = __builtin_amdgcn_raw_buffer_load_b128(rt0, tvo, j * TKB, 0);             // stage 0
-        const uint32_t s1 = nstage > 1 ? 4u : 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rt0, tvo, (s1 + j) * TKB, 0);      // stage 1
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tds[0][j][wv][lane] = PL0[j];
-    }
-    __syncthreads();
-    gttx_decode<PACKED>(B0, OA, bsh);
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) TA.t[d] = tds[0][0][d][lane];
-
-    for (int64_t st = 0; st < nstage; ++st) {
-        const int slot = (int)(st & 1);
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc8(gp + st * 128 * ldr);
-        const __amdgpu_buffer_rsrc_t rt = make_rsrc8(tp + st * 4 * TKB);
-        const uint32_t more = (st + 1 < nstage) ? 1u : 0u;
-        // planes: stage st+1 (in PL1) -> LDS slot^1 ; fetch stage st+2 into PL0 (then swap roles by copy)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tds[slot ^ 1][j][wv][lane] = PL1[j];
-        const uint32_t s2 = (st + 2 < nstage) ? 8u : 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) PL1[j] = __builtin_amdgcn_raw_buffer_load_b128(rt, tvo, (s2 + j) * TKB, 0);
-        const i32x4* cur = &tds[slot][0][0][lane];
-        const i32x4* nxt = &tds[slot ^ 1][0][0][lane];
-        // block 0 of the stage (operands TA/OA ready); next = block 1
-        gttx_load_g<PACKED>(B3, rg, gvo, 3u * L32, (uint32_t)ldr);
-        __builtin_amdgcn_sched_barrier(0);
-        gttx_phase<PACKED>(TA, OA, acc, B1, OB, TB, cur + 1 * kDigits * 64, bsh);
-        gttx_load_g<PACKED>(B0, rg, gvo, 4u * L32 * more, (uint32_t)ldr);
-        __builtin_amdgcn_sched_barrier(0);
-        gttx_phase<PACKED>(TB, OB, acc, B2, OA, TA, cur + 2 * kDigits * 64, bsh);
-        gttx_load_g<PACKED>(B1, rg, gvo, (4u * more + 1u) * L32, (uint32_t)ldr);
-        __builtin_amdgcn_sched_barrier(0);
-        gttx_phase<PACKED>(TA, OA, acc, B3, OB, TB, cur + 3 * kDigits * 64, bsh);
-        gttx_load_g<PACKED>(B2, rg, gvo, (4u * more + 2u) * L32, (uint32_t)ldr);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();     // stage st+1 is in LDS slot^1 for everyone; slot may be overwritten next trip after its last reads below
-        gttx_phase<PACKED>(TB, OB, acc, B0, OA, TA, nxt, bsh);   // block 3; prefetches block 0 of the next stage from slot^1
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!live) return;
-    double* yp = Ypart + (wchunk * Npad) * 32;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int64_t n = n0 + 4 * c + t;
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
-            double2 o;
-            o.x = combine_digits(acc[t], e); o.y = combine_digits(acc[t], e + 1);
-            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
-        }
-    }
 }
 
 // ================================================================================================
@@ -2046,19 +1221,9 @@ int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int
                  const Gtt8Plan& plan, const KernelOpts& ko) {
     if (plan.tasks_per_wg < 1 || plan.S * 128 != Mpad || !dma_shape_ok(Npad, 256, Mpad, kGQRowsPerWave) || ldg < Npad) return (int)hipErrorInvalidValue;   // 128-row stages, 256-sample pitch
     const dim3 grid((unsigned)plan.grid), blk(256);
-    const int remap = ko.gtt_xcd;   // measured 5.10 -> 5.00 ms per step
-    if (ko.dma_nt) hipLaunchKernelGGL((k_gtt_d<1>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
-    else hipLaunchKernelGGL((k_gtt_d<0>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
+    const int remap = ko.gtt_xcd;   // (1 in the product; the kbench harness turns it off: + 5-15 % without it)
+    hipLaunchKernelGGL((k_gtt_d<1>), grid, blk, sizeof(GqdSmem), st, (const uint8_t*)G, ldg, Npad, Td, Ypart, plan.S, plan.C, plan.ngroups, plan.W, plan.tasks_per_wg, plan.strided, remap);
     return 0;
-}
-
-void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                  double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko) {
-    const int64_t ngroups = (plan.nblocks_n + 3) / 4;
-    const dim3 grid((unsigned)plan.grid), blk(256);
-    const int remap = ko.gttx_xcd;
-    if (packed) hipLaunchKernelGGL((k_gtt_x<true>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
-    else hipLaunchKernelGGL((k_gtt_x<false>), grid, blk, 0, st, (const uint8_t*)Gb, ldr, Mpad, Npad, Td, Ypart, ngroups, plan.rows_per_wave, remap);
 }
 
 // The LDS-DMA kernels use more than 64 KiB of dynamic LDS: the opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is recorded
@@ -2068,129 +1233,11 @@ int init_device_kernels_i8() {
     int e = 0;
 #define GPCA_OPT_IN(KERNEL, BYTES) \
     if (e == 0) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));
-    GPCA_OPT_IN((k_gq_d<0>), sizeof(GqdSmem)) GPCA_OPT_IN((k_gq_d<1>), sizeof(GqdSmem))
+    GPCA_OPT_IN((k_gq_d<1>), sizeof(GqdSmem))
     GPCA_OPT_IN((k_gtt_p<kDigits>), sizeof(GtpSmem)) GPCA_OPT_IN((k_gtt_p<3>), sizeof(GtpSmem))
-    GPCA_OPT_IN((k_gtt_d<0>), sizeof(GqdSmem)) GPCA_OPT_IN((k_gtt_d<1>), sizeof(GqdSmem))
+    GPCA_OPT_IN((k_gtt_d<1>), sizeof(GqdSmem))
 #undef GPCA_OPT_IN
     return e;
 }
-
-// ------------------------------------------------------------------------------------------------
-// Quantisation of the skinny operand: column abs-max -> scale; X[rows][32] -> digit planes
-// blocked [block = row/32][d][lane = 32*((row%32)/16) + col][j = row%16] (16 B per lane per plane).
-// ------------------------------------------------------------------------------------------------
-constexpr int kAbsmaxRowsPerBlock = 1024;
-int64_t absmax_num_parts(int64_t rows) { return (rows + kAbsmaxRowsPerBlock - 1) / kAbsmaxRowsPerBlock; }
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_col_absmax(const T* __restrict__ X, int64_t rows, double* __restrict__ part, int64_t ldx) {
-    __shared__ double red[256];
-    const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int64_t r0 = (int64_t)blockIdx.x * kAbsmaxRowsPerBlock;
-    const int64_t r1 = (r0 + kAbsmaxRowsPerBlock < rows) ? r0 + kAbsmaxRowsPerBlock : rows;
-    double a = 0.0;
-    for (int64_t n = r0 + rg; n < r1; n += 8) { const double v = fabs((double)X[n * ldx + cc]); a = v > a ? v : a; }
-    red[threadIdx.x] = a;
-    __syncthreads();
-    if (rg == 0) {
-        for (int g = 1; g < 8; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
-        part[(int64_t)blockIdx.x * 32 + cc] = a;
-    }
-}
-// scale[j] = colmax_j / S (multiplier back to real units), inv[j] = S / colmax_j; colmax 0 -> scale 0, inv 0
-__global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict__ part, int64_t P, double* __restrict__ scale,
-                                                       double* __restrict__ inv, double S) {
-    __shared__ double red[1024];
-    const int cc = threadIdx.x & 31, pg = threadIdx.x >> 5;   // 32 part-groups
-    double a = 0.0;
-    int64_t p = pg;
-    for (; p + 96 < P; p += 128) {       // four loads in flight per thread (the one-load loop waited for each: 10 us for 256 KB)
-        const double v0 = part[p * 32 + cc], v1 = part[(p + 32) * 32 + cc], v2 = part[(p + 64) * 32 + cc], v3 = part[(p + 96) * 32 + cc];
-        a = fmax(fmax(a, fmax(v0, v1)), fmax(v2, v3));
-    }
-    for (; p < P; p += 32) { const double v = part[p * 32 + cc]; a = v > a ? v : a; }
-    red[threadIdx.x] = a;
-    __syncthreads();
-    if (pg != 0) return;
-    for (int g = 1; g < 32; ++g) { const double v = red[g * 32 + cc]; a = v > a ? v : a; }
-    scale[cc] = a > 0.0 ? a / S : 0.0;
-    inv[cc] = a > 0.0 ? S / a : 0.0;
-}
-
-// layout 0: block = 32 consecutive rows, lane half hh, element j -> row 32*blk + 16*hh + j
-// layout 1 (packed K1): block = MFMA step (b, s) of a 128-row group -> row 128*(blk/4) + 64*hh + 16*(blk%4) + j
-// The 16 loads of a lane are unconditional (row index clamped, the value zeroed afterwards) and issued together: with a
-// predicated load per element the compiler waited for each one before asking for the next (16 serial latencies per lane,
-// 3.8 TB/s on the 256 MB of a T' pass); ND is a template parameter so that the digit loop carries no runtime branch.
-template <int ND>
-__device__ __forceinline__ void split_digits(int v, unsigned (&w)[kDigits][4], int j) {
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d) {
-        int dg;
-        if (ND == 3) { if (d < 2) { dg = ((v + 128) & 255) - 128; v = (v - dg) >> 8; } else { dg = v; v = 0; } }    // base 256, plane 3 = 0
-        else if (d < kDigits - 1) { dg = ((v + 64) & 127) - 64; v = (v - dg) >> 7; } else dg = v;
-        w[d][j >> 2] |= ((unsigned)(dg & 0xff)) << (8 * (j & 3));
-    }
-}
-template <typename T, int ND>
-__global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64_t rows, int64_t rows_pad,
-                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int64_t ldx) {
-    const int lane = threadIdx.x & 63;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk * 32 >= rows_pad) return;
-    const int cc = lane & 31, hh = lane >> 5;
-    const double sc = inv[cc];
-    const int64_t rbase = layout ? (blk >> 2) * 128 + 64 * hh + 16 * (blk & 3) : blk * 32 + 16 * hh;
-    T xv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int64_t row = rbase + j;
-        xv[j] = X[(row < rows ? row : rows - 1) * ldx + cc];
-    }
-    unsigned w[kDigits][4];
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[d][q] = 0u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double x = rbase + j < rows ? (double)xv[j] : 0.0;
-        split_digits<ND>(__double2int_rn(x * sc), w, j);          // |x * sc| <= 0.49 * 2^28 (2^24 in three-plane mode): 32-bit digit arithmetic
-    }
-#pragma unroll
-    for (int d = 0; d < kDigits; ++d)
-        *reinterpret_cast<uint4*>(Xd + ((blk * kDigits + d) * 64 + lane) * 16) = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
-}
-template <typename T>
-static void launch_k_quantize(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) {
-    const int64_t blocks = rows_pad / 32;
-    const dim3 grid((unsigned)((blocks + 3) / 4)), blk(256);
-    if (nd == 3) hipLaunchKernelGGL((k_quantize<T, 3>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx);
-    else hipLaunchKernelGGL((k_quantize<T, kDigits>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx);
-}
-
-template <typename T>
-static void quantize_t(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, double* part, double* scale, double* inv,
-                       int8_t* Xd, int layout, int nd, int64_t ldx) {
-    const int64_t P = absmax_num_parts(rows);
-    hipLaunchKernelGGL((k_col_absmax<T>), dim3((unsigned)P), dim3(256), 0, st, X, rows, part, ldx);
-    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, (const double*)part, P, scale, inv, digit_scale(nd));
-    launch_k_quantize<T>(st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
-}
-// abs-max partials already produced by the kernel that wrote X (K1 epilogue): finish the scale and quantise
-void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
-                                double* scale, double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) {
-    hipLaunchKernelGGL(k_finish_scale, dim3(1), dim3(1024), 0, st, apart, P, scale, inv, digit_scale(nd));
-    launch_k_quantize<float>(st, X, rows, rows_pad, (const double*)inv, Xd, layout, nd, ldx);
-}
-// quantise X (f64) with a column scale that is already on the device (k_finish_q)
-void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout,
-                                   int nd, int64_t ldx) {
-    launch_k_quantize<double>(st, X, rows, rows_pad, inv, Xd, layout, nd, ldx);
-}
-void launch_quantize_f32(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) { quantize_t<float>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd, ldx); }
-void launch_quantize_f64(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, double* part, double* scale,
-                         double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) { quantize_t<double>(st, X, rows, rows_pad, part, scale, inv, Xd, layout, nd, ldx); }
 
 }  // namespace gpca

@@ -57,8 +57,6 @@ extern "C" const char* gpca_last_error(gpca_handle* h) {
     return h->err.c_str();
 }
 
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-
 extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (!out) return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: out is NULL");
     *out = nullptr;
@@ -82,28 +80,22 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
         // digit_planes = 0 leaves the choice to the library: four planes on int8 rows (HBM-bound: the planes cost nothing there), THREE
         // on 2-bit rows, whose kernels are matrix-core bound (a quarter less work).  Round 3 ran the whole parity suite and
         // scripts/planes3_parity.py under both settings: three planes sit within 3e-7 (max|dPC|) / 5e-8 (eigenvalues) of the f64
-        // checker on every shape -- closer than the f32-MFMA path (7e-7 / 2e-7).  GPCA_PACKED_PLANES=4 restores four.
-        if (dp == 0 && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT) {
-            const char* e = getenv("GPCA_PACKED_PLANES");
-            h->nd = (e && atoi(e) == 4) ? 4 : 3;
-        }
+        // checker on every shape -- closer than the f32-MFMA path (7e-7 / 2e-7).  digit_planes = 4 asks for four.
+        if (dp == 0 && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT) h->nd = 3;
     }
-    // diagnostic switches, read once per handle (defaults are the tuned values; DESIGN.md "Diagnostic switches")
-    h->gq_waves_target = std::max(4, env_int("GPCA_GQ_WAVES", h->gq_waves_target));
-    h->gtt_waves_target = std::max(4, env_int("GPCA_GTT_WAVES", h->gtt_waves_target));
-    h->lds_planes = env_int("GPCA_LDS_PLANES", h->lds_planes);
-    h->compact_ok = env_int("GPCA_COMPACT", h->compact_ok);
-    h->narrow_ok = env_int("GPCA_NARROW", h->narrow_ok);
-    h->gq_dma = env_int("GPCA_GQ_DMA", h->gq_dma);
-    h->spin_sync = env_int("GPCA_SPIN_SYNC", h->spin_sync);
-    h->gtt_dma = env_int("GPCA_GTT_DMA", h->gtt_dma);
-    h->ko.stream_nt = env_int("GPCA_STREAM_NT", 0) != 0;
-    h->ko.dma_nt = env_int("GPCA_GQ_DMA_NT", 1) != 0;
-    h->ko.gq_r = env_int("GPCA_GQ_R", 4);
-    h->ko.gq_chain = env_int("GPCA_GQ_CHAIN", 1) != 0;
-    h->ko.gq_phase = env_int("GPCA_GQ_PHASE", h->ko.gq_phase);
-    h->ko.gtt_xcd = env_int("GPCA_GTT_XCD", 1);
-    h->ko.gttx_xcd = env_int("GPCA_GTTX_XCD", 0);
+    // The kernel choice is the CALLER's (gpca_config.reserved[0..2], include/gpca.h), never the process environment's:
+    // reserved[0] = GPCA_CFG_* flags, reserved[1] / reserved[2] = resident-wave targets of K1 / K2 (0 = the tuned defaults).
+    {
+        const int32_t flags = cfg ? cfg->reserved[0] : 0, gqw = cfg ? cfg->reserved[1] : 0, gtw = cfg ? cfg->reserved[2] : 0;
+        if ((flags & ~GPCA_CFG_ALL) != 0 || gqw < 0 || gtw < 0 || (cfg && cfg->reserved[3] != 0)) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown bits in gpca_config.reserved"); }
+        h->simple_kernels = (flags & GPCA_CFG_SIMPLE_KERNELS) != 0;
+        h->compact_ok = (flags & GPCA_CFG_NO_COMPACT) == 0;
+        h->narrow_ok = (flags & GPCA_CFG_NO_NARROW) == 0;
+        h->spin_sync = (flags & GPCA_CFG_NO_SPIN_SYNC) == 0;
+        if (gqw) h->gq_waves_target = std::max(4, (int)gqw);
+        if (gtw) h->gtt_waves_target = std::max(4, (int)gtw);
+        if (h->simple_kernels && h->nd == 3 && !(cfg && cfg->digit_planes == 3)) h->nd = 3;     // (the reference packed K2 takes either plane count)
+    }
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
         delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
     }

@@ -153,7 +153,7 @@ struct gpca_handle {
     bool have_rsvd = false;
     float *dQ = nullptr, *dT = nullptr, *dTb = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
     double* h_pin = nullptr;     // pinned host staging for the l x l blocks of the final eigenproblem (W | Z | flag)
-    int spin_sync = 1;           // busy-poll the stream at the two syncs of gpca_rsvd (GPCA_SPIN_SYNC=0: hipStreamSynchronize)
+    int spin_sync = 1;           // busy-poll the stream at the two syncs of gpca_rsvd (GPCA_CFG_NO_SPIN_SYNC: hipStreamSynchronize)
     int* d_cholflag = nullptr;   // first failed CholeskyQR pivot + 1 (0 = ok), written by k_chol_inv
     double *d_scratch64 = nullptr, *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
     double* d_tr64 = nullptr; size_t cap_tr64 = 0;   // [N][k] compacted output of gpca_transform
@@ -201,10 +201,8 @@ struct gpca_handle {
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
     int nd = 4;           // digit planes of the exact path (gpca_config.digit_planes): 4 x base 128, or 3 x base 256 (packed storage)
-    int gtt_dma = 1;      // K2 (int8-resident) by LDS-DMA (GPCA_GTT_DMA=0: register-staged k_gtt_x)
-    int gq_dma = 1;       // K1 (int8-resident) genotype loads by LDS-DMA, full-line pieces (GPCA_GQ_DMA=0: register-staged k_gq_x)
-    int lds_planes = 1;   // share the digit planes of the exact GEMMs through LDS (GPCA_LDS_PLANES=0 disables)
-    int narrow_ok = 1;    // matrices of at most 256 samples (int8 rows) run the narrow K1 / K2 (GPCA_NARROW=0: the wide kernels on padded rows)
+    int simple_kernels = 0;   // gpca_config.reserved[0] & GPCA_CFG_SIMPLE_KERNELS: the register-only reference kernels (gemm_i8_simple.hip)
+    int narrow_ok = 1;    // matrices of at most 256 samples (int8 rows) run the narrow K1 / K2 (GPCA_CFG_NO_NARROW: the wide kernels on padded rows)
     int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X
 
     // Compact child: when QC dropped most SNP rows (the reference's solver only ever sees the PCA SNPs, prepare.rs:1465-1469), the kept
@@ -215,7 +213,7 @@ struct gpca_handle {
     bool child_valid = false, rsvd_on_child = false;
     bool is_child = false;           // (a child never compacts again and does not own its stream)
     const int64_t* d_row_ids = nullptr;   // child: original row of every row (the parent's d_pca_rows; not owned)
-    int compact_ok = 1;              // GPCA_COMPACT=0: never compact
+    int compact_ok = 1;              // GPCA_CFG_NO_COMPACT: never compact
 
     // comm
     int world = 1, rank = 0;

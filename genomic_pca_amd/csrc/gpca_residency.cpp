@@ -145,8 +145,8 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     if (h->storage == GPCA_STORE_2BIT) {
         h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4; h->ld8 = h->ldg;
         // row pitch an odd multiple of 256 B, like the int8 rows below: 1.9 % on the packed K1 (in-process A/B, both engine orders:
-        // 1.145 / 1.142 ms padded vs 1.167 / 1.164), nothing on K2; GPCA_PITCH_PAD=0 restores ldg / 4
-        if (!(getenv("GPCA_PITCH_PAD") && atoi(getenv("GPCA_PITCH_PAD")) == 0) && !((h->ld2 / 256) & 1)) h->ld2 += 256;
+        // 1.145 / 1.142 ms padded vs 1.167 / 1.164), nothing on K2; (measured with an environment switch that is gone)
+        if (!((h->ld2 / 256) & 1)) h->ld2 += 256;
         if (!resident) return GPCA_OK;
         HIPCHK(malloc_genotypes(h, (void**)&h->dG2, (size_t)h->Mpad * (size_t)h->ld2));
         if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG2 + (size_t)M * (size_t)h->ld2, 0, (size_t)(h->Mpad - M) * (size_t)h->ld2, h->st));
@@ -157,7 +157,6 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     // than rows an odd multiple apart (profiles/r1_kbench_summary.md section 6): 8 rows of one DMA piece then spread over fewer
     // channels.  The pitch gets one extra 256-byte block in that case; the kernels never read past ldg.
     h->ld8 = ((h->ldg / 256) & 1) ? h->ldg : h->ldg + 256;
-    if (getenv("GPCA_PITCH_PAD") && atoi(getenv("GPCA_PITCH_PAD")) == 0) h->ld8 = h->ldg;
     if (!resident) return GPCA_OK;
     HIPCHK(malloc_genotypes(h, (void**)&h->dG, (size_t)h->Mpad * (size_t)h->ld8));
     if (h->Mpad > M) HIPCHK(hipMemsetAsync(h->dG + (size_t)M * (size_t)h->ld8, 0, (size_t)(h->Mpad - M) * (size_t)h->ld8, h->st));

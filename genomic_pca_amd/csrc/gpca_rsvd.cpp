@@ -138,9 +138,7 @@ static inline bool narrow_shape(const gpca_handle* h) {
 }
 // the DMA kernels (k_gtt_d on int8 rows, k_gtt_p on 2-bit rows) take several consecutive tasks per workgroup: one batch of workgroups per launch
 static inline bool k2_batched(const gpca_handle* h) {
-    const bool packed = h->storage == GPCA_STORE_2BIT;
-    if (narrow_shape(h)) return false;
-    return packed ? ((h->lds_planes && h->gtt_dma) || h->nd == 3) : (h->lds_planes && h->gtt_dma);      // (the choices of k2_panel)
+    return !narrow_shape(h) && !h->simple_kernels;      // (the choices of k2_panel)
 }
 static inline Gtt8Plan k2_plan(const gpca_handle* h, int64_t rows_pad) {
     return narrow_shape(h) ? gtt8_plan_narrow(rows_pad, h->N, std::min(h->gtt_waves_target, 1024)) :   // (one wave per SIMD: k_gtt_i8 holds 1 workgroup per CU)
@@ -154,15 +152,16 @@ static int k2_panel(gpca_handle* h, const PanelView& pv, const int8_t* Td_half, 
     const int8_t* Td = Td_half + (size_t)(pv.row0 >> 5) * kPlaneBytesPerBlock;
     const bool packed = h->storage == GPCA_STORE_2BIT;
     if (narrow_shape(h)) launch_gtt_n(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan);
-    else if (h->lds_planes && h->gtt_dma && !packed) {
-        const int e = launch_gtt_d(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
-        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d launch failed (hip error " + std::to_string(e) + ")");
-    } else if (((h->lds_planes && h->gtt_dma) || h->nd == 3) && packed) {   // (three planes: only this kernel)
+    else if (h->simple_kernels) {        // the register-only reference kernels
+        if (packed) launch_gtt_2bit(h->st, pv.g2, h->ld2, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->nd);
+        else launch_gtt_i8(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+    } else if (packed) {
         const int e = launch_gtt_p(h->st, pv.g2, h->ld2, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->nd, h->ko);
         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_p launch failed (hip error " + std::to_string(e) + ")");
-    } else if (h->lds_planes) launch_gtt_x(h->st, packed ? (const void*)pv.g2 : (const void*)pv.g8, packed, packed ? h->ld2 : h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
-    else if (packed) launch_gtt_2bit(h->st, pv.g2, h->ld2, pv.rows_pad, h->ldg, Td, h->dYpart64, plan);
-    else launch_gtt_i8(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+    } else {
+        const int e = launch_gtt_d(h->st, pv.g8, h->ld8, pv.rows_pad, h->ldg, Td, h->dYpart64, plan, h->ko);
+        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gtt_d launch failed (hip error " + std::to_string(e) + ")");
+    }
     HIPCHK(hipGetLastError());
     return GPCA_OK;
 }
@@ -250,17 +249,13 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                         const int e = launch_gq_n(h->st, pv.g8, h->ld8, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L);
                         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_n launch failed (hip error " + std::to_string(e) + ")");
                     }
-                    else if (h->lds_planes && h->gq_dma) {
+                    else if (!h->simple_kernels) {
                         const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
                         if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
                     }
-                    else if (h->lds_planes) {
-                        const int e = launch_gq_x(h->st, pv.g8, h->ld8, plan, h->ldg, Qd, qsc, rr, bb, s32, Th, cp, ap, scale_out, L, h->ko);
-                        if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_x launch failed (hip error " + std::to_string(e) + ")");
-                    }
                     else launch_gq_i8(h->st, pv.g8, h->ld8, plan, h->N, Qd, qsc, rr, bb, s32, Th, cp, scale_out, L, h->ko);
                     HIPCHK(hipGetLastError());
-                    if (streamed && scale_out && (packed || h->lds_planes || narrow_shape(h))) {   // (streamed: the per-launch timer above is disabled) fold this panel's column abs-max before the next launch reuses ap
+                    if (streamed && scale_out && (packed || !h->simple_kernels || narrow_shape(h))) {   // (streamed: the per-launch timer above is disabled) fold this panel's column abs-max before the next launch reuses ap
                         launch_absmax_fold(h->st, ap, plan.waves, h->d_amax_run + 32 * hf);
                         HIPCHK(hipGetLastError());
                     }
@@ -273,7 +268,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                 launch_sum_partials_f32(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, 32, h->d_c + 32 * hf, h->d_scratch64);
                 HIPCHK(hipGetLastError());
             }
-        h->apart_valid = scale_out != 0 && (packed || h->lds_planes || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
+        h->apart_valid = scale_out != 0 && (packed || !h->simple_kernels || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
         for (int hf = 0; hf < 2; ++hf) h->apart_src[hf] = streamed ? h->d_amax_run + 32 * hf : h->d_apart + hf * ahalf;
         h->apart_parts = streamed ? 1 : h->gqplan.waves;
         return GPCA_OK;
@@ -319,12 +314,9 @@ static int stage_power_fused(gpca_handle* h) {
                     const int e = launch_gq_n(h->st, pv.g8, h->ld8, plan1, h->N, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L);
                     if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_n launch failed (hip error " + std::to_string(e) + ")");
                 }
-                else if (h->gq_dma) {
+                else {
                     const int e = launch_gq_d(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
                     if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_d launch failed (hip error " + std::to_string(e) + ")");
-                } else {
-                    const int e = launch_gq_x(h->st, pv.g8, h->ld8, plan1, h->ldg, Qd, h->d_qscale + 32 * hf, rr, bb, h->d_s32 + 32 * hf, Th, cp, ap, 1, L, h->ko);
-                    if (e != 0) return fail(h, GPCA_ERR_HIP, "k_gq_x launch failed (hip error " + std::to_string(e) + ")");
                 }
                 HIPCHK(hipGetLastError());
                 // this panel's rows of T' -> digit planes against this panel's column maxima
@@ -485,7 +477,7 @@ static int ensure_child(gpca_handle* h) {
     c->is_child = true; c->compact_ok = 0;
     c->device = h->device; c->precision = h->precision; c->storage = h->storage; c->nd = h->nd; c->ko = h->ko;
     c->st = h->st;                                                                      // same stream: ordered with the parent's work
-    c->gtt_dma = h->gtt_dma; c->gq_dma = h->gq_dma; c->lds_planes = h->lds_planes; c->narrow_ok = h->narrow_ok; c->spin_sync = h->spin_sync;
+    c->simple_kernels = h->simple_kernels; c->narrow_ok = h->narrow_ok; c->spin_sync = h->spin_sync;
     c->gq_waves_target = h->gq_waves_target; c->gtt_waves_target = h->gtt_waves_target;
     c->timing_on = h->timing_on;
     c->M = n; c->N = h->N; c->Mpad = npad; c->ldg = h->ldg; c->ld8 = h->ld8; c->ld2 = h->ld2; c->cap_rows_pad = npad; c->pack_flags = h->pack_flags;
@@ -585,7 +577,7 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     EXCHANGE(h->dY, h->N * (int64_t)L);
     LOCAL(stage_orth(h, power_iters == 0 ? 2 : 1));   // (the last basis before the projection gets CholeskyQR2, the earlier ones one round)
     // 2. power iterations
-    const bool fused = h->sm.on && h->sm.fused && (h->storage == GPCA_STORE_2BIT || h->lds_planes || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
+    const bool fused = h->sm.on && h->sm.fused && (h->storage == GPCA_STORE_2BIT || !h->simple_kernels || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
     for (int it = 0; it < power_iters; ++it) {
         if (fused) LOCAL(stage_power_fused(h));
         else { LOCAL(stage_AQ(h, 1)); LOCAL(stage_AtT_local(h)); }

@@ -14,13 +14,10 @@ struct QcParams { double min_call_rate, min_maf, max_hwe_p; };
 
 // Kernel-selection switches of one handle (read from the environment at gpca_create; defaults = the measured best).
 struct KernelOpts {
-    int stream_nt = 0;   // GPCA_STREAM_NT  : nt loads in the per-wave-plane kernels k_gq_i8 / k_gtt_i8
-    int dma_nt = 1;      // GPCA_GQ_DMA_NT  : nt on the LDS-DMA genotype streams (k_gq_d, k_gtt_d)
-    int gq_r = 4;        // GPCA_GQ_R       : max tiles per wave in k_gq_x
-    int gq_phase = -1;   // GPCA_GQ_PHASE   : workgroup b of k_gq_d starts its sweep of the sample axis at stage ((b % 8) A + (b / 8) B) mod stages, A = low 16 bits, B = high 16 bits; -1 = the launcher's choice (8 starting points per XCD up to 51k samples)
-    int gq_chain = 1;    // GPCA_GQ_CHAIN   : k_gq_d prefetches a wave's next round behind the current round's epilogue (0: drain + prologue per round)
-    int gtt_xcd = 1;     // GPCA_GTT_XCD    : XCD-aware n-group order in k_gtt_d / k_gtt_p
-    int gttx_xcd = 0;    // GPCA_GTTX_XCD   : the same in the register-staged k_gtt_x (measured: no gain there)
+    int gq_phase = -1;   // workgroup b of k_gq_d starts its sweep of the sample axis at stage ((b % 8) A + (b / 8) B) mod stages, A = low 16 bits,
+                         // B = high 16 bits; -1 = the launcher's choice (8 starting points per XCD up to 51k samples).  Harness knob.
+    int gq_chain = 1;    // k_gq_d prefetches a wave's next round behind the current round's epilogue (0: drain + prologue per round).  Harness knob.
+    int gtt_xcd = 1;     // XCD-aware workgroup order in k_gtt_d / k_gtt_p.  Harness knob.
 };
 // Opt-in to > 64 KiB of dynamic LDS for every kernel that needs it, on the CURRENT device (the attribute is per device).
 // Return a hipError_t value (0 = ok).
@@ -216,14 +213,7 @@ int launch_gtt_d(hipStream_t st, const int8_t* G, int64_t ldg, int64_t Mpad, int
 int launch_gq_d(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
                 int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
-// K1 with the digit planes of Q shared through LDS (int8-resident genotypes)
-int launch_gq_x(hipStream_t st, const int8_t* G, int64_t ldg, const GqPlan& plan, int64_t Npad, const int8_t* Qd,
-                 const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart, double* apart,
-                 int scale_out, int64_t ldt = 32, const KernelOpts& ko = KernelOpts());
-// K2 with the digit planes shared through LDS (packed = 0: int8 rows of pitch ldr, 1: 2-bit rows of pitch ldr)
-void launch_gtt_x(hipStream_t st, const void* Gb, int packed, int64_t ldr, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                  double* Ypart, const Gtt8Plan& plan, const KernelOpts& ko = KernelOpts());
 void launch_gtt_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td,
-                     double* Ypart, const Gtt8Plan& plan);
+                     double* Ypart, const Gtt8Plan& plan, int nd = 4);
 
 }  // namespace gpca

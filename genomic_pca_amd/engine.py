@@ -127,6 +127,14 @@ class PanelSource:
         return PanelSource(_lib.PANEL_SYNTH16, thresh=thresh16, seed=seed, snp_offset=snp_offset)
 
 
+# Defaults added to every GpcaEngine's gpca_config.reserved (flags OR-ed in, wave targets used when the caller passes 0).  The library
+# itself reads no environment variable for its kernel choice; a harness that wants every engine of a run on, say, the reference
+# kernels sets these (the parity tests do, through monkeypatch.setattr).
+DEFAULT_FLAGS = 0
+DEFAULT_GQ_WAVES = 0
+DEFAULT_GTT_WAVES = 0
+
+
 class GpcaEngine:
     """One opaque ``gpca_handle``: one GPU, one SNP-row shard of the genotype matrix.
 
@@ -134,11 +142,13 @@ class GpcaEngine:
     bench.py's headline times; ``PREC_F32_MFMA`` selects the f32 matrix-core path, ``STORE_2BIT`` packed residency."""
 
     def __init__(self, device: int = -1, precision: int = _lib.PREC_I8_EXACT, storage: int = _lib.STORE_INT8,
-                 digit_planes: int = 0):
+                 digit_planes: int = 0, flags: int = 0, gq_waves: int = 0, gtt_waves: int = 0):
+        """flags: _lib.CFG_* bits of gpca_config.reserved[0]; gq_waves / gtt_waves: grid targets of the two GEMMs (0 = tuned defaults)."""
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self._device, self.precision, self.storage, self.digit_planes = device, precision, storage, digit_planes
         cfg = _lib.gpca_config(device=device, precision=precision, storage=storage, digit_planes=digit_planes)
+        cfg.reserved[0], cfg.reserved[1], cfg.reserved[2] = flags | DEFAULT_FLAGS, gq_waves or DEFAULT_GQ_WAVES, gtt_waves or DEFAULT_GTT_WAVES
         rc = self._lib.gpca_create(C.byref(cfg), C.byref(self._h))
         if rc != _lib.GPCA_OK:
             raise GpcaError(rc, self._lib.gpca_last_error(None).decode())

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPCA_VERSION 230 /* 0.2.3: + mapped host sources (zero-staging), staging ring filled by a worker thread, gpca_stream_get_info */
+#define GPCA_VERSION 240 /* 0.2.4: kernel choice through gpca_config.reserved (no environment switches), sketches wider than 64 columns */
 #define GPCA_MISSING_I8 (-127) /* bed_reader i8 missing code, prepare.rs:1224 */
 
 typedef struct gpca_handle gpca_handle;
@@ -88,8 +88,18 @@ typedef struct gpca_config {
                              less matrix-core work; implemented for GPCA_STORE_2BIT, whose kernels are matrix-core bound.
                              0 = the library's choice: 4 on int8 rows (HBM-bound), 3 on 2-bit rows (measured max|dPC| <= 3e-7 against
                              the f64 checker on every parity shape, tighter than GPCA_PREC_F32_MFMA). */
-    int32_t reserved[4];
+    int32_t reserved[4];  /* [0] = GPCA_CFG_* flags below (0 = the defaults); [1], [2] = resident-wave targets of the two GEMM grids (0 = the
+                             values tuned on MI355X: 1 024 / 2 048; smaller values give small grids -- how the tests reach every round and
+                             task pattern on small matrices); [3] must be 0.  Which kernels run is decided here, by the caller: the library
+                             reads no environment variable for it. */
 } gpca_config;
+/* gpca_config.reserved[0] */
+#define GPCA_CFG_SIMPLE_KERNELS 1 /* GPCA_PREC_I8_EXACT: the register-only reference kernels (no LDS staging, no DMA, compiler-counted waits)
+                                     instead of the LDS-DMA ones: same integers, same pinned roundings -- the same bits, more slowly */
+#define GPCA_CFG_NO_COMPACT 2     /* never gather the kept rows into a matrix of their own when QC drops most of them */
+#define GPCA_CFG_NO_NARROW 4      /* matrices of <= 256 samples on the wide kernels (rows padded to 256 samples) */
+#define GPCA_CFG_NO_SPIN_SYNC 8   /* wait for the device with hipStreamSynchronize instead of a busy-polled stream (one host core less, ~0.1 ms per call more) */
+#define GPCA_CFG_ALL 15
 
 /* SNP QC thresholds = MicroarrayDataPreparerConfig, main.rs:302-309 / prepare.rs:1281-1311,1363.
  * Effective reference defaults (clap, main.rs:545-560): 0.98 / 0.01 / 1e-6.

@@ -68,3 +68,22 @@ def engine(gpca):
     e = gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA, storage=_lib.STORE_INT8)
     yield e
     e.close()
+
+
+def engine_defaults(mp, **kw):
+    """Kernel-choice defaults for every GpcaEngine created while the monkeypatch (context) `mp` is active: simple=1 (register-only
+    reference kernels), compact=0, narrow=0, gq_waves=..., gtt_waves=... -> genomic_pca_amd.engine.DEFAULT_* (gpca_config.reserved)."""
+    import genomic_pca_amd.engine as E
+    from genomic_pca_amd import _lib
+    flags = 0
+    if kw.get("simple"):
+        flags |= _lib.CFG_SIMPLE_KERNELS
+    if kw.get("compact", 1) == 0:
+        flags |= _lib.CFG_NO_COMPACT
+    if kw.get("narrow", 1) == 0:
+        flags |= _lib.CFG_NO_NARROW
+    if kw.get("spin_sync", 1) == 0:
+        flags |= _lib.CFG_NO_SPIN_SYNC
+    mp.setattr(E, "DEFAULT_FLAGS", flags)
+    mp.setattr(E, "DEFAULT_GQ_WAVES", int(kw.get("gq_waves", 0)))
+    mp.setattr(E, "DEFAULT_GTT_WAVES", int(kw.get("gtt_waves", 0)))

@@ -31,7 +31,7 @@ def test_no_undeclared_exports(gpca):
 
 def test_version_and_strings(gpca):
     lib = gpca.load()
-    assert lib.gpca_version() == 230
+    assert lib.gpca_version() == 240
     assert lib.gpca_status_string(0) == b"ok"
     assert b"missing genotype" in lib.gpca_status_string(-5)
 
@@ -123,7 +123,7 @@ def test_header_is_plain_c99_and_links(tmp_path, gpca):
         pytest.skip("GPU present: covered by test_c_client_full_path")
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "no CPU fallback" in out.stdout and "libgpca version 230" in out.stdout
+    assert "no CPU fallback" in out.stdout and "libgpca version 240" in out.stdout
 
 
 @pytest.mark.gpu

@@ -5,6 +5,8 @@ restatement with the same seed."""
 import numpy as np
 import pytest
 
+from conftest import engine_defaults
+
 pytestmark = pytest.mark.gpu
 
 TOL_PC = 1e-4   # BASELINE.json: max|dPC| vs ref, unit-norm sign-aligned
@@ -623,7 +625,7 @@ def test_i8_matches_f32_and_is_partition_independent(gpca, oracle, engine, engin
     # the integer GEMM partial sums are exact and the centring term c = b^T T is summed per 32-row unit in a fixed order, so a
     # different grid partition returns the same bits
     from genomic_pca_amd import _lib
-    monkeypatch.setenv("GPCA_GQ_WAVES", "64"); monkeypatch.setenv("GPCA_GTT_WAVES", "96")
+    engine_defaults(monkeypatch, gq_waves=64, gtt_waves=96)
     with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e2:
         e2.upload_genotypes_i8(G); e2.snp_stats(); e2.rsvd(6, 10, 2, seed=3)
         assert np.array_equal(e2.eigenvalues(), out["i8"][0])
@@ -864,7 +866,7 @@ def test_random_shapes_against_the_oracle(gpca, oracle, monkeypatch, case):
     idx, M, N, k, ov, q, prec, store, miss, seed = case
     ov = min(ov, min(M, N) - k - 1)
     if idx % 3 == 0:      # a grid of 2 workgroups: the full LDS-DMA rounds (>= 9 units of 32 rows per workgroup) run on these small matrices too
-        monkeypatch.setenv("GPCA_GQ_WAVES", "8"); monkeypatch.setenv("GPCA_GTT_WAVES", "64")
+        engine_defaults(monkeypatch, gq_waves=8, gtt_waves=64)
     th = gpca.synth_thresholds(M, k + 3, seed=seed, fst=0.35)
     G = oracle.synth_genotypes(M, N, seed, th)
     if miss:
@@ -892,17 +894,12 @@ def test_random_shapes_against_the_oracle(gpca, oracle, monkeypatch, case):
         assert oracle.max_abs_dpc(ld[:, sep], R["loadings"][ref["keep"].astype(bool)][:, sep]) < 1e-4
 
 
-@pytest.mark.parametrize("env", [{"GPCA_GQ_DMA": "0"}, {"GPCA_GTT_DMA": "0"}, {"GPCA_GQ_DMA": "0", "GPCA_GTT_DMA": "0"},
-                                 {"GPCA_LDS_PLANES": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GTT_WAVES": "64"},
-                                 {"GPCA_GQ_CHAIN": "0", "GPCA_GQ_WAVES": "8"}, {"GPCA_GTT_XCD": "0"}, {"GPCA_GQ_DMA_NT": "0"},
-                                 {"GPCA_GQ_DMA": "0", "GPCA_GQ_R": "2"}, {"GPCA_LDS_PLANES": "0", "GPCA_STREAM_NT": "1"},
-                                 {"GPCA_GTT_DMA": "0", "GPCA_GTTX_XCD": "1"},
-                                 {"GPCA_GQ_WAVES": "12", "GPCA_GQ_CHAIN": "0"}, {"GPCA_GQ_WAVES": "8", "GPCA_GQ_DMA_NT": "0"},
-                                 {"GPCA_GQ_CHAIN": "0"}, {"GPCA_GQ_WAVES": "4"}])
+@pytest.mark.parametrize("env", [dict(simple=1), dict(simple=1, gq_waves=8, gtt_waves=64), dict(gq_waves=8, gtt_waves=64), dict(gq_waves=8),
+                                 dict(gq_waves=12, gtt_waves=24), dict(gq_waves=4), dict(gtt_waves=8), dict(gtt_waves=2048 + 8), dict(spin_sync=0)])
 def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
-    """Register-staged (k_gq_x / k_gtt_x) and per-wave-plane (k_gq_i8 / k_gtt_i8) kernels, and a tiny grid that forces
-    full LDS-DMA rounds on a small matrix, against the default configuration: the integer products are exact, so only
-    the f32 partials of the centring term may move (<= 1e-8), and the oracle parity bar holds."""
+    """The register-only reference kernels (k_gq_i8 / k_gtt_i8: gpca_config.reserved[0] & GPCA_CFG_SIMPLE_KERNELS) and small grids that
+    force full LDS-DMA rounds, chained rounds and multi-task workgroups on a small matrix, against the default configuration: the
+    integer products are exact and every f32 rounding is pinned, so the results are the SAME BITS, and the oracle parity bar holds."""
     from genomic_pca_amd import _lib
     M, N, k = 20000, 1000, 10
     th = gpca.synth_thresholds(M, 16, seed=1, fst=0.2)
@@ -910,14 +907,12 @@ def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     res = {}
     for name, e_env in (("default", {}), ("alt", env)):
         with monkeypatch.context() as mp:
-            for key, val in e_env.items():
-                mp.setenv(key, val)
+            engine_defaults(mp, **e_env)
             with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
                 e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 10, 2, seed=1)
                 res[name] = (e.eigenvalues(), e.scores(f64=True), e.loadings().astype(np.float64))
-    assert np.max(np.abs(res["alt"][0] - res["default"][0]) / res["default"][0]) < 1e-8
-    assert oracle.max_abs_dpc(res["alt"][1], res["default"][1]) < 1e-8
-    assert oracle.max_abs_dpc(res["alt"][2], res["default"][2]) < 1e-6
+    for a, b in zip(res["alt"], res["default"]):
+        assert np.array_equal(a, b)
     st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
     r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
     R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=1)
@@ -930,7 +925,7 @@ def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, 
     """k_gq_d's rounds of fewer than four tiles per wave (R = 3, 2, 1 and waves that only ride along): grids of 1, 2 and 3 workgroups
     over 16 ... 116 row units leave every remainder class behind the full rounds -- (3,3,2,2), (2,2,1,1), (1,1,1,1), (2,1,1,1),
     (1,1,0,0) ... --, on 2 stages (the ring's prologue wraps around the sample axis) and on 8.  The register-staged kernel
-    (GPCA_GQ_DMA=0) computes the same integers with the same pinned f32 roundings: every result must be the same bits, and the
+    (GPCA_CFG_SIMPLE_KERNELS) computes the same integers with the same pinned f32 roundings: every result must be the same bits, and the
     oracle bar holds."""
     from genomic_pca_amd import _lib
     k = 5
@@ -939,16 +934,14 @@ def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, 
     res = {}
     # (N = 1000 and 1300 are 8 and 12 stages: the rounds of a workgroup are CHAINED there -- the next round's first units and planes
     #  are fetched behind the current round's epilogue, whatever the two rounds' tile counts; 2 stages keep the drained form)
-    for name, env in (("staged", {"GPCA_GQ_DMA": "0"}), ("w4", {"GPCA_GQ_WAVES": "4"}), ("w8", {"GPCA_GQ_WAVES": "8"}), ("w12", {"GPCA_GQ_WAVES": "12"}),
-                      ("w4_unchained", {"GPCA_GQ_WAVES": "4", "GPCA_GQ_CHAIN": "0"}), ("w8_lockstep", {"GPCA_GQ_WAVES": "8", "GPCA_GQ_PHASE": "0"}),
-                      ("w12_phases", {"GPCA_GQ_WAVES": "12", "GPCA_GQ_PHASE": str(3 + (5 << 16))}), ("default", {})):
+    for name, env in (("staged", dict(simple=1)), ("w4", dict(gq_waves=4)), ("w8", dict(gq_waves=8)), ("w12", dict(gq_waves=12)),
+                      ("w4_k2w8", dict(gq_waves=4, gtt_waves=8)), ("w16", dict(gq_waves=16, gtt_waves=32)), ("default", {})):
         with monkeypatch.context() as mp:
-            for key, val in env.items():
-                mp.setenv(key, val)
+            engine_defaults(mp, **env)
             with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
                 e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 5, 2, seed=3)
                 res[name] = (e.eigenvalues().copy(), e.scores(f64=True).copy(), e.loadings().copy())
-    for name in ("w4", "w8", "w12", "w4_unchained", "w8_lockstep", "w12_phases", "default"):
+    for name in ("w4", "w8", "w12", "w4_k2w8", "w16", "default"):
         for a, b in zip(res[name], res["staged"]):
             assert np.array_equal(a, b), name
     st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
@@ -963,15 +956,14 @@ def test_narrow_kernels_same_bits_as_the_wide_ones(gpca, oracle, monkeypatch, M,
     """At most 256 samples on int8 rows (BASELINE.json configs[2]'s shape class: 1 066 557 x 64): k_gq_n keeps all of Q's digit
     planes in registers and streams only the lines that hold samples, the narrow k_gtt_i8 gives every wave a row chunk of its
     own.  Same integers, same pinned f32 roundings, same per-unit c partials: the results are the wide kernels' bits
-    (GPCA_NARROW=0 runs those on the padded rows) -- resident, streamed 6-pass and fused -- and hold the oracle's parity bar."""
+    (GPCA_CFG_NO_NARROW runs those on the padded rows) -- resident, streamed 6-pass and fused -- and hold the oracle's parity bar."""
     from genomic_pca_amd import _lib
     th = gpca.synth_thresholds(M, 5, seed=2, fst=0.25)
     l = min(k + 10, N)
     res = {}
-    for name, env in (("narrow", {}), ("wide", {"GPCA_NARROW": "0"})):
+    for name, env in (("narrow", {}), ("wide", dict(narrow=0))):
         with monkeypatch.context() as mp:
-            for key, val in env.items():
-                mp.setenv(key, val)
+            engine_defaults(mp, **env)
             with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e:
                 e.synth_genotypes(M, N, 2, th)
                 st = e.snp_stats(gpca.QcConfig.none())
@@ -999,7 +991,7 @@ def test_narrow_kernels_same_bits_as_the_wide_ones(gpca, oracle, monkeypatch, M,
 def test_compact_child_when_qc_drops_most_rows(gpca, oracle, monkeypatch, prec, store):
     """QC that drops most SNP rows (configs[2] keeps 203 512 of 1 066 557): gpca_rsvd gathers the kept rows into a matrix of their
     own and runs there -- the passes, the sketch and the quantisations cost n_pca rows instead of M.  Omega is drawn by the rows'
-    ORIGINAL index, so the sketch is the one of the uncompacted run (GPCA_COMPACT=0): same answers (only the grouping of the
+    ORIGINAL index, so the sketch is the one of the uncompacted run (GPCA_CFG_NO_COMPACT): same answers (only the grouping of the
     f32 partial sums of c moves), the oracle's parity bar, loadings in PCA-SNP order, PCA::transform, the pull API still served
     by the parent, and a changed keep mask rebuilds the child."""
     from genomic_pca_amd import _lib
@@ -1010,10 +1002,9 @@ def test_compact_child_when_qc_drops_most_rows(gpca, oracle, monkeypatch, prec, 
     keep = (rng.random(M) < 0.2).astype(np.uint8)            # 20 % of the rows stay
     kw = dict(precision=_lib.PREC_I8_EXACT if prec == "i8" else _lib.PREC_F32_MFMA, storage=_lib.STORE_2BIT if store == "2bit" else _lib.STORE_INT8)
     res = {}
-    for name, env in (("compact", {}), ("plain", {"GPCA_COMPACT": "0"})):
+    for name, env in (("compact", {}), ("plain", dict(compact=0))):
         with monkeypatch.context() as mp:
-            for key, val in env.items():
-                mp.setenv(key, val)
+            engine_defaults(mp, **env)
             with gpca.GpcaEngine(**kw) as e:
                 e.upload_genotypes_i8(G)
                 st = e.snp_stats(gpca.QcConfig.none())

@@ -11,6 +11,8 @@ import threading
 import numpy as np
 import pytest
 
+from conftest import engine_defaults
+
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -22,8 +24,8 @@ def _resident_reference_uncompacted(monkeypatch):
     """The resident engines of this module are the references of bit-for-bit comparisons with streamed and sharded runs.  A resident
     matrix whose QC dropped more than half of the rows would run gpca_rsvd on the kept rows gathered into a matrix of their own
     (tests/test_gpu_parity.py::test_compact_child_when_qc_drops_most_rows), which regroups the f32 partial sums of c = b^T T -- 1e-9,
-    not the same bits; a streamed or sharded handle never compacts.  GPCA_COMPACT=0 keeps the references on the full matrix."""
-    monkeypatch.setenv("GPCA_COMPACT", "0")
+    not the same bits; a streamed or sharded handle never compacts.  GPCA_CFG_NO_COMPACT keeps the references on the full matrix."""
+    engine_defaults(monkeypatch, compact=0)
 
 
 def _modes(store):
