@@ -166,7 +166,7 @@ struct gpca_handle {
     // exact-integer path
     int8_t *dQd = nullptr, *dTd = nullptr;
     double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false; int64_t apart_parts = 0;   // column abs-max partials of T' from the K1 epilogue
-    const double* apart_src[2] = {nullptr, nullptr};   // where the partials of each 32-column half sit
+    const double* apart_src[4] = {nullptr, nullptr, nullptr, nullptr};   // where the partials of each 32-column block sit (kMaxSketch / 32 blocks)
     float* d_rmax = nullptr; bool rmax_valid = false;   // max_i r[i]: the sketch's digit scale is 6.67 * rmax (k_omega); recomputed when r changes
     double* d_amax_run = nullptr;    // [2][32] running column abs-max over the panels of a streamed K1 sweep
     double* d_yint = nullptr; size_t cap_yint = 0;   // [halves][N][32] integer partial sums of a streamed K2 sweep
@@ -275,6 +275,7 @@ inline void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 inline hipError_t malloc_genotypes(const gpca_handle*, void** p, size_t bytes) { return hipMalloc(p, bytes); }
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+constexpr int kMaxSketch = 128;   // most columns (k + oversample) a sketch may have: L = 32, 64 (specialised helpers) or 128 (wide_sketch.hip)
 
 // ---- timing ---------------------------------------------------------------------------------------
 void fold_timings(gpca_handle* h);   // resolve pending records into per-name totals and recycle their events

@@ -117,7 +117,7 @@ static void host_eigh_desc(std::vector<double>& A, std::vector<double>& V, std::
 }
 // test hook (host only, no GPU): eigen-decomposition of a symmetric n x n row-major matrix, eigenvalues descending
 extern "C" int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, double* v) {
-    if (!a_sym || !w || !v || n < 1 || n > 64) return GPCA_ERR_BAD_ARG;
+    if (!a_sym || !w || !v || n < 1 || n > kMaxSketch) return GPCA_ERR_BAD_ARG;
     std::vector<double> A(a_sym, a_sym + (size_t)n * n), V((size_t)n * n), W((size_t)n);
     host_eigh_desc(A, V, W, n);
     std::copy(W.begin(), W.end(), w); std::copy(V.begin(), V.end(), v);
@@ -229,7 +229,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
         const size_t qhalf = (size_t)h->ldg * 32 * kDigits;            // digit planes of one 32-column half of Q
         const size_t chalf = (size_t)h->Mpad;                           // per-unit partials of c of one half: [Mpad / 32][32]
         const size_t ahalf = (size_t)h->gqplan.waves * 32;              // per-wave abs-max partials of one launch
-        if (streamed && scale_out) HIPCHK(hipMemsetAsync(h->d_amax_run, 0, 64 * 8, h->st));
+        if (streamed && scale_out) HIPCHK(hipMemsetAsync(h->d_amax_run, 0, kMaxSketch * 8, h->st));
         {
             const double by = packed ? elems / 4 : elems;
             ScopedTimer sweep(h, "gemm_GQ", 2.0 * elems * h->l, by * halves, nullptr, streamed);
@@ -269,7 +269,7 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                 HIPCHK(hipGetLastError());
             }
         h->apart_valid = scale_out != 0 && (packed || !h->simple_kernels || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
-        for (int hf = 0; hf < 2; ++hf) h->apart_src[hf] = streamed ? h->d_amax_run + 32 * hf : h->d_apart + hf * ahalf;
+        for (int hf = 0; hf < kMaxSketch / 32; ++hf) h->apart_src[hf] = streamed ? h->d_amax_run + 32 * hf : h->d_apart + hf * ahalf;
         h->apart_parts = streamed ? 1 : h->gqplan.waves;
         return GPCA_OK;
     }
@@ -398,10 +398,11 @@ static int ensure_workspace(gpca_handle* h) {
     const int64_t p64 = std::max({gram_num_parts(N) * (int64_t)L * L, gram_num_parts(M) * (int64_t)L * L, colsum_num_parts(Npad) * (int64_t)L, absmax_num_parts(h->Mpad) * (int64_t)32, 2 * tail_num_parts(Npad) * (int64_t)L});
     CHK(ensure(h, h->d_part64, h->cap_part64, (size_t)p64));
     if (!h->d_c) {
-        HIPCHK(hipMalloc((void**)&h->d_c, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, 64 * 8));
-        HIPCHK(hipMalloc((void**)&h->d_s32, 64 * 4)); HIPCHK(hipMalloc((void**)&h->dW, (64 * 64 + 16) * 8));   // (+ the 16 status slots that ride the Gram's exchange)
-        HIPCHK(hipMalloc((void**)&h->dZ, 2 * 64 * 64 * 8));
-        HIPCHK(hipHostMalloc((void**)&h->h_pin, (3 * 64 * 64 + 16) * 8, hipHostMallocDefault)); HIPCHK(hipMalloc((void**)&h->d_sign, 64 * 4));
+        constexpr size_t LL = (size_t)kMaxSketch * kMaxSketch;
+        HIPCHK(hipMalloc((void**)&h->d_c, kMaxSketch * 8)); HIPCHK(hipMalloc((void**)&h->d_s64, kMaxSketch * 8));
+        HIPCHK(hipMalloc((void**)&h->d_s32, kMaxSketch * 4)); HIPCHK(hipMalloc((void**)&h->dW, (LL + 16) * 8));   // (+ the 16 status slots that ride the Gram's exchange)
+        HIPCHK(hipMalloc((void**)&h->dZ, 2 * LL * 8));
+        HIPCHK(hipHostMalloc((void**)&h->h_pin, (3 * LL + 16) * 8, hipHostMallocDefault)); HIPCHK(hipMalloc((void**)&h->d_sign, kMaxSketch * 4));
         HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
         HIPCHK(hipMalloc((void**)&h->d_cholflag, 4));
     }
@@ -416,9 +417,9 @@ static int ensure_workspace(gpca_handle* h) {
         CHK(ensure(h, h->d_apart, h->cap_apart, (size_t)h->gqplan.waves * 32 * (size_t)(L / 32)));
         if (h->sm.on) CHK(ensure(h, h->d_yint, h->cap_yint, (size_t)N * 32 * (size_t)(L / 32)));
         if (!h->d_qscale) {
-            HIPCHK(hipMalloc((void**)&h->d_qscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, 64 * 8));
-            HIPCHK(hipMalloc((void**)&h->d_tscale, 64 * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, 64 * 8));
-            HIPCHK(hipMalloc((void**)&h->d_amax_run, 64 * 8));
+            HIPCHK(hipMalloc((void**)&h->d_qscale, kMaxSketch * 8)); HIPCHK(hipMalloc((void**)&h->d_qinv, kMaxSketch * 8));
+            HIPCHK(hipMalloc((void**)&h->d_tscale, kMaxSketch * 8)); HIPCHK(hipMalloc((void**)&h->d_tinv, kMaxSketch * 8));
+            HIPCHK(hipMalloc((void**)&h->d_amax_run, kMaxSketch * 8));
             HIPCHK(hipMalloc((void**)&h->d_rmax, 4));
         }
     }
@@ -438,7 +439,9 @@ static int rsvd_preflight(gpca_handle* h, int32_t k, int32_t oversample, int32_t
     if (h->N < 2) return fail(h, GPCA_ERR_BAD_ARG, "PCA requires at least 2 samples.");   // main.rs:614-616
     if (!multi_rank(h) && h->n_pca == 0) return fail(h, GPCA_ERR_BAD_ARG, "PCA requires at least 1 variant (feature), found 0.");  // main.rs:617-619
     const int l = k + oversample;
-    if (l > 64) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: k + oversample must be <= 64");
+    if (l > kMaxSketch) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: k + oversample must be <= 128");
+    if (l > 64 && h->precision != GPCA_PREC_I8_EXACT)
+        return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: sketches wider than 64 columns (k + oversample > 64) run on GPCA_PREC_I8_EXACT; GPCA_PREC_F32_MFMA holds up to 64");
     if (l > h->N || (!multi_rank(h) && l > h->n_pca)) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: k + oversample exceeds min(samples, PCA SNPs)");
     if (h->flags & 1u) return fail(h, GPCA_ERR_MISSING_GENOTYPE,
         "Unexpected missing genotype (-127i8) in a PCA SNP. This should have been filtered by QC.");  // prepare.rs:1909-1911
@@ -448,7 +451,7 @@ static int rsvd_preflight(gpca_handle* h, int32_t k, int32_t oversample, int32_t
     if (h->precision == GPCA_PREC_I8_EXACT && h->N > ((int64_t)1 << 22))
         return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd: the exact-integer path holds up to 4 194 304 samples per matrix (i32 accumulators); use GPCA_PREC_F32_MFMA beyond");
     HIPCHK(hipSetDevice(h->device));
-    h->k = k; h->l = l; h->L = l <= 32 ? 32 : 64;
+    h->k = k; h->l = l; h->L = l <= 32 ? 32 : (l <= 64 ? 64 : kMaxSketch);
     h->have_rsvd = false;
     CHK(ensure_workspace(h));
     HIPCHK(hipMemsetAsync(h->d_cholflag, 0, 4, h->st));
@@ -607,8 +610,8 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     // (pageable copies and a sleeping hipStreamSynchronize cost ~220 us here); everything after it is enqueued at once.
     std::vector<double> C((size_t)l * l), V((size_t)l * l), w((size_t)l);
     double* Wfull = h->h_pin;
-    double* Zpin = h->h_pin + 64 * 64;                    // [scores Z (L x k) | loadings Z (L x k)]
-    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * 64 * 64);
+    double* Zpin = h->h_pin + (size_t)kMaxSketch * kMaxSketch;                    // [scores Z (L x k) | loadings Z (L x k)]
+    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * (size_t)kMaxSketch * kMaxSketch);
     bool status_here = false;     // the summed status slots have landed in h_status[16..32)
     auto fetch_w = [&]() -> int {
         HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
@@ -749,7 +752,7 @@ extern "C" int gpca_transform(gpca_handle* h, double* out) {
     // only the k columns asked for leave the device (the whole N x L block was 256 MB at N = 500k, L = 64): compacted on the device
     // by a right-multiplication with the L x k selection matrix, then one contiguous copy into the caller's buffer
     CHK(ensure(h, h->d_tr64, h->cap_tr64, (size_t)h->N * k));
-    double* Zsel = h->h_pin + 64 * 64;
+    double* Zsel = h->h_pin + (size_t)kMaxSketch * kMaxSketch;
     for (int j = 0; j < L; ++j) for (int c = 0; c < k; ++c) Zsel[(size_t)j * k + c] = j == c ? 1.0 : 0.0;
     HIPCHK(hipMemcpyAsync(h->dZ, Zsel, sizeof(double) * (size_t)L * k, hipMemcpyHostToDevice, h->st));
     launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_tr64, (float*)nullptr);
@@ -842,7 +845,7 @@ static int prep_custom_T(gpca_handle* h) {
 static int small_eigen(gpca_handle* h, int l, std::vector<double>& V, std::vector<double>& w) {
     const int L = h->L;
     double* Wfull = h->h_pin;
-    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * 64 * 64);
+    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * (size_t)kMaxSketch * kMaxSketch);
     HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
     HIPCHK(hipMemcpyAsync(flagpin, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
     HIPCHK(stream_wait(h));
@@ -863,6 +866,7 @@ extern "C" int gpca_rsvd_condensed(gpca_handle* h, int32_t k, int32_t oversample
     if (!h->d_cw) return fail(h, GPCA_ERR_STATE, "gpca_rsvd_condensed: call gpca_set_condensed_basis first");
     if (h->sm.on || multi_rank(h)) return fail(h, GPCA_ERR_STATE, "gpca_rsvd_condensed: needs a resident, unsharded matrix");
     if ((int64_t)k + oversample > h->c_R) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd_condensed: k + oversample exceeds the number of condensed features");
+    if ((int64_t)k + oversample > 64) return fail(h, GPCA_ERR_BAD_ARG, "gpca_rsvd_condensed: k + oversample must be <= 64 (the EigenSNP stages hold 64 sketch columns)");
     CHK(rsvd_preflight(h, k, oversample, power_iters));
     const int l = h->l, L = h->L, cmax = h->c_cmax;
     const int64_t R = h->c_R, Rpad = round_up(R, 128);
@@ -902,7 +906,7 @@ extern "C" int gpca_rsvd_condensed(gpca_handle* h, int32_t k, int32_t oversample
     h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
     for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
     for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
-    double* Zpin = h->h_pin + 64 * 64;
+    double* Zpin = h->h_pin + (size_t)kMaxSketch * kMaxSketch;
     const size_t zk = (size_t)L * k;
     for (size_t e = 0; e < zk; ++e) Zpin[e] = 0.0;
     for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Zpin[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
@@ -927,6 +931,7 @@ extern "C" int gpca_refine(gpca_handle* h, const double* S0, int32_t k) {
     if (multi_rank(h)) return fail(h, GPCA_ERR_STATE, "gpca_refine: not available on row-sharded handles");
     const uint8_t* saved_mask = h->d_smask;
     if (saved_mask) return fail(h, GPCA_ERR_STATE, "gpca_refine: clear the sample mask first (refinement uses every sample)");
+    if (k > 64) return fail(h, GPCA_ERR_BAD_ARG, "gpca_refine: k must be <= 64 (the EigenSNP stages hold 64 sketch columns)");
     CHK(rsvd_preflight(h, k, 0, 0));
     const int l = h->l, L = h->L;
     CHK(ensure(h, h->d_lqr, h->cap_lqr, (size_t)h->Mpad * L));
@@ -961,7 +966,7 @@ extern "C" int gpca_refine(gpca_handle* h, const double* S0, int32_t k) {
     h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
     for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
     for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
-    double* Zpin = h->h_pin + 64 * 64;
+    double* Zpin = h->h_pin + (size_t)kMaxSketch * kMaxSketch;
     const size_t zk = (size_t)L * k;
     for (size_t e = 0; e < 2 * zk; ++e) Zpin[e] = 0.0;
     for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Zpin[(size_t)j * k + c] = Zpin[zk + (size_t)j * k + c] = V[(size_t)j * l + c];

@@ -356,11 +356,18 @@ void launch_standardize_block(hipStream_t st, const int8_t* G, int64_t ld, const
 // One wave = 64 rows; writes Tp = r o Omega and the wave's partial of c = b^T Omega.
 // ------------------------------------------------------------------------------------------------
 int64_t omega_num_parts(int64_t Mpad) { return (Mpad + 63) / 64; }
+// sketches wider than 64 columns: the plain any-L kernels of wide_sketch.hip
+void launch_gram_any_f64(hipStream_t st, const double* X, int64_t rows, int64_t rpb, int64_t parts, int L, double* part);
+void launch_gram_any_f32(hipStream_t st, const float* X, int64_t rows, int64_t rpb, int64_t parts, int L, double* part);
+void launch_chol_inv_any(hipStream_t st, const double* W, int n, int L, double* Z, double* work, int* flag);
+void launch_apply_right_any(hipStream_t st, double* X, int64_t rows, int64_t parts, int L, const double* Z, double* csum_part, double* amax_part);
+void launch_rightmul_any_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64, float* out32);
+void launch_rightmul_any_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L, const double* Z, int K, float* out32);
 
 // LP = LDS pitch of the staged tile: L + 1 (33 for a 32-column sketch -- half the LDS of the 64-column form, so four waves per SIMD
 // stay resident beside the f64 log / sincospi chains instead of two; 90 VGPRs would allow five).
-template <int LP>
-__global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
+template <int LP, int NW = 2>
+__global__ __launch_bounds__(64 * NW) void k_omega(int64_t M, int64_t Mpad, int l, int L, int64_t snp_offset, uint64_t seed,
                                                const float* __restrict__ r, const float* __restrict__ b,
                                                float* __restrict__ Tb, float* __restrict__ cpart, double* __restrict__ apart,
                                                int blocked, int8_t* __restrict__ Td, const float* __restrict__ rmax,
@@ -370,10 +377,10 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
     //   * T' = r o Omega leaves as full rows, lane-contiguous (a lane writing its row 4 bytes at a time at a 128-byte
     //     stride cost 4.3x write amplification), and
     //   * the wave's partial of c = b^T Omega is a conflict-free column walk instead of 6 cross-lane steps per column.
-    __shared__ float zt[2][64][LP];
-    __shared__ float rs[2][64], bs[2][64];
+    __shared__ float zt[NW][64][LP];
+    __shared__ float rs[NW][64], bs[NW][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * 2 + wv;
+    const int64_t wave = (int64_t)blockIdx.x * NW + wv;
     const int64_t i0 = wave * 64, i = i0 + lane;
     const bool live = i < M;
     rs[wv][lane] = live ? r[i] : 0.f;
@@ -417,10 +424,11 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
         const double bound = 6.67 * (double)rmax[0];
         const double S = nd == 3 ? kDigitScale3 : kDigitScale;
         const double inv = bound > 0.0 ? S / bound : 0.0;
-        if (blockIdx.x == 0 && (int)threadIdx.x < L) {
-            tscale[threadIdx.x] = ((int)threadIdx.x < l && bound > 0.0) ? bound / S : 0.0;
-            tinv[threadIdx.x] = ((int)threadIdx.x < l) ? inv : 0.0;
-        }
+        if (blockIdx.x == 0)
+            for (int cj = threadIdx.x; cj < L; cj += 64 * NW) {
+                tscale[cj] = (cj < l && bound > 0.0) ? bound / S : 0.0;
+                tinv[cj] = (cj < l) ? inv : 0.0;
+            }
         const int cc = lane & 31, hh = lane >> 5;
         for (int hf = 0; hf < LT; ++hf)
             for (int b2 = 0; b2 < 2; ++b2) {
@@ -480,9 +488,11 @@ __global__ __launch_bounds__(128) void k_omega(int64_t M, int64_t Mpad, int l, i
                 }
             }
         } else {
-            float cv = 0.f;
-            for (int row = 0; row < 64; ++row) cv += bs[wv][row] * zt[wv][row][lane];
-            cpart[wave * L + lane] = cv;
+            for (int col = lane; col < L; col += 64) {
+                float cv = 0.f;
+                for (int row = 0; row < 64; ++row) cv += bs[wv][row] * zt[wv][row][col];
+                cpart[wave * L + col] = cv;
+            }
         }
     }
 }
@@ -493,7 +503,7 @@ void launch_omega(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, int64_t
     if (L == 32) hipLaunchKernelGGL(k_omega<33>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
                                     cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4, row_ids);
     else hipLaunchKernelGGL(k_omega<65>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, Tb,
-                            cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4, row_ids);
+                            cpart, apart, blocked, (int8_t*)nullptr, (const float*)nullptr, (double*)nullptr, (double*)nullptr, 4, row_ids);      // (f32 path: L <= 64)
 }
 // Exact-integer path: T' = r o Omega straight into digit planes Td ([L/32 halves][Mpad/32][kDigits][64][16 B]) against the analytic
 // column bound 6.67 * rmax; tscale / tinv [L] receive the scale (columns >= l: 0); cpart as above.  No f32 copy of T'.
@@ -503,8 +513,10 @@ void launch_omega_planes(hipStream_t st, int64_t M, int64_t Mpad, int l, int L, 
     const int64_t waves = omega_num_parts(Mpad);
     if (L == 32) hipLaunchKernelGGL(k_omega<33>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
                                     cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);
-    else hipLaunchKernelGGL(k_omega<65>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
-                            cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);
+    else if (L == 64) hipLaunchKernelGGL(k_omega<65>, dim3((unsigned)((waves + 1) / 2)), dim3(128), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
+                                         cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);
+    else hipLaunchKernelGGL((k_omega<129, 1>), dim3((unsigned)waves), dim3(64), 0, st, M, Mpad, l, L, snp_offset, seed, r, b, (float*)nullptr,
+                            cpart, (double*)nullptr, 0, Td, rmax, tscale, tinv, nd, row_ids);        // L = 128 (one wave per workgroup: 33 KB of LDS for its tile)
 }
 // dst row i <- src row ids[i] (rows of `pitch` bytes, a multiple of 16): the kept SNPs of a matrix gathered into one of their own
 __global__ __launch_bounds__(256) void k_gather_rows(const uint8_t* __restrict__ src, int64_t pitch, const int64_t* __restrict__ ids,
@@ -685,7 +697,8 @@ void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, doubl
     const int64_t rpb = gram_rows_per_block(rows);
     const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
     if (L == 32) hipLaunchKernelGGL((k_gram<double, 32>), grid, blk, 0, st, X, rows, rpb, part);
-    else hipLaunchKernelGGL((k_gram<double, 64>), grid, blk, 0, st, X, rows, rpb, part);
+    else if (L == 64) hipLaunchKernelGGL((k_gram<double, 64>), grid, blk, 0, st, X, rows, rpb, part);
+    else launch_gram_any_f64(st, X, rows, rpb, gram_num_parts(rows), L, part);
 }
 // Gram of the tall f32 factor (B = A Q, M rows) on the f64 matrix cores: W = X^T X as 16x16x4 MFMAs.  Lane (i = lane & 15,
 // k = lane >> 4) converts X[n + k][16 g + i] once and uses it both as the A element (X^T tile g) and as the B element
@@ -761,7 +774,8 @@ void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double
     const int64_t rpb = gram_rows_per_block(rows);
     const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
     if (L == 32) hipLaunchKernelGGL((k_gram_mfma<32>), grid, blk, 0, st, X, rows, rpb, part);
-    else hipLaunchKernelGGL((k_gram_mfma<64>), grid, blk, 0, st, X, rows, rpb, part);
+    else if (L == 64) hipLaunchKernelGGL((k_gram_mfma<64>), grid, blk, 0, st, X, rows, rpb, part);
+    else launch_gram_any_f32(st, X, rows, rpb, gram_num_parts(rows), L, part);
 }
 
 // X[n][:] <- X[n][:] Z, in place through an LDS row tile; optional f32 copy into Qout (pad rows zeroed)
@@ -824,7 +838,8 @@ void launch_apply_right_tail(hipStream_t st, double* X, int64_t rows, int L, con
                              double* csum_part, double* amax_part) {
     const dim3 grid((unsigned)tail_num_parts(rows_pad)), blk(256);
     if (L == 32) hipLaunchKernelGGL((k_apply_right_tail<32>), grid, blk, 0, st, X, rows, Z, Qout, rows_pad, csum_part, amax_part);
-    else hipLaunchKernelGGL((k_apply_right_tail<64>), grid, blk, 0, st, X, rows, Z, Qout, rows_pad, csum_part, amax_part);
+    else if (L == 64) hipLaunchKernelGGL((k_apply_right_tail<64>), grid, blk, 0, st, X, rows, Z, Qout, rows_pad, csum_part, amax_part);
+    else launch_apply_right_any(st, X, rows, tail_num_parts(rows_pad), L, Z, csum_part, amax_part);      // (exact path only: no f32 copy of the basis)
 }
 // s64/s32[c] = sum_p csum_part[p][c] (fixed order);  digit scale of column c from max_p amax_part[p][c]:
 // scale = max / S, inv = S / max (0 for an all-zero column), S = kDigitScale.  One workgroup.
@@ -948,14 +963,16 @@ __global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, 
 //  one workgroup adds 63 slices more slowly than the 16 workgroups of k_sum_partials.)
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
     if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
-    else hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
+    else if (ld == 64) hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
+    else launch_chol_inv_any(st, W, n, ld, Z, Z + (size_t)ld * ld, flag);       // (Z's allocation holds 2 x L x L doubles: the second half is the factor's scratch)
 }
 
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,
                                 int64_t rows_pad) {
     const int64_t span = Qout ? rows_pad : rows;
     if (L == 32) hipLaunchKernelGGL((k_apply_right<32>), dim3((unsigned)((span + 7) / 8)), dim3(256), 0, st, X, rows, Z, Qout, rows_pad);
-    else hipLaunchKernelGGL((k_apply_right<64>), dim3((unsigned)((span + 3) / 4)), dim3(256), 0, st, X, rows, Z, Qout, rows_pad);
+    else if (L == 64) hipLaunchKernelGGL((k_apply_right<64>), dim3((unsigned)((span + 3) / 4)), dim3(256), 0, st, X, rows, Z, Qout, rows_pad);
+    else launch_apply_right_any(st, X, rows, (rows + 63) / 64, L, Z, nullptr, nullptr);
 }
 
 // out[n][kc] = sum_j X[row(n)][j] Z[j][kc].  One thread per row: the row sits in registers (L/4 16-byte loads), Z is
@@ -1002,9 +1019,9 @@ void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, c
     const dim3 grid((unsigned)((rows + 255) / 256)), blk(256);
     const size_t lds = rightmul_lds(L, K, out32 != nullptr);
     if (L == 32) hipLaunchKernelGGL((k_rightmul<double, 32>), grid, blk, lds, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
-    else {   // (> 64 KiB of dynamic LDS: opted in per device by init_device_kernels_common)
+    else if (L == 64) {   // (> 64 KiB of dynamic LDS: opted in per device by init_device_kernels_common)
         hipLaunchKernelGGL((k_rightmul<double, 64>), grid, blk, lds, st, X, (const int64_t*)nullptr, rows, Z, K, out64, out32);
-    }
+    } else launch_rightmul_any_f64(st, X, rows, L, Z, K, out64, out32);
 }
 // Loadings = B[rows] (V S^-1): the tall f32 factor times an L x K f64 matrix, on the f64 matrix cores (the VALU kernel
 // above is LDS-broadcast bound: 640 ds_reads per row).  One wave = 16 rows per tile: lane (i = lane & 15, kq = lane >> 4)
@@ -1073,6 +1090,7 @@ __global__ __launch_bounds__(256) void k_rightmul_mfma(const float* __restrict__
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
                                 const double* Z, int K, float* out32) {
     if (nrows == 0) return;
+    if (L > 64) { launch_rightmul_any_gather_f32(st, X, row_ids, nrows, L, Z, K, out32); return; }
     const int64_t ntiles = (nrows + 15) / 16;
     int64_t tpw = ntiles / (4 * 2048);            // ~2048 workgroups, at least one tile per wave
     if (tpw < 1) tpw = 1;

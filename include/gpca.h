@@ -26,7 +26,8 @@
  * the handle (or, for a thread that has not failed on it, the handle's last message).  Functions return GPCA_OK (0) or a
  * negative gpca_status.
  *
- * Limits: k + oversample <= 64 sketch columns; GPCA_PREC_I8_EXACT holds up to 2^22 (4 194 304) samples per matrix (i32
+ * Limits: k + oversample <= 128 sketch columns on GPCA_PREC_I8_EXACT (<= 64 on GPCA_PREC_F32_MFMA and in the EigenSNP stage calls: the
+ * reference adds 10 to any k <= min(samples, variants), main.rs:621-628, 636); GPCA_PREC_I8_EXACT holds up to 2^22 (4 194 304) samples per matrix (i32
  * accumulators; GPCA_PREC_F32_MFMA has no such bound); SNP rows per handle are bounded by device memory only (64M rows x 1 000
  * samples and 10M x 100k as 2-bit codes were run on one MI355X), the bit-for-bit guarantees between partitions of the same
  * matrix (streamed = resident, any kernel variant) hold up to 2^25 (33.5M) rows per handle, where integer sums stay below 2^53.
@@ -226,7 +227,7 @@ GPCA_API int gpca_set_standardization(gpca_handle* h, const float* mu, const flo
 /* Current parameters, length M each (any may be NULL): what gpca_snp_stats computed or gpca_set_standardization set. */
 GPCA_API int gpca_get_standardization(gpca_handle* h, float* mu, float* sigma, uint8_t* keep);
 /* Host helper (no GPU): the symmetric eigen-solver gpca_rsvd uses for its l x l host step (Householder tridiagonalisation +
- * implicit QL), exposed so that CPU-only tests can pin it against LAPACK.  a_sym: n x n row-major (n <= 64); w: eigenvalues
+ * implicit QL), exposed so that CPU-only tests can pin it against LAPACK.  a_sym: n x n row-major (n <= 128); w: eigenvalues
  * descending; v: eigenvectors in columns, row-major. */
 GPCA_API int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, double* v);
 /* Host helper, same branches as prepare.rs:1641-1745. */
@@ -243,7 +244,7 @@ GPCA_API int64_t gpca_num_qc_samples(gpca_handle* h); /* prepare.rs:2027-2029 */
 GPCA_API int gpca_get_pca_snp_rows(gpca_handle* h, int64_t* rows);
 
 /* ---- a5/a6: randomized PCA (PCA::rfit main.rs:648-656; compute_pca main.rs:365) ---------- */
-/* l = k + oversample columns (<= 64); power_iters QR-stabilised iterations; Omega from
+/* l = k + oversample columns (<= 128, see Limits); power_iters QR-stabilised iterations; Omega from
  * Philox4x32-10 keyed by seed.  Requires stats.  Results stay on the device until fetched.
  * Row-sharded runs (gpca_comm_init / gpca_set_allreduce_hook): the ranks agree on a status word before the first and after
  * the last exchange of the call, so a rank-local failure (missing genotype in one shard, out of memory, a failed launch)

@@ -84,7 +84,7 @@ def test_host_eigensolver_against_lapack(gpca):
     import numpy as np
     lib = gpca.load()
     rng = np.random.default_rng(0)
-    for n in (1, 2, 3, 7, 16, 30, 31, 32, 50, 64):
+    for n in (1, 2, 3, 7, 16, 30, 31, 32, 50, 64, 70, 100, 128):
         for kind in ("gram", "spread", "rank_deficient", "repeated"):
             B = rng.standard_normal((max(n, 2) * 3, n))
             if kind == "spread":

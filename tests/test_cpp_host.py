@@ -323,15 +323,50 @@ def test_cpp_vcf_workflow_equals_python_cli(tmp_path, host_bin, gpca, oracle):
             f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
             for i in range(lo, hi):
                 f.write(f"{ci + 1}\t{i + 1}\t.\tA\tC\t.\t.\t.\tGT:DP\t" + "\t".join(gt[int(v)] + ":5" for v in G[i]) + "\n")
-    for extra in ([], ["--write-eigenvalues"]):
+    # (-k 38 with 48 samples: the reference clamps k to min(samples, variants) and adds 10 -- a 48-column sketch; -k 60 asks for more
+    #  components than there are samples: clamped to 48, the oversampling to what is left)
+    for kk, extra in (("4", []), ("4", ["--write-eigenvalues"]), ("38", ["--write-eigenvalues"]), ("60", ["--write-eigenvalues"])):
         out_c, out_p = str(tmp_path / "c" / "v"), str(tmp_path / "p" / "v")
-        common = ["--vcf-dir", str(d), "-k", "4", "--maf", "0.05", "--rfit-seed", "3"] + extra
+        common = ["--vcf-dir", str(d), "-k", kk, "--maf", "0.05", "--rfit-seed", "3"] + extra
         r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert main(["--out", out_p] + common) == 0
         for sfx in (".vcf.pca.tsv", ".eigenvalues.tsv"):
             assert open(out_c + sfx).read() == open(out_p + sfx).read(), sfx
         assert (len(open(out_c + ".eigenvalues.tsv").read().split("\n")) > 3) == bool(extra)
+
+
+@pytest.mark.gpu
+def test_both_clis_components_60(tmp_path, host_bin, gpca, oracle):
+    """`--components 60` (missing #2): the reference clamps k to min(samples, variants) and adds 10 (main.rs:621-628, 636), a
+    70-column sketch; both command lines run it (128 padded columns on the exact-integer path), write the same bytes, and the leading PCs
+    are the oracle's."""
+    from genomic_pca_amd.cli import main
+    M, N, P = 900, 130, 6
+    G = oracle.synth_genotypes(M, N, 5, gpca.synth_thresholds(M, P, seed=5, fst=0.3))
+    names = [f"S{i}" for i in range(N)]
+    gt = {0: "0/0", 1: "0|1", 2: "1/1"}
+    d = tmp_path / "vcfs"; d.mkdir()
+    with open(d / "chr1.vcf", "wt") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for i in range(M):
+            f.write(f"1\t{i + 1}\t.\tA\tC\t.\t.\t.\tGT\t" + "\t".join(gt[int(v)] for v in G[i]) + "\n")
+    out_c, out_p = str(tmp_path / "c" / "v"), str(tmp_path / "p" / "v")
+    common = ["--vcf-dir", str(d), "--components", "60", "--maf", "0.0", "--rfit-seed", "3", "--write-eigenvalues"]
+    r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert main(["--out", out_p] + common) == 0
+    for sfx in (".vcf.pca.tsv", ".eigenvalues.tsv"):
+        assert open(out_c + sfx).read() == open(out_p + sfx).read(), sfx
+    rows = [ln.split("\t") for ln in open(out_p + ".vcf.pca.tsv").read().strip().split("\n")]
+    assert rows[0] == ["SampleID"] + [f"PC{i + 1}" for i in range(60)] and len(rows) == N + 1
+    pcs = np.array([[float(x) for x in rw[1:]] for rw in rows[1:]])
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    keep = st["keep"].astype(bool)
+    r_, b_ = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r_, b_, 60, 10, 2, seed=3)
+    assert keep.sum() > 800
+    assert oracle.max_abs_dpc(pcs[:, :P - 1], R["scores"][:, :P - 1]) < 1e-4 + 2e-6      # ({:.6} in the file)
 
 
 @pytest.mark.gpu

@@ -180,6 +180,42 @@ def test_rsvd_l64_path(gpca, oracle, engine):
     assert oracle.max_abs_dpc(engine.scores(f64=True)[:, :20], R["scores"][:, :20]) < TOL_PC
 
 
+@pytest.mark.parametrize("store", ["int8", "2bit", "2bit4"])
+@pytest.mark.parametrize("M,N,P,k", [(8000, 900, 60, 90), (5000, 700, 40, 60)])
+def test_rsvd_wide_sketch(gpca, oracle, store, M, N, P, k):
+    """Sketches wider than 64 columns: k = 90 -> l = 100 and k = 60 -> l = 70, both padded to 128 columns = four 32-column GEMM blocks and
+    the any-L helpers of wide_sketch.hip (Gram, Cholesky + inverse in global memory, right multiplications).  The reference clamps k only
+    to min(samples, variants) and always adds 10 (main.rs:621-628, 636), so -k 60 is an ordinary call there; it was refused here up to
+    round 3.  Bars: the oracle's, on every structured PC; the orthonormality of what comes back on all k."""
+    from genomic_pca_amd import _lib
+    th = gpca.synth_thresholds(M, P, seed=7, fst=0.3)
+    G = oracle.synth_genotypes(M, N, 7, th)
+    st = oracle.snp_stats(G, N, 0.0, 0.0, 1.0)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=7)
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_INT8 if store == "int8" else _lib.STORE_2BIT,
+                         digit_planes=4 if store == "2bit4" else 0) as e:
+        e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none()); e.rsvd(k, 10, 2, seed=7)
+        ev, sc, ld, sv = e.eigenvalues(), e.scores(f64=True), e.loadings().astype(np.float64), e.singular_values()
+        tr = e.transform()
+    assert ev.shape == (k,) and sc.shape == (N, k) and ld.shape == (M, k) and sv.shape == (k + 10,)
+    assert np.max(np.abs(ev - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+    ns = P - 1                                                       # the population PCs; the rest sit in the noise bulk
+    assert oracle.max_abs_dpc(sc[:, :ns], R["scores"][:, :ns]) < TOL_PC
+    assert oracle.max_abs_dpc(ld[:, :ns], R["loadings"][:, :ns]) < TOL_PC
+    gram = sc.T @ sc
+    assert np.max(np.abs(gram - np.diag(np.diag(gram)))) < 1e-8 * gram[0, 0]          # scores orthogonal, norms = singular values
+    assert np.max(np.abs(np.sqrt(np.diag(gram)) - sv[:k]) / sv[:k]) < 1e-8
+    assert np.max(np.abs(ld.T @ ld - np.eye(k))) < 1e-5                                # loadings orthonormal (f32 storage)
+    assert oracle.max_abs_dpc(tr[:, :ns], sc[:, :ns]) < 1e-2                           # PCA::transform on the fitted matrix
+    with gpca.GpcaEngine(precision=_lib.PREC_F32_MFMA) as e:                           # the f32 path holds 64 columns: a clear refusal, not garbage
+        e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig.none())
+        with pytest.raises(gpca.GpcaError, match="wider than 64 columns"):
+            e.rsvd(k, 10, 2, seed=7)
+        with pytest.raises(gpca.GpcaError, match="<= 128"):
+            e.rsvd(120, 10, 2, seed=7)
+
+
 def test_rsvd_vs_exact_pca(gpca, oracle, engine):
     """Converged answer: exact f64 PCA (reference's own cross-check pattern, tests/pca.py:81-141)."""
     G, r, b, R = _rsvd_case(gpca, oracle, engine, 8000, 400, 8, 6, seed=2, fst=0.3)
