@@ -692,7 +692,7 @@ def test_i8_wide_sketch_two_column_halves(gpca, oracle, store, planes):
         assert oracle.max_abs_dpc(tr[:, :20], f.transform()[:, :20]) < TOL_PC
     with pytest.raises(gpca.GpcaError):
         with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT) as e2:
-            e2.upload_genotypes_i8(G); e2.snp_stats(gpca.QcConfig.none()); e2.rsvd(60, 10)      # l = 70 > 64
+            e2.upload_genotypes_i8(G); e2.snp_stats(gpca.QcConfig.none()); e2.rsvd(120, 10)     # l = 130 > 128 (l = 70: test_rsvd_wide_sketch)
 
 
 # ------------------------------------------------------------------------------------------------
