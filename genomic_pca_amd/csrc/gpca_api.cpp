@@ -10,10 +10,12 @@ thread_local std::string g_last_global_err;
 
 // The failing call's text is kept twice: on the handle, and for the calling thread -- several threads may be inside
 // gpca_standardize_block on one handle at once, and each must read ITS failure back from gpca_last_error.
-static thread_local const gpca_handle* g_tls_err_handle = nullptr;
+// (keyed by the handle's generation id, not its address: a new handle at a recycled address must not read a stale text)
+static thread_local uint64_t g_tls_err_gen = 0;
 static thread_local std::string g_tls_err;
+static std::atomic<uint64_t> g_next_gen{1};
 int fail(gpca_handle* h, int code, const std::string& msg) {
-    if (h) { h->err = msg; g_tls_err_handle = h; g_tls_err = msg; } else g_last_global_err = msg;
+    if (h) { h->err = msg; g_tls_err_gen = h->gen; g_tls_err = msg; } else g_last_global_err = msg;
     return code;
 }
 
@@ -53,7 +55,7 @@ extern "C" const char* gpca_status_string(int s) {
 extern "C" const char* gpca_last_error(gpca_handle* h) {
     if (!h) return g_last_global_err.c_str();
     // this thread's own last failure on this handle (a thread that never failed here reads the handle's text)
-    if (g_tls_err_handle == h) return g_tls_err.c_str();
+    if (g_tls_err_gen == h->gen) return g_tls_err.c_str();
     return h->err.c_str();
 }
 
@@ -64,6 +66,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, GPCA_ERR_NO_DEVICE, "gpca_create: no HIP device visible (this engine has no CPU fallback)");
     gpca_handle* h = new gpca_handle();
+    h->gen = g_next_gen.fetch_add(1, std::memory_order_relaxed);
     int dev = cfg ? cfg->device : -1;
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= ndev) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: device ordinal out of range"); }
@@ -124,12 +127,21 @@ void drop_child(gpca_handle* h) {
     gpca_handle* c = h->child;
     h->child = nullptr;
     c->d_row_ids = nullptr;
+    if (h->timing_on || !c->agg.empty() || !c->recs.empty()) {     // the passes that ran on the child stay in this handle's timings
+        (void)hipStreamSynchronize(h->st);
+        fold_timings(c);
+        for (const gpca_kernel_timing& t : c->agg) {
+            size_t i = 0;
+            for (; i < h->agg.size(); ++i) if (strcmp(h->agg[i].name, t.name) == 0) break;
+            if (i == h->agg.size()) h->agg.push_back(t);
+            else { h->agg[i].launches += t.launches; h->agg[i].total_ms += t.total_ms; h->agg[i].flops += t.flops; h->agg[i].bytes += t.bytes; }
+        }
+    }
     (void)gpca_destroy(c);
 }
 
 extern "C" int gpca_destroy(gpca_handle* h) {
     if (!h) return GPCA_OK;
-    if (g_tls_err_handle == h) g_tls_err_handle = nullptr;    // (the address may come back as another handle)
     { LOCK(h);
       (void)hipSetDevice(h->device);
       (void)hipStreamSynchronize(h->st);
@@ -147,6 +159,7 @@ extern "C" int gpca_destroy(gpca_handle* h) {
       dfree(h->d_status); if (h->h_status) { (void)hipHostFree(h->h_status); h->h_status = nullptr; }
       if (!h->is_child) (void)hipStreamDestroy(h->st);      // (a compact child runs on its parent's stream)
     }
+    { std::lock_guard<std::mutex> lk(h->pull_mu); }        // a pull that has just counted itself out may still be inside its critical section
     delete h;
     return GPCA_OK;
 }
@@ -402,8 +415,8 @@ extern "C" int gpca_standardize_block(gpca_handle* h, const int64_t* snp_ids, in
         std::lock_guard<std::mutex> lk(h->pull_mu);
         h->lanes_free.push_back(ln);
         h->pulls_in_flight.fetch_sub(1, std::memory_order_acq_rel);
+        h->pull_cv.notify_all();     // (under pull_mu: a gpca_destroy woken in drain_pulls cannot delete the handle before this returns)
     }
-    h->pull_cv.notify_all();
     if (rc != GPCA_OK) { LOCK_SHARED(h); return fail(h, rc, msg); }
     return GPCA_OK;
 }
@@ -436,6 +449,7 @@ extern "C" int gpca_comm_init(gpca_handle* h, int32_t world, int32_t rank, const
     }
     if (!h->d_status) HIPCHK(hipMalloc((void**)&h->d_status, 16 * sizeof(double)));   // allocated here so that the agreement itself cannot run out of memory
     if (!h->h_status) HIPCHK(hipHostMalloc((void**)&h->h_status, 32 * sizeof(double), hipHostMallocDefault));
+    if (h->snp_offset != snp_offset) drop_child(h);      // (a compact child draws Omega by global row index: rebuilt with the new offset)
     h->world = world; h->rank = rank; h->snp_offset = snp_offset; h->hook = nullptr;
     return GPCA_OK;
 }
@@ -447,6 +461,7 @@ extern "C" int gpca_set_allreduce_hook(gpca_handle* h, gpca_allreduce_fn fn, voi
     HIPCHK(hipSetDevice(h->device));
     if (!h->d_status) HIPCHK(hipMalloc((void**)&h->d_status, 16 * sizeof(double)));
     if (!h->h_status) HIPCHK(hipHostMalloc((void**)&h->h_status, 32 * sizeof(double), hipHostMallocDefault));
+    if (h->snp_offset != snp_offset) drop_child(h);
     h->hook = fn; h->hook_user = user; h->world = world; h->rank = rank; h->snp_offset = snp_offset;
     return GPCA_OK;
 }

@@ -201,6 +201,7 @@ struct gpca_handle {
     double *dYpart64 = nullptr, *d_qscale = nullptr, *d_qinv = nullptr, *d_tscale = nullptr, *d_tinv = nullptr;
     size_t cap_Qd = 0, cap_Td = 0, cap_Ypart64 = 0;
     int nd = 4;           // digit planes of the exact path (gpca_config.digit_planes): 4 x base 128, or 3 x base 256 (packed storage)
+    uint64_t gen = 0;         // generation id of this handle (per-thread error texts are keyed by it)
     int simple_kernels = 0;   // gpca_config.reserved[0] & GPCA_CFG_SIMPLE_KERNELS: the register-only reference kernels (gemm_i8_simple.hip)
     int narrow_ok = 1;    // matrices of at most 256 samples (int8 rows) run the narrow K1 / K2 (GPCA_CFG_NO_NARROW: the wide kernels on padded rows)
     int gq_waves_target = 1024, gtt_waves_target = 2048;   // resident-wave targets (256 CUs x 4 SIMDs x 1 or 2), tuned on MI355X

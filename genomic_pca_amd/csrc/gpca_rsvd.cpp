@@ -465,7 +465,15 @@ static bool wants_child(gpca_handle* h, int32_t k, int32_t oversample) {
     if (!h->compact_ok || h->is_child || h->sm.on || multi_rank(h) || h->d_smask || !h->have_stats || (!h->dG && !h->dG2)) return false;
     if (h->n_pca < 1 || k + oversample > h->n_pca) return false;                       // (the usual preflight reports these)
     if ((h->flags & 3u) != 0) return false;                                             // (missing / invalid genotypes: ditto)
-    return 2 * round_up(h->n_pca, kGQRowsPerWave) <= h->Mpad;
+    // ... and only when it pays.  A child costs a workspace of its own (~35 allocations), a gather and, when the keep mask changes, the
+    // matching frees: milliseconds.  A call over a few thousand rows gains microseconds from losing half of them -- the per-block local
+    // stage of the EigenSNP hosts re-targets ONE scratch handle at thousands of ~300-row LD blocks (copy_rows + set_standardization +
+    // rsvd), where compaction turned a 1.7 ms block into allocator traffic.  Worth it from 32 Ki dropped rows AND 8 MiB of genotype
+    // bytes that no longer stream six times per call (configs[2]: 860k of 1 066 557 rows, 220 MB).
+    const int64_t npad = round_up(h->n_pca, kGQRowsPerWave), dropped = h->Mpad - npad;
+    const int64_t pitch = h->storage == GPCA_STORE_2BIT ? h->ld2 : h->ld8;
+    if (dropped < 32768 || dropped * pitch < ((int64_t)8 << 20)) return false;
+    return 2 * npad <= h->Mpad;
 }
 static int ensure_child(gpca_handle* h) {
     if (h->child && h->child_valid) return GPCA_OK;

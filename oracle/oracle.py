@@ -27,14 +27,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MISSING = -127  # prepare.rs:1224
+# GPCA_ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build of the same source (oracle/_asan/, `make -C oracle asan`); the process must
+# run with LD_PRELOAD=$(gcc -print-file-name=libasan.so) (scripts/sanitize_cpu.sh does)
+_LIBDIR = os.path.join(_HERE, "_asan") if os.environ.get("GPCA_ORACLE_SANITIZE") == "1" else _HERE
 
 
 def build(force: bool = False) -> None:
     need = force or any(
-        not os.path.exists(os.path.join(_HERE, f)) for f in ("liboracle_f64.so", "liboracle_f32.so")
+        not os.path.exists(os.path.join(_LIBDIR, f)) for f in ("liboracle_f64.so", "liboracle_f32.so")
     )
     if need:
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _LIBDIR != _HERE else []) + (["-B"] if force else []))
 
 
 _libs: dict = {}
@@ -43,7 +46,7 @@ _libs: dict = {}
 def lib(real: str = "f64") -> C.CDLL:
     if real not in _libs:
         build()
-        L = C.CDLL(os.path.join(_HERE, f"liboracle_{real}.so"))
+        L = C.CDLL(os.path.join(_LIBDIR, f"liboracle_{real}.so"))
         L.orc_hwe_p.restype = C.c_double
         L.orc_hwe_p.argtypes = [C.c_uint64] * 3
         L.orc_standardize_block.restype = C.c_int64

@@ -12,14 +12,16 @@ import pytest
 from genomic_pca_amd import io as gio
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "genomic_pca_amd", "bin", "genomic_pca")
+SANITIZE = os.environ.get("GPCA_HOST_SANITIZE") == "1"            # scripts/sanitize_cpu.sh: the host program and the parser harness under ASan + UBSan
+BIN = os.path.join(ROOT, "genomic_pca_amd", "bin", "genomic_pca_asan" if SANITIZE else "genomic_pca")
+SANFLAGS = ["-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if SANITIZE else []
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 @pytest.fixture(scope="module")
 def host_bin(gpca):
     gpca.load()                                                   # (builds libgpca.so when it is missing)
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "genomic_pca_amd", "host"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "genomic_pca_amd", "host"), "-s"] + (["asan"] if SANITIZE else []))
     assert os.path.exists(BIN)
     return BIN
 
@@ -27,7 +29,7 @@ def host_bin(gpca):
 @pytest.fixture(scope="module")
 def dump(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("cpp") / "dump_formats")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "genomic_pca_amd", "host"),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror"] + SANFLAGS + ["-I" + os.path.join(ROOT, "genomic_pca_amd", "host"),
                            os.path.join(ROOT, "tests", "cpp", "dump_formats.cpp"), "-lz", "-o", exe])
 
     def run(*args):

@@ -216,6 +216,39 @@ def test_rsvd_wide_sketch(gpca, oracle, store, M, N, P, k):
             e.rsvd(120, 10, 2, seed=7)
 
 
+@pytest.mark.parametrize("planes", [3, 4])
+def test_three_planes_under_a_wide_maf_spectrum(gpca, oracle, planes):
+    """three digit planes are the default on 2-bit rows, and the sketch's planes are scaled by the analytic bound 6.67 max r over
+    ALL kept rows.  With rare variants in the PCA (MAF down to the clap default's QC floor, 0.01) r = 1/sigma spans ~5x, so the typical
+    row sits several bits below the scale of the rarest one.  A realistic spectrum -- ancestral frequencies log-uniform on [0.012, 0.5],
+    half of the SNPs below 8 % -- through the default QC: the three-plane engine must still hold the oracle's bar (recorded: see the
+    assertion message), as the four-plane form does."""
+    from genomic_pca_amd import _lib
+    M, N, P, k = 30000, 1200, 6, 10
+    rng = np.random.default_rng(11)
+    p_anc = np.exp(rng.uniform(np.log(0.012), np.log(0.5), M))
+    fst = 0.1
+    a = p_anc * (1 - fst) / fst; bb = (1 - p_anc) * (1 - fst) / fst
+    p_pop = np.clip(rng.beta(a[:, None], bb[:, None], size=(M, P)), 0.0, 1.0)
+    th = np.minimum(np.floor(p_pop * 4294967296.0), 4294967295.0).astype(np.uint32)
+    G = oracle.synth_genotypes(M, N, 11, th)
+    qc = (0.98, 0.01, 1e-6)
+    st = oracle.snp_stats(G, N, *qc)
+    keep = st["keep"].astype(bool)
+    r, b = oracle.scale_shift(st["mu"], st["sigma"], st["keep"])
+    spread = r[keep].max() / r[keep].min()
+    assert keep.sum() > 0.6 * M and spread > 4.0, (keep.sum(), spread)
+    R = oracle.rsvd(G, N, r, b, k, 10, 2, seed=2)
+    with gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_2BIT, digit_planes=planes) as e:
+        e.upload_genotypes_i8(G); e.snp_stats(gpca.QcConfig(*qc)); e.rsvd(k, 10, 2, seed=2)
+        dsc = oracle.max_abs_dpc(e.scores(f64=True)[:, :P - 1], R["scores"][:, :P - 1])
+        dld = oracle.max_abs_dpc(e.loadings().astype(np.float64)[:, :P - 1], R["loadings"][keep][:, :P - 1])
+        dev = float(np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]))
+    msg = f"planes {planes}: r spread {spread:.1f}x, max|dPC| scores {dsc:.2e} loadings {dld:.2e}, eigenvalues {dev:.2e}"
+    print(msg)
+    assert dsc < (1e-5 if planes == 3 else 1e-7) and dld < 1e-4 and dev < (1e-5 if planes == 3 else 1e-7), msg
+
+
 def test_rsvd_vs_exact_pca(gpca, oracle, engine):
     """Converged answer: exact f64 PCA (reference's own cross-check pattern, tests/pca.py:81-141)."""
     G, r, b, R = _rsvd_case(gpca, oracle, engine, 8000, 400, 8, 6, seed=2, fst=0.3)
@@ -1066,6 +1099,14 @@ def test_compact_child_when_qc_drops_most_rows(gpca, oracle, monkeypatch, prec, 
                     r2, b2 = oracle.scale_shift(st["mu"], st["sigma"], keep2)
                     R2 = oracle.rsvd(G, N, r2, b2, k, 10, 2, seed=5)
                     assert oracle.max_abs_dpc(e.scores(f64=True)[:, :5], R2["scores"][:, :5]) < TOL_PC
+    # ... and only when it pays: a matrix that loses fewer than 32 Ki rows is swept as it is -- the EigenSNP hosts re-target one
+    # scratch handle at thousands of ~300-row LD blocks, where a child per block was milliseconds of allocator traffic for microseconds saved
+    with gpca.GpcaEngine(**kw) as e:
+        Ms = 20_000
+        e.upload_genotypes_i8(G[:Ms]); st = e.snp_stats(gpca.QcConfig.none())
+        e.set_standardization(st["mu"], st["sigma"], keep[:Ms]); e.enable_timings(True); e.rsvd(k, 10, 2, seed=5)
+        tim = e.timings()
+        assert abs(tim["gemm_GQ"]["bytes"] / tim["gemm_GQ"]["launches"] / (N * (0.25 if store == "2bit" else 1.0)) - Ms) < 1
     tol = 1e-7 if prec == "i8" else 1e-5
     assert np.max(np.abs(res["compact"][0] - res["plain"][0]) / res["plain"][0]) < tol
     assert oracle.max_abs_dpc(res["compact"][1][:, :5], res["plain"][1][:, :5]) < tol

@@ -346,6 +346,48 @@ def test_panel_cache_pad_columns_on_recycled_device_memory(gpca, oracle):
                 assert np.array_equal(st[key], ref[key]), key
 
 
+@pytest.mark.parametrize("store", ["int8", "2bit"])
+def test_second_engine_on_recycled_device_memory_returns_the_first_engines_bits(gpca, oracle, store):
+    """VERDICT r3 #7.  Round 3 saw wrong statistics from the SECOND engine of a process when genotype storage came from
+    hipExtMallocWithFlags(hipDeviceMallocContiguous) and withdrew that allocation path; one reading of the evidence was a dependence on
+    bytes that are zero only because their allocation is fresh (row-pitch pad columns, rows M .. Mpad, the tail rows of T, digit planes
+    of pad rows).  This test makes every such dependence show with plain hipMalloc: three shapes (N % 16 != 0, M % 128 != 0, a wide
+    64-column sketch, missing genotypes in dropped rows) are run FIRST on pristine memory, then the pool is dirtied -- engines of
+    other shapes whose genotype buffer is all 1s or 2s (0x01 / 0x02 in every pad position they would cover) and whose workspaces are
+    full of live floats, resident and streamed, created and destroyed -- and the same shapes run again, in another order, interleaved
+    with more dirt.  Every result must be the first run's bits."""
+    cases = [(5003, 1003, 6, 3), (2999, 517, 40, 5), (12001, 2050, 10, 7)]
+    data = {}
+    for (M, N, k, seed) in cases:
+        G = oracle.synth_genotypes(M, N, seed, gpca.synth_thresholds(M, 4, seed=seed, fst=0.2))
+        G[::97, : N // 3] = -127                                   # rows that QC drops (call rate), missing codes in them
+        data[(M, N)] = G
+
+    def run(M, N, k, seed, streamed=False):
+        G = data[(M, N)]
+        with gpca.GpcaEngine(**_modes(store)) as e:
+            if streamed:
+                e.stream_open(gpca.PanelSource.host_i8(lambda r0, r: G[r0:r0 + r]), M, N, panel_rows=1024, ring_slots=2, fused=False)
+            else:
+                e.upload_genotypes_i8(G)
+            return _run(e, k, seed, gpca.QcConfig(0.9, 0.0, 1.0))
+
+    def dirt(M, N, val, k):
+        with gpca.GpcaEngine(**_modes(store)) as d:
+            d.upload_genotypes_i8(np.full((M, N), val, np.int8) if val else (np.arange(M * N, dtype=np.int64).reshape(M, N) % 3).astype(np.int8))
+            d.snp_stats(gpca.QcConfig.none())
+            if val == 0:
+                d.rsvd(k, 10, 1, seed=1)                           # live workspaces: T, Y, digit planes, partial tiles
+    first = {c: run(*c) for c in cases}
+    for c in cases:                                                # (streamed = resident, bit for bit, on pristine memory too)
+        _same(first[c], run(*c, streamed=True))
+    dirt(13000, 2304, 1, 4); dirt(6100, 1280, 2, 4); dirt(9000, 1111, 0, 30); dirt(3100, 600, 0, 8)
+    for c in reversed(cases):
+        _same(first[c], run(*c))
+        dirt(c[0] + 257, c[1] + 130, 1, 4); dirt(4000, 900, 0, 20)
+        _same(first[c], run(*c, streamed=True))
+
+
 @pytest.mark.parametrize("store,fused", [("int8", False), ("2bit", False), ("2bit", True)])
 def test_panel_cache_reads_the_source_once(gpca, store, fused):
     """gpca_stream_set_cache: the leading panels keep an HBM buffer of their own -- the source is asked for them once (during
