@@ -1103,8 +1103,8 @@ def test_compact_child_when_qc_drops_most_rows(gpca, oracle, monkeypatch, prec, 
     # scratch handle at thousands of ~300-row LD blocks, where a child per block was milliseconds of allocator traffic for microseconds saved
     with gpca.GpcaEngine(**kw) as e:
         Ms = 20_000
-        e.upload_genotypes_i8(G[:Ms]); st = e.snp_stats(gpca.QcConfig.none())
-        e.set_standardization(st["mu"], st["sigma"], keep[:Ms]); e.enable_timings(True); e.rsvd(k, 10, 2, seed=5)
+        e.upload_genotypes_i8(G[:Ms]); st_s = e.snp_stats(gpca.QcConfig.none())
+        e.set_standardization(st_s["mu"], st_s["sigma"], keep[:Ms]); e.enable_timings(True); e.rsvd(k, 10, 2, seed=5)
         tim = e.timings()
         assert abs(tim["gemm_GQ"]["bytes"] / tim["gemm_GQ"]["launches"] / (N * (0.25 if store == "2bit" else 1.0)) - Ms) < 1
     tol = 1e-7 if prec == "i8" else 1e-5
