@@ -256,17 +256,11 @@ template <int R, int ND = kDigits>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
                                           const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float* __restrict__ cunit, float& amax, int64_t row0, int c, int h, int lane, const unsigned* lut,
-                                          float* __restrict__ tile) {
+                                          float* __restrict__ cunit, float& amax, int64_t row0, int c, int h, int lane, const unsigned* lut) {
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
     uint32_t gvo[R];
 #pragma unroll
     for (int t = 0; t < R; ++t) gvo[t] = (uint32_t)((32 * t + c) * ld2 + 16 * h);
-    // r and b of the group's rows, one row per lane (row 32 t + c), asked for before the sweep: the epilogue picks them up with a
-    // cross-lane read instead of 32 dependent global loads per tile
-    float rrow[R], brow[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) { rrow[t] = rv[row0 + 32 * t + c]; brow[t] = bv[row0 + 32 * t + c]; }
     const uint32_t qvo = (uint32_t)(lane * 16);
     constexpr uint32_t QCH = kDigits * 1024;   // bytes of digit planes per MFMA step
     const uint32_t nsteps = (uint32_t)(nsuper * 16);
@@ -316,8 +310,21 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
 #undef GQ2_BLOCK
 #undef GQ2_PHASE
 #pragma unroll
-    for (int t = 0; t < R; ++t)
-        gq_tile_out<ND == 3 ? 8 : 7, false, true>(acc[t], rrow[t], brow[t], nullptr, nullptr, qs, sj, scale_out, tile, Tout, ldt, row0 / 32 + t, cunit, amax, lane);
+    for (int t = 0; t < R; ++t) {
+        float ct = 0.f;     // this tile's share of c = b^T T: one partial per 32-row unit, so c does not depend on the grid partition
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = row0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float ri = rv[row], bi = bv[row];
+            const float gq = (float)(combine_digits<ND == 3 ? 8 : 7>(acc[t], e) * qs);
+            const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+            ct = __fmaf_rn(bi, tv, ct);
+            const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
+            amax = fmaxf(amax, fabsf(ov));
+            Tout[row * ldt + c] = ov;
+        }
+        GPCA_STORE_CUNIT(row0 / 32 + t)
+    }
 }
 
 template <int ND>
@@ -340,19 +347,18 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
     // 32 interleaved copies (entry v of copy j at word 32 v + j): lane l reads copy l % 32, i.e. always bank l % 32 -- a single
     // 1-KiB table made 69 % of this kernel's LDS cycles bank conflicts (random bytes of 32 lanes over 32 banks)
     __shared__ unsigned lut_all[256 * 32];
-    __shared__ __attribute__((aligned(16))) float tile_all[4][32 * 32];     // a wave's 32 x 32 tile of T on its way out (gq_tile_out)
     for (int e = threadIdx.x; e < 256 * 32; e += 256) lut_all[e] = (unsigned)spread4((unsigned)(e >> 5), 0);
     const unsigned* lut = lut_all + (lane & 31);
     __syncthreads();
 #if GPCA_ABLATE & 16
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut, tile_all[wv]);
+    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut);
     // the 1-3 units left over go in ONE more sweep over the samples (a wave with 31 units used to make two, of 2 and of 1 tile:
     // every sweep re-reads all of Q's planes and pays its prologue)
-    if (u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut, tile_all[wv]); u += 3; }
-    else if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut, tile_all[wv]); u += 2; }
-    else if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut, tile_all[wv]); u += 1; }
+    if (u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 3; }
+    else if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 2; }
+    else if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 1; }
     const float am = fmaxf(amax, __shfl_xor(amax, 32));
     if (h == 0) apart[wave * 32 + c] = (double)am;
 #if GPCA_ABLATE & 16
@@ -474,6 +480,50 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
     r.z = 0x7fffffff;
     r.w = GPCA_RSRC_FLAGS;
     return r;
+}
+
+// One tile of a K1 epilogue: T = r o (G Q) + b s^T from the exact digit-plane sums, the unit's share of c, the column abs-max, and
+// the tile on its way out through a wave-private 4 KiB of LDS so that it leaves as four 16-byte stores per lane (a lane's 16
+// elements are 16 different rows: written directly they are 16 dword stores with a 64-bit address each).  `rrow` / `brow` hold r
+// and b of row 32 t + c in lane c.  The sched_barrier keeps one tile's accumulators live at a time: without it hipcc read all 256
+// accumulators into VGPRs first, spilled the address arithmetic to scratch and waited (vmcnt(0)) on every reload behind the store it
+// had just issued -- one store round trip per element, ~19 us per round at any N (the per-round cost the shape sweep showed).
+template <int BITS, bool RB_LDS>
+__device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rrow, float brow, const float* rl, const float* bl,
+                                            double qs, float sj, int scale_out,
+                                            float* __restrict__ tile, float* __restrict__ Tout, int64_t ldt, int64_t unit,
+                                            float* __restrict__ cunit, float& amax, int lane_in) {
+    __builtin_amdgcn_sched_barrier(0);
+    // the lane id is made opaque here: everything derived from it (LDS offsets, cross-lane indices, store addresses) is then computed
+    // where it is used instead of being hoisted out of the round loop as ~40 loop-invariant registers that the stage loop's register
+    // pressure sent to scratch
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int c = lane & 31, h = lane >> 5;
+    float ct = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
+        // r and b of that row: from the wave's LDS staging (k_gq_d: DMA-ed at the start of the round, no compiler-visible load whose
+        // wait would drain the DMA queue), or from lane `rin` of registers loaded one row per lane
+        const float ri = RB_LDS ? rl[rin] : __shfl(rrow, rin), bi = RB_LDS ? bl[rin] : __shfl(brow, rin);
+        const float gq = (float)(combine_digits<BITS>(a, e) * qs);
+        const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+        ct = __fmaf_rn(bi, tv, ct);
+        const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
+        amax = fmaxf(amax, fabsf(ov));
+        tile[rin * 32 + c] = ov;
+    }
+    GPCA_STORE_CUNIT(unit)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (one wave's LDS operations execute in order: no barrier)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (lane >> 3) + 8 * i;
+        const float4 v = *reinterpret_cast<const float4*>(tile + rr * 32 + 4 * (lane & 7));
+        *reinterpret_cast<float4*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the tile is free again before the next one is written)
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // What a wave does in one round: R tiles starting at row unit `unit0`, `nv` of them real (nv = 0: the wave rides along on the round's

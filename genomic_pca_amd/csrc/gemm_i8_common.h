@@ -60,58 +60,5 @@ __device__ __forceinline__ int permb(int hi, int lo, unsigned sel) { return (int
 // the four k-contiguous operands of a 32-row block of G^T (sample byte t of rows 0..15 per lane half)
 struct Gtt2Ops { i32x4 bt[4]; };
 
-// One tile of a K1 epilogue: T = r o (G Q) + b s^T from the exact digit-plane sums, the unit's share of c, the column abs-max, and
-// the tile on its way out through a wave-private 4 KiB of LDS so that it leaves as four 16-byte stores per lane (a lane's 16
-// elements are 16 different rows: written directly they are 16 dword stores with a 64-bit address each).  `rrow` / `brow` hold r
-// and b of row 32 t + c in lane c.  The sched_barrier keeps one tile's accumulators live at a time: without it hipcc read all 256
-// accumulators into VGPRs first, spilled the address arithmetic to scratch and waited (vmcnt(0)) on every reload behind the store it
-// had just issued -- one store round trip per element, ~19 us per round at any N (the per-round cost the shape sweep showed).
-template <int BITS, bool RB_LDS, bool RELANE = false>
-__device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rrow, float brow, const float* rl, const float* bl,
-                                            double qs, float sj, int scale_out,
-                                            float* __restrict__ tile, float* __restrict__ Tout, int64_t ldt, int64_t unit,
-                                            float* __restrict__ cunit, float& amax, int lane_in) {
-    __builtin_amdgcn_sched_barrier(0);
-    // the lane id is made opaque here: everything derived from it (LDS offsets, cross-lane indices, store addresses) is then computed
-    // where it is used instead of being hoisted out of the round loop as ~40 loop-invariant registers that the stage loop's register
-    // pressure sent to scratch
-    // (RELANE: the lane id is recomputed from an opaque mask instead of being passed in -- in k_gq_2bit a register carried across the
-    //  sweep for it was spilled; in k_gq_d the passed-in form allocates better)
-    int lane = lane_in;
-    if constexpr (RELANE) {
-        unsigned all = ~0u;
-        asm volatile("" : "+s"(all));
-        lane = (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
-    } else {
-        asm volatile("" : "+v"(lane));
-    }
-    const int c = lane & 31, h = lane >> 5;
-    float ct = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
-        // r and b of that row: from the wave's LDS staging (k_gq_d: DMA-ed at the start of the round, no compiler-visible load whose
-        // wait would drain the DMA queue), or from lane `rin` of registers loaded one row per lane
-        const float ri = RB_LDS ? rl[rin] : __shfl(rrow, rin), bi = RB_LDS ? bl[rin] : __shfl(brow, rin);
-        const float gq = (float)(combine_digits<BITS>(a, e) * qs);
-        const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
-        ct = __fmaf_rn(bi, tv, ct);
-        const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
-        amax = fmaxf(amax, fabsf(ov));
-        tile[rin * 32 + c] = ov;
-    }
-    GPCA_STORE_CUNIT(unit)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (one wave's LDS operations execute in order: no barrier)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rr = (lane >> 3) + 8 * i;
-        const float4 v = *reinterpret_cast<const float4*>(tile + rr * 32 + 4 * (lane & 7));
-        *reinterpret_cast<float4*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the tile is free again before the next one is written)
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-
 }  // namespace gpca
 #endif
