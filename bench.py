@@ -672,11 +672,11 @@ def main():
         # bench lines of the other BASELINE.json configs, measured with this build by the scripts named in DESIGN.md (too large or too
         # long for the default run; each file holds one line in this same format)
         out["see_also"] = {k_: v_ for k_, v_ in {
-            "configs[2] chr22_subset50 shape, 1 066 557 x 64": "profiles/r2_config3_chr22_shape_1066557x64.json",
-            "configs[3] per-GPU shard, 1.25M x 100k int8": "profiles/r2_bench_c4shard_1.25Mx100k_int8.json",
+            "this command on one box this round: bench line, rocprofv3 --kernel-trace --stats, PMC passes, one call launch by launch": "profiles/r4a_summary.md",
+            "A/B and ablation evidence behind the round's kernel changes": "profiles/r4_kbench_summary.md",
             "10M x 100k on ONE GPU, 2-bit rows, exact path": "profiles/r2_bench_10Mx100k_2bit_one_gpu.json",
-            "north_star literal: 10M x 100k on ONE GPU, MFMA-fp32 path": "profiles/r2_northstar_10Mx100k_f32_mfma_2bit_one_gpu.json",
-            "configs[4] per-GPU shard streamed out of core, 6.25M x 500k, k = 40": "profiles/r2_stream_config5_6.25Mx500k_k40_2bit_cache.json",
+            "configs[2] end to end through the command line": "profiles/r2_cli_config3_end_to_end.json",
+            "host panel sources at link rate (32 GB matrix)": "profiles/r3_stream_host_link_rates_32GB.jsonl",
         }.items() if os.path.exists(os.path.join(ROOT, v_))}
         if extra_errors:
             out["extra_path_errors"] = extra_errors

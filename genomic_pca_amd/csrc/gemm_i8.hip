@@ -327,8 +327,8 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     }
 }
 
-template <int ND>
-__global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ G2, int64_t ld2, int64_t units, int64_t nsuper,
+template <int ND, int RMAX = 4>
+__global__ __launch_bounds__(256, RMAX == 4 ? 1 : 2) void k_gq_2bit(const uint8_t* __restrict__ G2, int64_t ld2, int64_t units, int64_t nsuper,
                                                      const int8_t* __restrict__ Qd, const double* __restrict__ qscale,
                                                      const float* __restrict__ rv, const float* __restrict__ bv,
                                                      const float* __restrict__ sv, float* __restrict__ Tout,
@@ -353,10 +353,13 @@ __global__ __launch_bounds__(256, 1) void k_gq_2bit(const uint8_t* __restrict__ 
 #if GPCA_ABLATE & 16
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut);
+    if constexpr (RMAX == 4)
+        for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut);
+    else        // (kbench experiment: two tiles per sweep, two waves per SIMD)
+        for (; u + 2 <= u_end; u += 2) gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut);
     // the 1-3 units left over go in ONE more sweep over the samples (a wave with 31 units used to make two, of 2 and of 1 tile:
     // every sweep re-reads all of Q's planes and pays its prologue)
-    if (u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 3; }
+    if (RMAX == 4 && u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 3; }
     else if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 2; }
     else if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 1; }
     const float am = fmaxf(amax, __shfl_xor(amax, 32));

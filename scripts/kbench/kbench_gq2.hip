@@ -56,6 +56,37 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&cp, (M / 32) * 32 * 4));   /* one c partial per 32-row unit (not per wave: the kernels write cunit[unit][32]) */ CK(hipMalloc(&ap, waves * 32 * 8));
     gpca::GqPlan plan{M / 32, waves};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    if (argc > 3 && argv[3][0] == 'o') {
+        // occupancy A/B (round 4), round-robin in one process: the product form (four tiles per sweep, one wave per SIMD, 1 024 waves)
+        // against two tiles per sweep with two waves per SIMD (2 048 waves), for both plane counts
+        struct V { const char* name; int nd, rmax, w; };
+        const V vs[] = {{"4 planes, 4 tiles/sweep, 1 wave/SIMD", 4, 4, 1024}, {"4 planes, 2 tiles/sweep, 2 waves/SIMD", 4, 2, 2048},
+                        {"3 planes, 4 tiles/sweep, 1 wave/SIMD", 3, 4, 1024}, {"3 planes, 2 tiles/sweep, 2 waves/SIMD", 3, 2, 2048}};
+        double sum[4] = {0, 0, 0, 0};
+        auto go = [&](const V& v) {
+            const dim3 grid((unsigned)(v.w / 4)), blk(256);
+            const int64_t nsuper = Npad / 512;
+            if (v.nd == 4 && v.rmax == 4) hipLaunchKernelGGL((gpca::k_gq_2bit<4, 4>), grid, blk, 0, 0, G2, ld2, M / 32, nsuper, Qd, qs, r, b, s, T, cp, ap, 1, (int64_t)32);
+            else if (v.nd == 4) hipLaunchKernelGGL((gpca::k_gq_2bit<4, 2>), grid, blk, 0, 0, G2, ld2, M / 32, nsuper, Qd, qs, r, b, s, T, cp, ap, 1, (int64_t)32);
+            else if (v.rmax == 4) hipLaunchKernelGGL((gpca::k_gq_2bit<3, 4>), grid, blk, 0, 0, G2, ld2, M / 32, nsuper, Qd, qs, r, b, s, T, cp, ap, 1, (int64_t)32);
+            else hipLaunchKernelGGL((gpca::k_gq_2bit<3, 2>), grid, blk, 0, 0, G2, ld2, M / 32, nsuper, Qd, qs, r, b, s, T, cp, ap, 1, (int64_t)32);
+        };
+        double* ap2; CK(hipMalloc(&ap2, 2048 * 32 * 8)); ap = ap2;
+        for (int it = 0; it < 10; ++it) go(vs[0]);
+        CK(hipDeviceSynchronize());
+        const int reps = 4;
+        for (int rep = 0; rep < reps; ++rep)
+            for (int v = 0; v < 4; ++v) {
+                go(vs[v]);
+                hipEventRecord(e0);
+                for (int it = 0; it < 10; ++it) go(vs[v]);
+                hipEventRecord(e1); CK(hipEventSynchronize(e1));
+                float t; hipEventElapsedTime(&t, e0, e1); sum[v] += t / 10;
+            }
+        printf("k_gq_2bit %lld x %lld, %s operands, %d x 10 launches per variant, round-robin\n", (long long)M, (long long)N, real ? "real-like" : "random", reps);
+        for (int v = 0; v < 4; ++v) printf("  %-42s %.4f ms\n", vs[v].name, sum[v] / reps);
+        return 0;
+    }
     for (int it = 0; it < 2; ++it) gpca::launch_gq_2bit(0, G2, ld2, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1);
     CK(hipDeviceSynchronize());
     hipEventRecord(e0);
