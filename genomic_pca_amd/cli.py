@@ -67,6 +67,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="EigenSNP workflow: walk the .bed out of core through a ring of HBM panels instead of holding it resident "
                         "(auto = when the resident load runs out of device memory; needs --gpca-precision i8)")
     p.add_argument("--gpca-panel-rows", type=int, default=0, help="--gpca-stream: SNP rows per panel (0 = engine default)")
+    p.add_argument("--gpca-rfit-power-iters", type=int, default=2,
+                   help="VCF workflow: power iterations of the randomized PCA (PCA::rfit's own count is fixed inside the un-vendored "
+                        "efficient_pca crate and unknown; 2 = the EigenSNP default, main.rs:318; 4 puts the PCs within 2e-6 of exact PCA)")
     p.add_argument("--gpca-eigensnp-local-stage", action="store_true",
                    help="EigenSNP workflow: run the multi-stage algorithm the --eigensnp-* local / refine flags parameterise (per-block "
                         "local bases on a sample subset, condensed features, global PCA, refinement) instead of one global randomized "
@@ -118,7 +121,7 @@ def run_vcf_workflow(a) -> int:
         raise SystemExit("No variants available to build matrix.")                  # vcf.rs:321-323
     prec, store = _engine_modes(a)
     model = PCA(device=a.device, precision=prec, storage=store)
-    model.rfit(G.T, a.components, 10, a.rfit_seed, None)                            # main.rs:636-656 (x = samples x variants)
+    model.rfit(G.T, a.components, 10, a.rfit_seed, None, power_iters=a.gpca_rfit_power_iters)                            # main.rs:636-656 (x = samples x variants)
     pcs = model.transform()
     _ensure_parent(a.output_prefix)
     gio.write_principal_components(a.output_prefix, "vcf.pca.tsv", samples, pcs)    # main.rs:231

@@ -321,7 +321,7 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
             ct = __fmaf_rn(bi, tv, ct);
             const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
             amax = fmaxf(amax, fabsf(ov));
-            Tout[row * ldt + c] = ov;
+            Tout[row * ldt + c] = ov;      // (a streaming store measured the same here: the packed kernel is bound by its decode, not by HBM)
         }
         GPCA_STORE_CUNIT(row0 / 32 + t)
     }
@@ -424,8 +424,11 @@ constexpr int kGqdSlots = 6;
 __device__ unsigned long long g_gqd_stamp[1024 * 64];     // [workgroup][slot]: 0 = start, 1 + 2 r = stage loop of round r done, 2 + 2 r = its epilogue done
 __device__ int g_gqd_stamp_n;
 #define GQD_STAMP(SLOT) { if (threadIdx.x == 0 && blockIdx.x < 1024 && (SLOT) < 64) g_gqd_stamp[blockIdx.x * 64 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); }
+__device__ unsigned long long g_gqd_stage_stamp[256 * 3 * 128];     // [workgroup][round < 3][stage < 128]: start of every stage (GPCA_STAMP=2)
+#define GQD_STAGE_STAMP(RND, ST) { if (GPCA_STAMP == 2 && threadIdx.x == 0 && blockIdx.x < 256 && (RND) < 3 && (ST) < 128) g_gqd_stage_stamp[(blockIdx.x * 3 + (RND)) * 128 + (ST)] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define GQD_STAMP(SLOT)
+#define GQD_STAGE_STAMP(RND, ST)
 #endif
 // plane batches younger than the fill of unit m + 1 while unit m (tile t = m mod R) is consumed, steady state (m >= 4)
 constexpr int gqd_q_young(int R, int t) {
@@ -523,7 +526,16 @@ __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rr
     for (int i = 0; i < 4; ++i) {
         const int rr = (lane >> 3) + 8 * i;
         const float4 v = *reinterpret_cast<const float4*>(tile + rr * 32 + 4 * (lane & 7));
+#ifndef GPCA_T_TEMPORAL
+        // streaming store: written through instead of left dirty in L2 for the next round's genotype reads to evict one line at a
+        // time -- that write-back, interleaved with the reads, made the first ten stages of every round ~25 % slower
+        // (stage stamps, profiles/r4_kbench_summary.md); k_gq_d 1.563 -> 1.550 ms at 1M x 10k
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v vv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)));
+#else
         *reinterpret_cast<float4*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)) = v;
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the tile is free again before the next one is written)
     __builtin_amdgcn_sched_barrier(0);
@@ -650,6 +662,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
         else if constexpr (R == 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
         else if constexpr (R == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        GQD_STAGE_STAMP(round_ix, st)
         GQD_ISSUE_Q(st + 1 < nstage ? st + 1 : 0, (int)((st + 1) & 1))
         i32x4 q[4][kDigits];
 #pragma unroll

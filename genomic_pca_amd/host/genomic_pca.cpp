@@ -33,7 +33,7 @@ struct Args {
     // clap's effective defaults when --eigensnp is given (main.rs:545-588)
     double min_call_rate = 0.98, min_maf = 0.01, max_hwe_p = 1e-6, subset_factor = 0.075;
     int64_t k_global = 10, components_per_block = 7, min_subset = 10000, max_subset = 40000, global_oversampling = 10, global_power_iter = 2,
-            local_oversampling = 10, local_power_iter = 2, strip_size = 2000, refine_passes = 1;
+            local_oversampling = 10, local_power_iter = 2, strip_size = 2000, refine_passes = 1, rfit_power_iters = 2;
     uint64_t seed = 2025;
     // extensions
     int device = -1;
@@ -87,6 +87,7 @@ void print_help() {
         "      --gpca-storage <auto|int8|2bit>  HBM residency of the genotypes (auto = 2bit for a .bed of >= 1024 samples, else int8)\n"
         "      --gpca-stream <auto|on|off>      walk the .bed out of core (auto = when it does not fit the device)\n"
         "      --gpca-panel-rows <N>            SNP rows per panel for --gpca-stream (0 = engine default)\n"
+        "      --gpca-rfit-power-iters <N>      VCF workflow: power iterations of the randomized PCA [default: 2]\n"
         "      --gpca-eigensnp-local-stage      run the multi-stage algorithm of the --eigensnp-* local / refine flags instead of\n"
         "                                       one global randomized PCA over all blocks (the default)\n"
         "  -h, --help                           Print help");
@@ -150,6 +151,7 @@ Args parse(int argc, char** argv) {
         else if (f == "--gpca-storage") { a.storage = val(); if (a.storage != "auto" && a.storage != "int8" && a.storage != "2bit") usage_error("invalid value '" + a.storage + "' for '--gpca-storage' (auto, int8, 2bit)"); }
         else if (f == "--gpca-stream") { a.stream = val(); if (a.stream != "auto" && a.stream != "on" && a.stream != "off") usage_error("invalid value '" + a.stream + "' for '--gpca-stream' (auto, on, off)"); }
         else if (f == "--gpca-panel-rows") a.panel_rows = to_i64(f, val());
+        else if (f == "--gpca-rfit-power-iters") a.rfit_power_iters = to_i64(f, val());
         else if (f == "--gpca-eigensnp-local-stage") a.local_stage = true;
         else usage_error("unexpected argument '" + f + "' found");
     }
@@ -196,7 +198,7 @@ int run_vcf_workflow(Args a) {
     logmsg(buf);
     if (n_variants == 0) { std::fprintf(stderr, "No variants available to build matrix.\n"); return 1; }              // vcf.rs:321-323
     gpca::PCA model(a.device, engine_precision(a), engine_storage(a));
-    model.rfit(v.dosages.data(), n_variants, n_samples, (int)a.components, 10, a.have_seed ? a.rfit_seed : 0);          // main.rs:636-656
+    model.rfit(v.dosages.data(), n_variants, n_samples, (int)a.components, 10, a.have_seed ? a.rfit_seed : 0, (int)a.rfit_power_iters);          // main.rs:636-656
     const std::vector<double> pcs = model.transform();
     gpca_host::ensure_parent(a.output_prefix);
     gpca_host::write_principal_components(a.output_prefix, "vcf.pca.tsv", v.samples, pcs.data(), n_samples, model.components());   // main.rs:231

@@ -111,6 +111,23 @@ int main(int argc, char** argv) {
         for (int x = 0; x < 8; ++x) printf("  %d: %.0f / %.0f / %.0f", x, sum[x] / cnt[x], mn[x], mx[x]);
         printf("\n");
     }
+#if GPCA_STAMP == 2
+    {   // stage by stage: median over the workgroups of the time between consecutive stage starts, rounds 0-2
+        std::vector<unsigned long long> ss(256 * 3 * 128);
+        CK(hipMemcpyFromSymbol(ss.data(), HIP_SYMBOL(gpca::g_gqd_stage_stamp), ss.size() * 8));
+        const int ns = (int)std::min<int64_t>(Npad / 128, 128);
+        for (int rd = 0; rd < 3 && rd < nr; ++rd) {
+            printf("  round %d, median stage duration (us) by stage:", rd);
+            for (int st = 0; st + 1 < ns; ++st) {
+                std::vector<double> d;
+                for (int w = 0; w < nb; ++w) d.push_back((ss[(w * 3 + rd) * 128 + st + 1] - ss[(w * 3 + rd) * 128 + st]) * 0.01);
+                std::sort(d.begin(), d.end());
+                if (st < 12 || st % 8 == 0 || st + 2 >= ns) printf(" %d:%.2f", st, d[nb / 2]);
+            }
+            printf("\n");
+        }
+    }
+#endif
     const int brief = argc > 5 ? atoi(argv[5]) : 0;
     for (int rd = 0; rd < nr && rd < 31; ++rd) {
         if (brief && rd != 1 && rd != nr - 1) continue;

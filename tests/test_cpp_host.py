@@ -327,7 +327,8 @@ def test_cpp_vcf_workflow_equals_python_cli(tmp_path, host_bin, gpca, oracle):
                 f.write(f"{ci + 1}\t{i + 1}\t.\tA\tC\t.\t.\t.\tGT:DP\t" + "\t".join(gt[int(v)] + ":5" for v in G[i]) + "\n")
     # (-k 38 with 48 samples: the reference clamps k to min(samples, variants) and adds 10 -- a 48-column sketch; -k 60 asks for more
     #  components than there are samples: clamped to 48, the oversampling to what is left)
-    for kk, extra in (("4", []), ("4", ["--write-eigenvalues"]), ("38", ["--write-eigenvalues"]), ("60", ["--write-eigenvalues"])):
+    for kk, extra in (("4", []), ("4", ["--write-eigenvalues"]), ("38", ["--write-eigenvalues"]), ("60", ["--write-eigenvalues"]),
+                      ("4", ["--write-eigenvalues", "--gpca-rfit-power-iters", "4"])):
         out_c, out_p = str(tmp_path / "c" / "v"), str(tmp_path / "p" / "v")
         common = ["--vcf-dir", str(d), "-k", kk, "--maf", "0.05", "--rfit-seed", "3"] + extra
         r = subprocess.run([host_bin, "--out", out_c] + common, capture_output=True, text=True, timeout=300)
