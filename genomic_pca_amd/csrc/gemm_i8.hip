@@ -187,6 +187,8 @@ Gtt8Plan gtt8_plan_batched(int64_t Mpad, int64_t Npad, int target_waves) {
 // 0.25 B per genotype; the kernels become matrix-core / VALU bound.
 // ================================================================================================
 
+template <int NT> __device__ __forceinline__ void gqd_dma(uint32_t lds_addr, uint32_t voff, i32x4 rsrc, uint32_t soff);   // (defined with k_gq_d below)
+__device__ __forceinline__ i32x4 gqd_rsrc(const void* p);
 #ifndef GPCA_ABLATE
 #define GPCA_ABLATE 0   // scripts/kbench/kbench_gq2.hip: bit0 no decode, bit1 no Q loads, bit2 no G loads, bit3 no MFMA,
 #endif                  // bit4 clock stamps (s_memtime / s_memrealtime per workgroup into g_kbench_stamp)
@@ -285,9 +287,22 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     // One phase = one MFMA step: prefetch the digit planes 3 steps ahead; the R x 4 int8 MFMAs of this step (matrix
     // pipe) and the bit-spreading of the NEXT step's operands (VALU, 5 ops per dword) sit in one scheduling region so
     // that they interleave.  Operand sets alternate opA / opB.
+#if GPCA_ABLATE & 32
+    // upper bound of sharing the planes through LDS (timing only, nothing synchronised): each wave brings ONE plane of the step into
+    // a ring by LDS-DMA and reads all ND back with ds_read_b128
+    __shared__ i32x4 abl_qring[4][kDigits][64];
+    const int abl_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i32x4 abl_rsrc = gqd_rsrc(Qd);
+#define GQ2_ABL_SHARED(QN, NST) \
+    if (abl_wv < ND) gqd_dma<0>((uint32_t)(uintptr_t)&abl_qring[(NST) & 3u][abl_wv][0], qvo, abl_rsrc, ((NST) < nsteps ? (NST) : 0u) * QCH + abl_wv * 1024u); \
+    _Pragma("unroll") for (int d_ = 0; d_ < ND; ++d_) QN.q[d_] = abl_qring[(NST) & 3u][d_][lane];
+#else
+#define GQ2_ABL_SHARED(QN, NST)
+#endif
 #define GQ2_PHASE(OPCUR, OPNXT, GNXT, BN, SN, QCUR, QNEXT, STEP)                            \
     { const uint32_t nst_ = (STEP) + 3u;                                                     \
-      if (!(GPCA_ABLATE & 2)) gq8_load_q<ND>(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }  \
+      if (GPCA_ABLATE & 32) { GQ2_ABL_SHARED(QNEXT, nst_) }                                    \
+      else if (!(GPCA_ABLATE & 2)) gq8_load_q<ND>(QNEXT, rq, qvo, (nst_ < nsteps ? nst_ : 0u) * QCH); }  \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     gq2_mfma_decode<R, SN, ND>(OPCUR, QCUR, acc, GNXT.g[BN], OPNXT, lut);                        \
     __builtin_amdgcn_sched_barrier(0);
@@ -309,6 +324,7 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
     }
 #undef GQ2_BLOCK
 #undef GQ2_PHASE
+#undef GQ2_ABL_SHARED
 #pragma unroll
     for (int t = 0; t < R; ++t) {
         float ct = 0.f;     // this tile's share of c = b^T T: one partial per 32-row unit, so c does not depend on the grid partition
