@@ -353,7 +353,7 @@ def test_errors_and_state(gpca, engine):
     with pytest.raises(gpca.GpcaError):
         engine.rsvd(0)                            # main.rs:607-609
     with pytest.raises(gpca.GpcaError):
-        engine.rsvd(60, 10)                       # l > 64
+        engine.rsvd(60, 10)                       # l > 64 on the f32 path (and l > N)
     with pytest.raises(gpca.GpcaError):
         engine.rsvd(35, 10)                       # l > N
     with pytest.raises(ValueError):

@@ -729,7 +729,7 @@ def test_no_device_memory_is_lost_across_handles_and_modes(gpca, oracle):
                 e.stream_set_cache(-1 if rep % 4 else 2 << 20)
                 e.snp_stats(); e.rsvd(5, 10, 2, seed=1)
                 with pytest.raises(gpca.GpcaError):
-                    e.rsvd(80, 10, 2, seed=1)                     # l > 64: an error path between two good calls
+                    e.rsvd(125, 10, 2, seed=1)                    # l > 128: an error path between two good calls
                 e.upload_genotypes_i8(G[:500])                    # closes the stream, frees ring and cache
                 e.snp_stats(); e.rsvd(3, 5, 1, seed=2)
         free1, total = probe.device_memory()
