@@ -864,27 +864,14 @@ void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax
 
 // CholeskyQR's small factorisation on the device: W (n x n, pitch NN, upper triangle used) = R^T R, Z = R^-1 (upper,
 // zero elsewhere, the whole NN x NN block written), so that no host round trip (and no stream sync) sits between the
-// Gram matrix and the right-multiplication.  ONE WAVE, everything in registers: lane c owns column c of R and of R^-1;
-// an element of another column is fetched with v_readlane (compile-time lane after full unrolling), so there is no
-// LDS traffic and no barrier -- a 1024-thread LDS version spent 50 us on its ~180 barriers and dependent LDS reads.
+// Gram matrix and the right-multiplication.  ONE WAVE, the matrix in registers: lane c owns column c of R and of R^-1.
 //   * Cholesky, right-looking: step j scales row j by 1/sqrt(pivot) and subtracts its outer product from the trailing
 //     rows (each element sees the same subtractions, in the same order, as a row-by-row Cholesky-Crout).
 //   * R^-1: lane c back-substitutes R x = e_c from the bottom row up; x[k] = 0 for k > c falls out by itself.
 // Rows / columns n..NN-1 are treated as identity.  A pivot that is not finite records (j + 1) in *flag (first failure wins)
 // and the factorisation carries on with pivot 1, so nothing downstream spins or faults; the caller checks the flag
-// once, at the end of the rSVD.  A pivot that is zero to rounding drops its column from the basis (see CholStep).
-// (volatile asm tied to the accumulator it feeds: left to itself the scheduler hoists all ~1000 broadcasts ahead of
-//  the FMAs that consume them and then spills ~1400 SGPRs through v_writelane)
+// once, at the end of the rSVD.  A pivot that is zero to rounding drops its column from the basis (see the step below).
 constexpr double kCholRankTol = 1e-13;   // relative to the column's own squared norm (Gram rounding is ~32 x 2.2e-16)
-template <int LANE>
-__device__ __forceinline__ double lane_bcast(double v, double& dep) {
-    int lo, hi;
-    // the compiler's hazard recogniser does not look inside the string: the wait states a VALU-written VGPR needs before
-    // v_readlane reads it, and a VALU-written SGPR needs before a VALU reads it as an operand, are supplied here
-    asm volatile("s_nop 1\n\tv_readlane_b32 %0, %3, %5\n\tv_readlane_b32 %1, %4, %5\n\ts_nop 1"
-                 : "=s"(lo), "=s"(hi), "+v"(dep) : "v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(LANE));
-    return __hiloint2double(hi, lo);
-}
 // 1 / sqrt(x) in f64 from the hardware estimate and two Newton steps (the correctly rounded sqrt + divide pair costs
 // ~500 dependent cycles per pivot; this chain ~100)
 __device__ __forceinline__ double rsqrt_nr(double x) {
@@ -893,55 +880,25 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     y = y * (1.5 - 0.5 * x * y * y);
     return y;
 }
-template <int NN, int J, int R>
-struct CholRow {   // col[r] -= R[j][r] * R[j][c] for r = R .. NN-1 (compile-time lanes)
-    static __device__ __forceinline__ void run(double (&col)[NN]) {
-        if constexpr (R < NN) { const double a = lane_bcast<R>(col[J], col[R]); col[R] -= a * col[J]; CholRow<NN, J, R + 1>::run(col); }
-    }
-};
-template <int NN, int J>
-struct CholStep {
-    static __device__ __forceinline__ void run(double (&col)[NN], double (&dinv)[NN], double& diag0, int c, int* flag) {
-        if constexpr (J < NN) {
-            double piv = lane_bcast<J>(col[J], col[J]);
-            const double d0 = lane_bcast<J>(diag0, diag0);          // column J's own squared norm before the elimination
-            if (!isfinite(piv) || !isfinite(d0)) {
-                if (c == 0) atomicCAS(flag, 0, J + 1);
-                piv = 1.0;
-            }
-            // Column J lies in the span of the columns before it (what is left of its squared norm is rounding noise, possibly
-            // negative): a sketch wider than the rank of the matrix -- k + oversample = N samples of centred rows have rank N - 1.
-            // The column leaves the basis: row J of R and of R^-1 become zero, so Q's column J is zero and every later product
-            // carries a zero column (zero singular value) instead of the call failing.
-            const bool dependent = !(piv > kCholRankTol * d0);
-            dinv[J] = dependent ? 0.0 : rsqrt_nr(piv);
-            col[J] = (c == J) ? piv * dinv[J] : col[J] * dinv[J];
-            CholRow<NN, J, J + 1>::run(col);
-            CholStep<NN, J + 1>::run(col, dinv, diag0, c, flag);
-        }
-    }
-};
-template <int NN, int I, int K>
-struct InvRow {
-    static __device__ __forceinline__ void run(const double (&col)[NN], const double (&x)[NN], double& acc) {
-        if constexpr (K < NN) { const double a = lane_bcast<K>(col[I], acc); acc -= a * x[K]; InvRow<NN, I, K + 1>::run(col, x, acc); }
-    }
-};
-template <int NN, int I>
-struct InvStep {
-    static __device__ __forceinline__ void run(const double (&col)[NN], double (&x)[NN], const double (&dinv)[NN], int c) {
-        if constexpr (I >= 0) {
-            double acc = (c == I) ? 1.0 : 0.0;
-            InvRow<NN, I, I + 1>::run(col, x, acc);
-            x[I] = acc * dinv[I];
-            InvStep<NN, I - 1>::run(col, x, dinv, c);
-        }
-    }
-};
+// How an element of another column reaches a lane.  Rounds 1-3: one v_readlane pair per element (~1 000 of them for NN = 32, each
+// with its hazard nops) -- 24 us.  Round 4: a finished row of R is broadcast through LDS: step j writes its scaled row once
+// (ds_write_b64, lane c -> rs[j][c]) and every lane reads the entries it needs back from a wave-uniform address (a broadcast read,
+// no bank conflict), one batch of wide reads per step; the back substitution reads the same rows again.  Same operations on the
+// same values in the same order, so the bits do not change (scripts/fingerprint.py before / after) -- 17 us (the chain of a
+// step: pivot, 1/sqrt by Newton, the row through LDS, 31 - j dependent-free FMAs; what is left is one wave's f64 latency).
+// The asm pins keep a step's FMAs in the step: left free, the scheduler sinks them behind the last row's reads with every row live.
+// (Dropped after measurement: the whole matrix in LDS (round 3, 100 us); the fold of the Gram partials ahead of the factorisation
+//  (round 3, 45 us against 5 + 23); Gram + fold + factorisation in one launch, the last workgroup to finish doing the small work
+//  (round 4: 58 us against 12.5 + 4.7 + 17 -- one CU folds 63 partials of 8 KiB more slowly than 16 do).)
+__device__ __forceinline__ double bcast_lane(double v, int lane) {      // lane: a constant once the loop around the call is unrolled
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// One wave (lanes c = 0..63); Wg may be global or LDS; rs = NN x NN doubles of LDS (rs[j][c] = R[j][c], row j final after step j).
+// wave_sync(): orders this wave's LDS write of a row before its reads of it (one wave's LDS operations execute in order: the
+// compiler's fence and wait, no barrier needed -- a block-wide barrier would also hang the fused caller, whose other waves have left).
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 template <int NN>
-__global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, int n, double* __restrict__ Zg,
-                                                 int* __restrict__ flag) {
-    const int c = threadIdx.x;
+__device__ __forceinline__ void chol_inv_wave(const double* Wg, int n, double* __restrict__ Zg, int* __restrict__ flag, double* rs, int c) {
     double col[NN], x[NN], dinv[NN];
 #pragma unroll
     for (int r = 0; r < NN; ++r) col[r] = Wg[r * NN + (c & (NN - 1))];      // (unconditional: the loads stay in flight together)
@@ -950,17 +907,54 @@ __global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, 
     double diag0 = 0.0;
 #pragma unroll
     for (int r = 0; r < NN; ++r) diag0 = (r == c) ? col[r] : diag0;
-    CholStep<NN, 0>::run(col, dinv, diag0, c, flag);
-    InvStep<NN, NN - 1>::run(col, x, dinv, c);
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        __builtin_amdgcn_sched_barrier(0);      // (a step's row reads stay in the step: hoisted, they fill the register file and spill)
+        // pivot = R[j][j] so far (lane j's col[j]); d0 = column j's own squared norm before the elimination
+        double piv = bcast_lane(col[j], j);
+        const double d0 = bcast_lane(diag0, j);
+        if (!isfinite(piv) || !isfinite(d0)) {
+            if (c == 0) atomicCAS(flag, 0, j + 1);
+            piv = 1.0;
+        }
+        // Column j lies in the span of the columns before it (what is left of its squared norm is rounding noise, possibly
+        // negative): a sketch wider than the rank of the matrix -- k + oversample = N samples of centred rows have rank N - 1.
+        // The column leaves the basis: row j of R and of R^-1 become zero, so Q's column j is zero and every later product
+        // carries a zero column (zero singular value) instead of the call failing.
+        const bool dependent = !(piv > kCholRankTol * d0);
+        dinv[j] = dependent ? 0.0 : rsqrt_nr(piv);
+        col[j] = (c == j) ? piv * dinv[j] : col[j] * dinv[j];
+        if (c < NN) rs[j * NN + c] = col[j];
+        wave_lds_sync();
+        double row[NN];                         // the row, read in one batch of wide LDS reads ahead of the FMAs
+#pragma unroll
+        for (int r = j + 1; r < NN; ++r) row[r] = rs[j * NN + r];
+#pragma unroll
+        for (int r = j + 1; r < NN; ++r) asm volatile("" : "+v"(row[r]));
+#pragma unroll
+        for (int r = j + 1; r < NN; ++r) { col[r] -= row[r] * col[j]; asm volatile("" : "+v"(col[r])); }   // (pinned to its step, as x[i] below)
+    }
+    // R^-1: lane c back-substitutes R x = e_c from the bottom row up
+#pragma unroll
+    for (int i = NN - 1; i >= 0; --i) {
+        __builtin_amdgcn_sched_barrier(0);
+        double acc = (c == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = i + 1; k < NN; ++k) acc -= rs[i * NN + k] * x[k];
+        x[i] = acc * dinv[i];
+        asm volatile("" : "+v"(x[i]));          // (the step's FMAs stay in the step: left free they all sink behind the last row's reads, every row live)
+    }
     if (c < NN) {
 #pragma unroll
         for (int i = 0; i < NN; ++i) Zg[i * NN + c] = (i < n && c < n) ? x[i] : 0.0;
     }
 }
-// (Two variants of this kernel were built and measured in round 3, and dropped: the matrix kept in LDS with rows of R broadcast by
-//  ds_read instead of v_readlane -- 100-110 us against 25, every element update became a read-modify-write through LDS behind a
-//  wavefront fence -- and the sum over the Gram partials folded in ahead of the register factorisation -- 45-49 us against 5 + 23:
-//  one workgroup adds 63 slices more slowly than the 16 workgroups of k_sum_partials.)
+template <int NN>
+__global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, int n, double* __restrict__ Zg,
+                                                 int* __restrict__ flag) {
+    __shared__ double rs[NN * NN];
+    chol_inv_wave<NN>(Wg, n, Zg, flag, rs, (int)threadIdx.x);
+}
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
     if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
     else if (ld == 64) hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
@@ -1123,19 +1117,23 @@ void launch_colsum_f64(hipStream_t st, const double* X, int64_t rows, int L, dou
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)colsum_num_parts(rows)), dim3(256), 0, st, X, rows, L, part);
 }
 
-// sign of the first element with maximal |x| per column; one block per column
-__global__ __launch_bounds__(256) void k_col_sign(const double* __restrict__ X, int64_t rows, int K, int* __restrict__ sign) {
-    __shared__ double bv[256];
-    __shared__ long long bi[256];
+// sign of the first element with maximal |x| per column; one block per column.  1 024 threads and four independent loads per trip:
+// the 256-thread form walked 10 000 rows in 39 dependent round trips to L2 (17 us for 10 columns)
+__global__ __launch_bounds__(1024) void k_col_sign(const double* __restrict__ X, int64_t rows, int K, int* __restrict__ sign) {
+    __shared__ double bv[1024];
+    __shared__ long long bi[1024];
     const int col = blockIdx.x;
     double best = -1.0; long long idx = -1;
-    for (int64_t n = threadIdx.x; n < rows; n += 256) {
-        const double a = fabs(X[n * K + col]);
-        if (a > best) { best = a; idx = n; }
+    for (int64_t n0 = threadIdx.x; n0 < rows; n0 += 4096) {
+        double a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t n = n0 + 1024 * u; a[u] = n < rows ? fabs(X[n * K + col]) : -1.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (a[u] > best) { best = a[u]; idx = n0 + 1024 * u; }      // (ascending rows: the first maximum stays)
     }
     bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             const double ob = bv[threadIdx.x + s]; const long long oi = bi[threadIdx.x + s];
             if (ob > bv[threadIdx.x] || (ob == bv[threadIdx.x] && oi >= 0 && (bi[threadIdx.x] < 0 || oi < bi[threadIdx.x]))) {
@@ -1147,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_col_sign(const double* __restrict__ X, 
     if (threadIdx.x == 0) sign[col] = (bi[0] >= 0 && X[bi[0] * K + col] < 0.0) ? -1 : 1;
 }
 void launch_col_sign(hipStream_t st, const double* X, int64_t rows, int K, int* sign) {
-    hipLaunchKernelGGL(k_col_sign, dim3(K), dim3(256), 0, st, X, rows, K, sign);
+    hipLaunchKernelGGL(k_col_sign, dim3(K), dim3(1024), 0, st, X, rows, K, sign);
 }
 __global__ void k_scale_cols(double* X64, float* X32, int64_t rows, int K, const int* sign) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;

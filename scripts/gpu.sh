@@ -6,6 +6,7 @@
 #   smoke                            __graft_entry__.smoke()                      -> gpurun_out/smoke_<tag>.log
 #   bench[=<bench.py arguments>]     python bench.py ...                          -> gpurun_out/bench_<tag>[_n].json
 #   profile                          scripts/gpu_profile.sh <tag>: bench + rocprofv3 stats + PMC passes -> profiles/<tag>_*
+#   trace                            rocprofv3 --kernel-trace of a short headline run, one call launch by launch -> gpurun_out/timeline_<tag>.md
 #   timeline                         scripts/call_timeline.py <tag>               -> profiles/<tag>_call_timeline.md
 #   ab=<ENV=a>,<ENV=b>[,reps]        scripts/ab_env.py, both orders               -> gpurun_out/ab_<tag>.log
 #   kbench=<name>[,args]             hipcc scripts/kbench/<name>.hip and run it   -> gpurun_out/kbench_<name>_<tag>.log
@@ -35,6 +36,10 @@ for step in "$@"; do
       rc=$?; if [ $rc -ne 0 ]; then tail -8 $out.err; exit $rc; fi
       python scripts/bench_brief.py $out.json ;;
     profile) bash scripts/gpu_profile.sh $tag || exit 1 ;;
+    trace)      # kernel trace of a short headline run + the launch-by-launch table of one call   -> gpurun_out/timeline_<tag>.md
+      ( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_$tag -- python bench.py --steps 14 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/trace_$tag.log 2>&1 ) || { tail -5 gpurun_out/trace_$tag.log; exit 1; }
+      csv=$(find gpurun_out/trace_$tag -name '*kernel_trace.csv' | head -1)
+      python scripts/call_timeline.py $csv 10 > gpurun_out/timeline_$tag.md; tail -75 gpurun_out/timeline_$tag.md; rm -rf gpurun_out/trace_$tag ;;
     timeline) timeout -k 10 300 python scripts/call_timeline.py $tag || exit 1 ;;
     ab)
       IFS=, read -r a b reps <<< "$arg"; reps=${reps:-8}
