@@ -13,7 +13,20 @@ __device__ __forceinline__ double reduce_slices(const double* __restrict__ Ypart
         e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         live = e < total;
         double s = 0.0;
-        if (live) for (int w = 0; w < W; ++w) s += Ypart[w * stride + e];
+        if (live) {
+            // eight loads in flight per thread (the sums are integers: any order gives the same bits).  K2 writes its partial tiles with
+            // streaming stores, so this read comes from HBM, not from L2 / MALL: latency, not the adds, is what a thread waits for
+            const double* p = Ypart + e;
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int w = 0;
+            for (; w + 8 <= W; w += 8) {
+                const double v0 = p[(w + 0) * stride], v1 = p[(w + 1) * stride], v2 = p[(w + 2) * stride], v3 = p[(w + 3) * stride];
+                const double v4 = p[(w + 4) * stride], v5 = p[(w + 5) * stride], v6 = p[(w + 6) * stride], v7 = p[(w + 7) * stride];
+                s += v0; s1 += v1; s2 += v2; s3 += v3; s += v4; s1 += v5; s2 += v6; s3 += v7;
+            }
+            for (; w < W; ++w) s += p[w * stride];
+            s = (s + s1) + (s2 + s3);
+        }
         return s;
     }
     __shared__ double part[256];

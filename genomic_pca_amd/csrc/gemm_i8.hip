@@ -962,12 +962,55 @@ struct GtdTask { const uint8_t* gp; const int8_t* tp; int64_t kblocks; int64_t n
 // hoisted out of the task loop into registers that the stage loop's pressure sends to scratch (their reloads carried vmcnt(0) waits
 // that drained the DMA queue at every task boundary).
 template <int BITS>
-__device__ __forceinline__ void gtt_tiles_out(const i32x16 (&acc)[4][kDigits], double* __restrict__ Ypart, int64_t slice, int64_t Npad, int64_t n0) {
+__device__ __forceinline__ void gtt_tiles_out(const i32x16 (&acc)[4][kDigits], double* __restrict__ Ypart, int64_t slice, int64_t Npad, int64_t n0,
+                                              char* stage = nullptr) {
     __builtin_amdgcn_sched_barrier(0);
     unsigned all = ~0u;
     asm volatile("" : "+s"(all));                     // (opaque mask: the lane id is recomputed HERE -- hoisted out of the task loop it would be kept across the stage loop, i.e. spilled)
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
     const int c = lane & 31, h = lane >> 5;
+#ifndef GPCA_YPART_DIRECT
+    if (stage) {
+        // The wave's tile of Y^T is one contiguous 32 KiB of Ypart (128 samples x 32 doubles), but a lane holds 16-byte pieces of it 1 KiB
+        // apart: written directly, each store instruction touches 64 lines with 16 bytes each (2 048 partial-line writes per tile;
+        // the stores were worth 2.3 % of a launch for 1.3 % of its bytes).  Through a wave-private 4 KiB of LDS a store instruction
+        // writes 8 full 128-byte lines: per (sample t of the lane's four, half of the row) lane (c, h) parks its 8 doubles in line c
+        // (16-byte chunks XOR-swizzled by c), lane L takes chunk L & 7 of lines L >> 3 (+ 8, 16, 24) back and stores it -- as a
+        // STREAMING store: the same full lines written with plain stores measured no gain at all (1.5245 against 1.5246 ms direct);
+        // what costs is the dirty tile evicted from L2 between the genotype reads, as in K1.  1M x 10k: 1.525 -> 1.498 ms (-1.8 %),
+        // 125k x 100k: 1.937 -> 1.869 (-3.5 %) (profiles/r4_kbench_summary.md section 8); the fold that reads the tiles next now
+        // reads them from HBM (22 -> 30 us at configs[1], part of it won back there).
+        double* ybase = Ypart + (slice * Npad + n0) * 32;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int ip = 0; ip < 2; ++ip) {
+                        const int e = 8 * half + 4 * q + 2 * ip;
+                        double2 o;
+                        o.x = combine_digits<BITS>(acc[t], e); o.y = combine_digits<BITS>(acc[t], e + 1);
+                        const int ch = 4 * q + 2 * h + ip;
+                        *reinterpret_cast<double2*>(stage + c * 128 + ((ch ^ (c & 7)) << 4)) = o;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (one wave's LDS operations execute in order: no barrier)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int line = (lane >> 3) + 8 * i, ch = lane & 7;
+                    const double2 v = *reinterpret_cast<const double2*>(stage + line * 128 + ((ch ^ (line & 7)) << 4));
+                    typedef double d2v __attribute__((ext_vector_type(2)));
+                    const d2v vv = {v.x, v.y};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<d2v*>(ybase + (4 * line + t) * 32 + 16 * half + 2 * ch));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_sched_barrier(0);                            // (a quarter of a tile's accumulators live at a time)
+            }
+        }
+        return;
+    }
+#endif
     double* yp = Ypart + (slice * Npad + n0 + 4 * c) * 32 + 4 * h;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1106,7 +1149,7 @@ __global__ __launch_bounds__(256, 1) void k_gtt_d(const uint8_t* __restrict__ Gb
         const int64_t nstage = k.kblocks >> 2;
         GTD_STAGE(true)                                        // the task's first block starts the sums (C = 0)
         for (int64_t st = 1; st < nstage; ++st) GTD_STAGE(false)
-        if (k.live && !((ABL & 16) && acc[0][0][0] != 0x7fffffff)) gtt_tiles_out<7>(acc, Ypart, k.slice, Npad, k.n0);
+        if (k.live && !((ABL & 16) && acc[0][0][0] != 0x7fffffff)) gtt_tiles_out<7>(acc, Ypart, k.slice, Npad, k.n0, reinterpret_cast<char*>(&sm->tile[wv][0]));
     }
 #undef GTD_STAGE
 #undef GTD_PHASE
