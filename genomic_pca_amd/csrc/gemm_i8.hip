@@ -510,11 +510,14 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
 // and b of row 32 t + c in lane c.  The sched_barrier keeps one tile's accumulators live at a time: without it hipcc read all 256
 // accumulators into VGPRs first, spilled the address arithmetic to scratch and waited (vmcnt(0)) on every reload behind the store it
 // had just issued -- one store round trip per element, ~19 us per round at any N (the per-round cost the shape sweep showed).
+#ifndef GPCA_T_NT_MODE
+#define GPCA_T_NT_MODE 2      // (harness: 0 never, 1 every round, 2 every round but a workgroup's last)
+#endif
 template <int BITS, bool RB_LDS>
 __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rrow, float brow, const float* rl, const float* bl,
                                             double qs, float sj, int scale_out,
                                             float* __restrict__ tile, float* __restrict__ Tout, int64_t ldt, int64_t unit,
-                                            float* __restrict__ cunit, float& amax, int lane_in) {
+                                            float* __restrict__ cunit, float& amax, int lane_in, bool stream_store = false) {
     __builtin_amdgcn_sched_barrier(0);
     // the lane id is made opaque here: everything derived from it (LDS offsets, cross-lane indices, store addresses) is then computed
     // where it is used instead of being hoisted out of the round loop as ~40 loop-invariant registers that the stage loop's register
@@ -542,16 +545,17 @@ __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rr
     for (int i = 0; i < 4; ++i) {
         const int rr = (lane >> 3) + 8 * i;
         const float4 v = *reinterpret_cast<const float4*>(tile + rr * 32 + 4 * (lane & 7));
-#ifndef GPCA_T_TEMPORAL
-        // streaming store: written through instead of left dirty in L2 for the next round's genotype reads to evict one line at a
-        // time -- that write-back, interleaved with the reads, made the first ten stages of every round ~25 % slower
-        // (stage stamps, profiles/r4_kbench_summary.md); k_gq_d 1.563 -> 1.550 ms at 1M x 10k
+        // Streaming store when another round follows: written through instead of left dirty in L2 for the next round's genotype
+        // reads to evict one line at a time -- that write-back, interleaved with the reads, made the first ten stages of every round
+        // ~25 % slower (stage stamps, profiles/r4_kbench_summary.md section 6; k_gq_d 1.563 -> 1.550 ms at 1M x 10k).  A workgroup's
+        // LAST round keeps the plain store: nothing streams behind it, and the launch does not have to wait for HBM to take the tile.
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v vv = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)));
-#else
-        *reinterpret_cast<float4*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7)) = v;
-#endif
+        f4v* dst = reinterpret_cast<f4v*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7));
+        // (the streaming form is inline asm: written as two C++ stores under an if, the optimiser merges them into one plain store --
+        //  the common metadata of the two -- and the hint is gone)
+        if (GPCA_T_NT_MODE == 1 || (GPCA_T_NT_MODE == 2 && stream_store)) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(vv) : "memory");
+        else *dst = vv;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the tile is free again before the next one is written)
     __builtin_amdgcn_sched_barrier(0);
@@ -736,7 +740,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     float* tile = sm->tile[wv];
 #pragma unroll
     for (int t = 0; t < R; ++t)
-        if (t < nvalid) gq_tile_out<7, true>(acc[t], 0.f, 0.f, &sm->rb[wv][0][32 * t], &sm->rb[wv][1][32 * t], qs, sj, scale_out, tile, Tout, ldt, unit0 + t, cunit, amax, lane);
+        if (t < nvalid) gq_tile_out<7, true>(acc[t], 0.f, 0.f, &sm->rb[wv][0][32 * t], &sm->rb[wv][1][32 * t], qs, sj, scale_out, tile, Tout, ldt, unit0 + t, cunit, amax, lane, chain);
     GQD_STAMP(2 + 2 * round_ix)
 }
 
