@@ -967,7 +967,7 @@ struct GtdTask { const uint8_t* gp; const int8_t* tp; int64_t kblocks; int64_t n
 // that drained the DMA queue at every task boundary).
 template <int BITS>
 __device__ __forceinline__ void gtt_tiles_out(const i32x16 (&acc)[4][kDigits], double* __restrict__ Ypart, int64_t slice, int64_t Npad, int64_t n0,
-                                              char* stage = nullptr) {
+                                              char* stage = nullptr, int piece_stride = 1024) {
     __builtin_amdgcn_sched_barrier(0);
     unsigned all = ~0u;
     asm volatile("" : "+s"(all));                     // (opaque mask: the lane id is recomputed HERE -- hoisted out of the task loop it would be kept across the stage loop, i.e. spilled)
@@ -979,7 +979,9 @@ __device__ __forceinline__ void gtt_tiles_out(const i32x16 (&acc)[4][kDigits], d
         // apart: written directly, each store instruction touches 64 lines with 16 bytes each (2 048 partial-line writes per tile;
         // the stores were worth 2.3 % of a launch for 1.3 % of its bytes).  Through a wave-private 4 KiB of LDS a store instruction
         // writes 8 full 128-byte lines: per (sample t of the lane's four, half of the row) lane (c, h) parks its 8 doubles in line c
-        // (16-byte chunks XOR-swizzled by c), lane L takes chunk L & 7 of lines L >> 3 (+ 8, 16, 24) back and stores it -- as a
+        // (16-byte chunks XOR-swizzled by c; the 4 KiB are four 1-KiB pieces `piece_stride` bytes apart: contiguous in k_gq_d's
+        // tile buffer, the wave's own DMA pieces of a drained stage buffer in k_gtt_p), lane L takes chunk L & 7 of lines L >> 3
+        // (+ 8, 16, 24) back and stores it -- as a
         // STREAMING store: the same full lines written with plain stores measured no gain at all (1.5245 against 1.5246 ms direct);
         // what costs is the dirty tile evicted from L2 between the genotype reads, as in K1.  1M x 10k: 1.525 -> 1.498 ms (-1.8 %),
         // 125k x 100k: 1.937 -> 1.869 (-3.5 %) (profiles/r4_kbench_summary.md section 8); the fold that reads the tiles next now
@@ -997,13 +999,13 @@ __device__ __forceinline__ void gtt_tiles_out(const i32x16 (&acc)[4][kDigits], d
                         double2 o;
                         o.x = combine_digits<BITS>(acc[t], e); o.y = combine_digits<BITS>(acc[t], e + 1);
                         const int ch = 4 * q + 2 * h + ip;
-                        *reinterpret_cast<double2*>(stage + c * 128 + ((ch ^ (c & 7)) << 4)) = o;
+                        *reinterpret_cast<double2*>(stage + (c >> 3) * piece_stride + (c & 7) * 128 + ((ch ^ (c & 7)) << 4)) = o;
                     }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (one wave's LDS operations execute in order: no barrier)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int line = (lane >> 3) + 8 * i, ch = lane & 7;
-                    const double2 v = *reinterpret_cast<const double2*>(stage + line * 128 + ((ch ^ (line & 7)) << 4));
+                    const double2 v = *reinterpret_cast<const double2*>(stage + i * piece_stride + (lane >> 3) * 128 + ((ch ^ (line & 7)) << 4));
                     typedef double d2v __attribute__((ext_vector_type(2)));
                     const d2v vv = {v.x, v.y};
                     __builtin_nontemporal_store(vv, reinterpret_cast<d2v*>(ybase + (4 * line + t) * 32 + 16 * half + 2 * ch));
@@ -1254,18 +1256,10 @@ __device__ __forceinline__ void gtp_segment(const uint8_t* __restrict__ G2, int6
     }
 #undef GTP_PHASE
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // no DMA may land after this segment; every wave has left the ring
-    double* yp = Ypart + (slice * Npad) * 32;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int64_t n = n0 + 4 * c + t;
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const int j = (e & 3) + 8 * (e >> 2) + 4 * h;
-            double2 o;
-            o.x = combine_digits<ND == 3 ? 8 : 7>(acc[t], e); o.y = combine_digits<ND == 3 ? 8 : 7>(acc[t], e + 1);
-            *reinterpret_cast<double2*>(yp + n * 32 + j) = o;
-        }
-    }
+    // the ring is drained and every wave has left it: the wave's own DMA pieces of stage buffer 3 (1 KiB in each of its four blocks of
+    // genotype rows, written by nobody else -- a faster wave may already be filling the ring for the next task) stage the tile on its
+    // way out (gtt_tiles_out: full lines, streaming stores)
+    gtt_tiles_out<ND == 3 ? 8 : 7>(acc, Ypart, slice, Npad, n0, &sm->stg[3].g[0][1024 * wv], (int)sizeof(sm->stg[3].g[0]));
 }
 
 template <int ND>

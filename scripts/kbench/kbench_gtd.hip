@@ -79,7 +79,38 @@ static int plans_main(int argc, char** argv) {
     }
     return 0;
 }
+// packed K2 (k_gtt_p, 2-bit rows): the product's plan, four and three digit planes round-robin      ./kbench_gtd packed M N reps
+static int packed_main(int argc, char** argv) {
+    const int64_t M = atoll(argv[2]), N = atoll(argv[3]);
+    const int reps = atoi(argv[4]);
+    const int64_t Npad = (N + 1023) / 1024 * 1024, ld2 = Npad / 4, Mpad = (M + 127) / 128 * 128;
+    const gpca::Gtt8Plan p = gpca::gtt8_plan_batched(Mpad, Npad, 2048);
+    uint8_t* G2; int8_t* Td; double* Yp;
+    CK(hipMalloc(&G2, Mpad * ld2)); CK(hipMalloc(&Td, Mpad * 32 * 4)); CK(hipMalloc(&Yp, (size_t)p.W * Npad * 32 * 8));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G2, Mpad * ld2 / 4, 1u, 0xaaaaaaaau ^ 0xffffffffu);   // codes 0 / 1 only
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)Td, Mpad * 32, 2u, 0x3f3f3f3fu);
+    if (gpca::init_device_kernels_i8()) { printf("LDS opt-in failed\n"); return 1; }
+    gpca::KernelOpts ko;
+    double sum[2] = {0, 0};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 5; ++it) if (gpca::launch_gtt_p(0, G2, ld2, Mpad, Npad, Td, Yp, p, 4, ko)) { printf("launch refused\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < reps; ++rep)
+        for (int v = 0; v < 2; ++v) {
+            const int nd = v ? 3 : 4;
+            gpca::launch_gtt_p(0, G2, ld2, Mpad, Npad, Td, Yp, p, nd, ko);
+            hipEventRecord(e0);
+            for (int it = 0; it < 10; ++it) gpca::launch_gtt_p(0, G2, ld2, Mpad, Npad, Td, Yp, p, nd, ko);
+            hipEventRecord(e1); CK(hipEventSynchronize(e1));
+            float t; hipEventElapsedTime(&t, e0, e1); sum[v] += t / 10;
+        }
+    printf("k_gtt_p %lld x %lld (W %d, %lld workgroups x %d tasks), %d x 10 launches per variant, round-robin: four planes %.4f ms, three planes %.4f ms\n",
+           (long long)M, (long long)N, p.W, (long long)p.grid, p.tasks_per_wg, reps, sum[0] / reps, sum[1] / reps);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 4 && std::string(argv[1]) == "packed") return packed_main(argc, argv);
     if (argc > 5 && std::string(argv[1]) == "plans") return plans_main(argc, argv);
     const int64_t M = argc > 1 ? atoll(argv[1]) : 1000064, N = argc > 2 ? atoll(argv[2]) : 10000;
     const int reps = argc > 3 ? atoi(argv[3]) : 4;
