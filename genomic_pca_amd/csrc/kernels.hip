@@ -14,6 +14,9 @@
 #include "kernels.h"
 #include "philox.hpp"
 
+#ifndef GPCA_OMEGA_ABLATE
+#define GPCA_OMEGA_ABLATE 0     // scripts/kbench/kbench_omega.hip
+#endif
 namespace gpca {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -392,20 +395,28 @@ __global__ __launch_bounds__(64 * NW) void k_omega(int64_t M, int64_t Mpad, int 
     for (int jq = 0; jq < L / 4; ++jq) {
         double z[4] = {0, 0, 0, 0};
         if (4 * jq < l && live) {
+#if GPCA_OMEGA_ABLATE & 2
+            philox_out o; o.v[0] = (uint32_t)gi * 2654435761u + jq; o.v[1] = o.v[0] ^ 0x9e3779b9u; o.v[2] = o.v[0] * 3u; o.v[3] = ~o.v[0];
+#else
             philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)jq, GPCA_STREAM_OMEGA,
                                          (uint32_t)seed, (uint32_t)(seed >> 32));
-            const double sc = 1.0 / 4294967296.0, twopi = 6.283185307179586476925286766559;
+#endif
+            const double sc = 1.0 / 4294967296.0;
             const double u0 = ((double)o.v[0] + 1.0) * sc, u1 = ((double)o.v[1] + 1.0) * sc;
             const double u2 = ((double)o.v[2] + 1.0) * sc, u3 = ((double)o.v[3] + 1.0) * sc;
+#if GPCA_OMEGA_ABLATE & 1
+            z[0] = u0; z[1] = u1; z[2] = u2; z[3] = u3;
+            const double twopi = 0;
+#else
             const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
             // sin / cos of 2 pi u through sincospi(2 u): one shared, exact argument reduction instead of two reductions of the
             // rounded product (agrees with the oracle's cos(twopi * u) to ~1e-16, far below the f32 rounding of Omega)
             double s1, c1, s3, c3;
             sincospi(2.0 * u1, &s1, &c1);
             sincospi(2.0 * u3, &s3, &c3);
-            (void)twopi;
             z[0] = r0 * c1; z[1] = r0 * s1;
             z[2] = r1 * c3; z[3] = r1 * s3;
+#endif
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(64 * NW) void k_omega(int64_t M, int64_t Mpad, int 
         }
     }
     __syncthreads();
-    if (Td) {
+    if (Td && !(GPCA_OMEGA_ABLATE & 4)) {
         // Exact-integer path: the digit planes of T' = r o Omega leave this kernel directly (no f32 T', no quantisation pass over
         // it).  The column scale is an analytic bound instead of the measured maximum: |z| <= sqrt(-2 ln 2^-32) = 6.6604 for the
         // Box-Muller draw above and r <= rmax, so |T'| <= 6.67 rmax -- at M = 10^6 rows that is within a factor ~2 of the measured
