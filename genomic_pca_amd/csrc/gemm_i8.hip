@@ -554,7 +554,7 @@ __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rr
         f4v* dst = reinterpret_cast<f4v*>(Tout + (unit * 32 + rr) * ldt + 4 * (lane & 7));
         // (the streaming form is inline asm: written as two C++ stores under an if, the optimiser merges them into one plain store --
         //  the common metadata of the two -- and the hint is gone)
-        if (GPCA_T_NT_MODE == 1 || (GPCA_T_NT_MODE == 2 && stream_store)) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(vv) : "memory");
+        if (GPCA_T_NT_MODE == 1 || (GPCA_T_NT_MODE == 2 && stream_store)) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(dst), "v"(vv) : "memory");   // (s_nop: a VALU write of the data registers needs two wait states behind a store wider than 8 bytes, and the hazard recogniser does not read asm)
         else *dst = vv;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the tile is free again before the next one is written)
