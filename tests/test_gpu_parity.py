@@ -1193,3 +1193,19 @@ def test_exact_path_with_qc_dropped_and_missing_rows(gpca, oracle, store, planes
         assert oracle.max_abs_dpc(e.loadings().astype(np.float64), R["loadings"][kept]) < TOL_PC
         assert oracle.max_abs_dpc(e.scores(f64=True), R["scores"]) < TOL_PC
         assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
+
+
+@pytest.mark.gpu
+def test_product_bits_did_not_move():
+    """sha256 of eigenvalues, f64 scores and loadings of five fixed problems (L = 32 / 64 / 128, int8 and 2-bit rows, a sketch as wide
+    as the sample count) against tests/golden/product_fingerprint.txt.  This is a guard, not a parity claim: a kernel rewritten without
+    a change of arithmetic must leave every line alone (round 4: the Cholesky through LDS, the streaming stores, the prefetch depths
+    all did); a change that is MEANT to move bits regenerates the file with `python scripts/fingerprint.py` and says so."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("fingerprint", os.path.join(os.path.dirname(here), "scripts", "fingerprint.py"))
+    fp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fp)
+    want = open(os.path.join(here, "golden", "product_fingerprint.txt")).read().split("\n")
+    want = [w for w in want if w.strip()]
+    assert fp.lines() == want
