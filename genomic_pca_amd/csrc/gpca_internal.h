@@ -291,7 +291,7 @@ struct ScopedTimer {
         TimingRec r; r.name = name; r.flops = flops; r.bytes = bytes; r.a = r.b = nullptr;
         for (hipEvent_t* e : {&r.a, &r.b}) {
             if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
-            else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
+            else if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) != hipSuccess) { on = false; return; }   // (timing only: no system-scope fence when it records)
         }
         (void)hipEventRecord(r.a, st);
         h->recs.push_back(r); idx = h->recs.size() - 1; h->open_timers++;
