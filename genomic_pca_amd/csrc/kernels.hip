@@ -893,10 +893,10 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 // How an element of another column reaches a lane.  Rounds 1-3: one v_readlane pair per element (~1 000 of them for NN = 32, each
-// with its hazard nops) -- 24 us.  Round 4: a finished row of R is broadcast through LDS: step j writes its scaled row once
+// with its hazard nops) -- 18.9 us per launch (scripts/kbench/kbench_chol.hip, both forms alternating in one process).  Round 4: a finished row of R is broadcast through LDS: step j writes its scaled row once
 // (ds_write_b64, lane c -> rs[j][c]) and every lane reads the entries it needs back from a wave-uniform address (a broadcast read,
 // no bank conflict), one batch of wide reads per step; the back substitution reads the same rows again.  Same operations on the
-// same values in the same order, so the bits do not change (scripts/fingerprint.py before / after) -- 17 us (the chain of a
+// same values in the same order, so the bits do not change (the harness compares the results; scripts/fingerprint.py before / after) -- 12.5 us (the chain of a
 // step: pivot, 1/sqrt by Newton, the row through LDS, 31 - j dependent-free FMAs; what is left is one wave's f64 latency).
 // The asm pins keep a step's FMAs in the step: left free, the scheduler sinks them behind the last row's reads with every row live.
 // (Dropped after measurement: the whole matrix in LDS (round 3, 100 us); the fold of the Gram partials ahead of the factorisation
