@@ -1053,33 +1053,22 @@ __global__ __launch_bounds__(256) void k_rightmul_mfma(const float* __restrict__
     const int64_t ntiles = (nrows + 15) >> 4;
     const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * tiles_per_wave;
     const int64_t t1 = (t0 + tiles_per_wave < ntiles) ? t0 + tiles_per_wave : ntiles;
-    // A tile's rows are requested two tiles ahead and their ids (the gather through row_ids) three: the id load and the row load it
-    // feeds used to sit back to back in front of every tile -- two dependent round trips with 2 KiB per wave in flight, 3.1 TB/s.
-    float xa[E], xb[E], xc[E];
-    auto tile_src = [&](int64_t tile) -> int64_t {          // source row of this lane's row of the tile, -1 = none
+    float xa[E], xn[E];
+    auto load_tile = [&](int64_t tile, float (&dst)[E]) {
         const int64_t row = tile * 16 + i;
-        if (!(row < nrows && tile < t1)) return -1;
-        return row_ids ? row_ids[row] : row;
-    };
-    auto load_tile = [&](int64_t src, float (&dst)[E]) {
-        const bool valid = src >= 0;
-        const float4* xp = reinterpret_cast<const float4*>(X + (valid ? src : 0) * L + E * kq);
+        const bool valid = row < nrows && tile < t1;
+        const int64_t src = valid ? (row_ids ? row_ids[row] : row) : 0;
+        const float4* xp = reinterpret_cast<const float4*>(X + src * L + E * kq);
 #pragma unroll
         for (int v = 0; v < E / 4; ++v) {
             const float4 q = xp[v];
             dst[4 * v] = valid ? q.x : 0.f; dst[4 * v + 1] = valid ? q.y : 0.f; dst[4 * v + 2] = valid ? q.z : 0.f; dst[4 * v + 3] = valid ? q.w : 0.f;
         }
     };
-    int64_t s2a = -1, s3a = -1;                              // ids of tiles +2 and +3
-    if (t0 < t1) {
-        load_tile(tile_src(t0), xa);
-        load_tile(tile_src(t0 + 1), xb);
-        s2a = tile_src(t0 + 2);
-    }
+    if (t0 < t1) load_tile(t0, xa);
     for (int64_t tile = t0; tile < t1; ++tile) {
-        s3a = tile_src(tile + 3);
-        load_tile(s2a, xc);                                  // tile + 2: in flight behind two tiles of MFMAs and stores
-        s2a = s3a;
+        load_tile(tile + 1, xn);                        // next tile's rows are in flight behind this tile's MFMAs (two tiles ahead and the
+                                                        // row ids three ahead measured the same: 55.6 against 55.3 - 55.8 us, kbench_tail.hip)
         f64x4 acc[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) acc[jt] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -1102,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_rightmul_mfma(const float* __restrict__
         float* dst = out32 + tile * 16 * K;
         for (int e = lane; e < (int)rows_here * K; e += 64) dst[e] = osm[wv][e];
 #pragma unroll
-        for (int s2 = 0; s2 < E; ++s2) { xa[s2] = xb[s2]; xb[s2] = xc[s2]; }
+        for (int s2 = 0; s2 < E; ++s2) xa[s2] = xn[s2];
     }
 }
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
