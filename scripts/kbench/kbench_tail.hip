@@ -6,6 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o kbench_tail kbench_tail.hip && ./kbench_tail
 #include "../../genomic_pca_amd/csrc/kernels.hip"
 #include "../../genomic_pca_amd/csrc/wide_sketch.hip"
+#include "../../genomic_pca_amd/csrc/fold_quantize_i8.hip"
 #include <cstdio>
 #include <vector>
 #include <cstring>
@@ -104,6 +105,17 @@ __global__ __launch_bounds__(256) void k_col_sign_old(const double* __restrict__
     }
     if (threadIdx.x == 0) sign[col] = (bi[0] >= 0 && X[bi[0] * K + col] < 0.0) ? -1 : 1;
 }
+// the fold of K2's partial tiles as rounds 1-3 wrote it (the compiler's own unroll of a dependent chain of adds)
+__global__ __launch_bounds__(256) void k_reduce_y_old(const double* __restrict__ Ypart, int W, int64_t Npad, int64_t N,
+                                                      const double* __restrict__ cvec, const double* __restrict__ tscale,
+                                                      double* __restrict__ Y, int64_t ldy) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * 32) return;
+    double s = 0.0;
+    for (int w = 0; w < W; ++w) s += Ypart[w * (Npad * 32) + e];
+    const int j = (int)(e & 31);
+    Y[(e >> 5) * ldy + j] = fma(tscale[j], s, cvec[j]);
+}
 }  // namespace gpca
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void k_fillf(float* p, int64_t n) { for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = (float)((i * 2654435761u) & 0xffff) / 65536.f - 0.5f; }
@@ -139,6 +151,30 @@ int main() {
     CK(hipMemcpy(s0.data(), sg0, K * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(s1.data(), sg1, K * 4, hipMemcpyDeviceToHost));
     printf("k_rightmul_mfma<32, 2> 1M gathered rows x 20: one tile ahead %.2f us, two ahead + ids three ahead %.2f us; results %s\n", t[0] / 6, t[1] / 6,
            memcmp(a.data(), b.data(), a.size() * 4) == 0 ? "bit-identical" : "DIFFER");
+    {   // fold: 51 partial tiles of 10 240 x 32 doubles (134 MB), written just before by a streaming kernel's worth of stores
+        const int W = 51; const int64_t Npad = 10240;
+        double *Yp, *Y0, *Y1, *cv, *ts;
+        CK(hipMalloc(&Yp, (size_t)W * Npad * 32 * 8)); CK(hipMalloc(&Y0, N * 32 * 8)); CK(hipMalloc(&Y1, N * 32 * 8)); CK(hipMalloc(&cv, 256)); CK(hipMalloc(&ts, 256));
+        hipLaunchKernelGGL(k_filld, dim3(4096), dim3(256), 0, 0, Yp, (int64_t)W * Npad * 32); hipLaunchKernelGGL(k_filld, dim3(1), dim3(64), 0, 0, cv, (int64_t)32); hipLaunchKernelGGL(k_filld, dim3(1), dim3(64), 0, 0, ts, (int64_t)32);
+        double tf[2] = {0, 0};
+        for (int rep = 0; rep < 6; ++rep)
+            for (int v = 0; v < 2; ++v) {
+                auto go = [&]() {
+                    hipLaunchKernelGGL(k_fillf, dim3(4096), dim3(256), 0, 0, T, M * L);      // 128 MB through L2 between folds: the tiles are not cache-resident
+                    if (v == 0) hipLaunchKernelGGL(gpca::k_reduce_y_old, dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, 0, Yp, W, Npad, N, cv, ts, Y0, (int64_t)32);
+                    else gpca::launch_reduce_y_i8(0, Yp, W, Npad, N, cv, ts, Y1, 32);
+                };
+                go();
+                hipEventRecord(e0);
+                for (int it = 0; it < 10; ++it) go();
+                hipEventRecord(e1); CK(hipEventSynchronize(e1));
+                float ms; hipEventElapsedTime(&ms, e0, e1); tf[v] += ms / 10 * 1e3;
+            }
+        std::vector<double> ya(N * 32), yb(N * 32);
+        CK(hipMemcpy(ya.data(), Y0, N * 32 * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(yb.data(), Y1, N * 32 * 8, hipMemcpyDeviceToHost));
+        printf("fold of 51 partial tiles (+ a 128 MB fill in front of each, same for both): plain loop %.2f us, eight loads in flight %.2f us; results %s\n", tf[0] / 6, tf[1] / 6,
+               memcmp(ya.data(), yb.data(), ya.size() * 8) == 0 ? "bit-identical" : "DIFFER");
+    }
     printf("k_col_sign 10 000 x 20: 256 threads %.2f us, 1 024 threads %.2f us; results %s\n", t[2] / 6, t[3] / 6, s0 == s1 ? "identical" : "DIFFER");
     return 0;
 }
