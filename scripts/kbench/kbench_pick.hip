@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o kbench_pick kbench_pick.hip && ./kbench_pick [NB]
 #include "../../genomic_pca_amd/csrc/gemm_i8.hip"
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -63,6 +64,33 @@ int main(int argc, char** argv) {
             printf("kept buffer %d, %-58s K1 %.1f us | K2 %.1f us\n", best, what, a1 / 4, a2 / 4);
         };
         k12("every candidate still allocated:");
+        {   // Is it the idle gaps?  A product call = 3 x (K2, K1) with two host synchronisations (the l x l eigenproblem, the end of the call).
+            // The same six launches per "call" here, timed by events around each launch, with and without a host sync + ~80 us pause per call.
+            hipEvent_t ea[6], eb[6];
+            for (int i = 0; i < 6; ++i) { hipEventCreateWithFlags(&ea[i], hipEventDisableSystemFence); hipEventCreateWithFlags(&eb[i], hipEventDisableSystemFence); }
+            for (int mode = 0; mode < 3; ++mode) {
+                double k1 = 0, k2 = 0; int n = 0;
+                const auto t_begin = std::chrono::steady_clock::now();
+                for (int call = 0; call < 200; ++call) {
+                    for (int i = 0; i < 3; ++i) {
+                        hipEventRecord(ea[2 * i], 0); gpca::launch_gtt_d(0, G[best], ld8, Mpad, Npad, Td, Yp, p2, ko); hipEventRecord(eb[2 * i], 0);
+                        hipEventRecord(ea[2 * i + 1], 0); gpca::launch_gq_d(0, G[best], ld8, p1, Npad, Qd, qs, r, bb, s, T, cp, ap, 1, 32, ko); hipEventRecord(eb[2 * i + 1], 0);
+                        if (mode == 2 && i == 1) { hipStreamSynchronize(0); const auto t1 = std::chrono::steady_clock::now(); while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() < 70.0) {} }
+                    }
+                    if (mode >= 1) { hipStreamSynchronize(0); const auto t1 = std::chrono::steady_clock::now(); while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() < 30.0) {} }
+                    else if (call % 20 == 19) hipStreamSynchronize(0);
+                    if (call >= 100 && (mode >= 1 || call % 20 == 19)) {
+                        hipEventSynchronize(eb[5]);
+                        for (int i = 0; i < 3; ++i) { float a, b; hipEventElapsedTime(&a, ea[2 * i], eb[2 * i]); hipEventElapsedTime(&b, ea[2 * i + 1], eb[2 * i + 1]); k2 += a; k1 += b; }
+                        n += 3;
+                    }
+                }
+                const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+                printf("200 'calls' of 3 x (K2, K1), %-62s K1 %.1f us | K2 %.1f us (events, calls 100-199)  wall %.2f ms per call\n",
+                       mode == 0 ? "no host synchronisation:" : (mode == 1 ? "host sync + 30 us pause after every call:" : "... and a sync + 70 us pause inside every call:"),
+                       k1 / n * 1e3, k2 / n * 1e3, wall / 200);
+            }
+        }
         for (int b = 0; b < NB; ++b) if (b != best) { CK(hipFree(G[b])); G[b] = nullptr; }
         k12("the other candidates freed:");
         k12("(again)");
