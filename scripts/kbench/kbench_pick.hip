@@ -64,6 +64,17 @@ int main(int argc, char** argv) {
             printf("kept buffer %d, %-58s K1 %.1f us | K2 %.1f us\n", best, what, a1 / 4, a2 / 4);
         };
         k12("every candidate still allocated:");
+        if (argc > 2) {   // how large does a free have to be?   ./kbench_pick NB sizes   (a fresh allocation of each size, written once, freed, K1 / K2 right after)
+            for (const double gb : {0.016, 0.25, 1.0, 4.0, 16.0}) {
+                int8_t* q = nullptr; const size_t nb = (size_t)(gb * (1 << 30));
+                CK(hipMalloc(&q, nb)); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)q, (int64_t)(nb / 4), 1u, 0x01010101u);
+                for (int i = 0; i < 300; ++i) { gpca::launch_gq_d(0, G[best], ld8, p1, Npad, Qd, qs, r, bb, s, T, cp, ap, 1, 32, ko); gpca::launch_gtt_d(0, G[best], ld8, Mpad, Npad, Td, Yp, p2, ko); }
+                CK(hipDeviceSynchronize());
+                char what[96]; snprintf(what, sizeof what, "settled (1 s of load), then");  k12(what);
+                CK(hipFree(q));
+                snprintf(what, sizeof what, "... right after hipFree of %.3f GiB:", gb);  k12(what);
+            }
+        }
         {   // Is it the idle gaps?  A product call = 3 x (K2, K1) with two host synchronisations (the l x l eigenproblem, the end of the call).
             // The same six launches per "call" here, timed by events around each launch, with and without a host sync + ~80 us pause per call.
             hipEvent_t ea[6], eb[6];
