@@ -112,6 +112,50 @@ def parity_check(g, precision, seed):
 EXTRA_PATH_MIN_WARM_S = 1.5
 
 
+def weak_scaling_fields(ms_per_step, solo_ms):
+    """Weak-scaling efficiency of a multi-rank run against ITS OWN reference: every rank timed the same shard as a matrix of its own
+    (no exchange) in the same process just before it joined the exchange (`solo_ms`, one figure per rank).  ms_per_step is the contract's
+    max over ranks.  Two readings: against the mean of the solo times (what the exchange + waiting for peers cost on average) and
+    against the slowest rank's solo time (a max-over-ranks step can never beat the slowest GPU: this one isolates the exchange from
+    the +-4 % spread between processes / GPUs that a max over ranks absorbs).  NOT against the --gpus 1 line, which is configs[1]."""
+    solo = [float(x) for x in solo_ms if x is not None]
+    if not solo or not ms_per_step:
+        return {"weak_scaling_efficiency": None, "weak_scaling_efficiency_vs_slowest_rank": None}
+    mean, worst = sum(solo) / len(solo), max(solo)
+    return {"weak_scaling_efficiency": mean / ms_per_step, "weak_scaling_efficiency_vs_slowest_rank": worst / ms_per_step,
+            "same_shard_without_exchange_ms_mean": mean, "same_shard_without_exchange_ms_slowest": worst,
+            "same_shard_spread_between_ranks": (worst - min(solo)) / mean,
+            "weak_scaling_reference": "the same shard on the same GPU in the same process without the exchange (three calls before the "
+                                      "communicator is joined); NOT the --gpus 1 line, which is BASELINE.json configs[1] (1M x 10k)",
+            "expected_band": "0.95-1.0 vs the slowest rank (3 x N x L f64 sketch + one L^2 Gram per call: < 1 % of a step over xGMI); "
+                             "up to 4 % lower vs the mean, which also carries the spread between the ranks' GPUs"}
+
+
+def shard_bytes_needed(M, N, storage, k, oversample, streamed=False, panel_rows=0, ring=3):
+    """Device bytes a rank needs before it generates anything: the resident shard (padded pitch) or the panel ring, plus the solver's
+    workspace (gpca.h: about 1 KiB per SNP row and 8 KiB per sample for l <= 32; twice that for wider sketches) and a 2 GiB margin."""
+    l = k + oversample
+    wide = 1 if l <= 32 else (2 if l <= 64 else 4)
+    if storage == "2bit":
+        ldg = -(-N // 1024) * 1024
+        pitch = ldg // 4 + (256 if (ldg // 4 // 256) % 2 == 0 else 0)
+    else:
+        ldg = -(-N // 256) * 256
+        pitch = ldg + (256 if (ldg // 256) % 2 == 0 else 0)
+    rows = (min(M, (panel_rows or 131072)) * ring) if streamed else -(-M // 128) * 128
+    return rows * pitch + wide * (M * 1024 + N * 8192) + (2 << 30)
+
+
+def memory_preflight(eng, what, need_bytes, rank):
+    """Fail with a sentence instead of an out-of-memory abort half-way through generating 125 GB."""
+    free_b, total_b = eng.device_memory()
+    if need_bytes > free_b:
+        raise SystemExit(f"bench.py: rank {rank}: {what} needs about {need_bytes / 2**30:.1f} GiB of device memory, "
+                         f"{free_b / 2**30:.1f} GiB of {total_b / 2**30:.1f} GiB are free on its GPU -- is the device shared, or is --snps / --samples "
+                         f"meant for a larger part?  (--storage 2bit needs a quarter of the shard; --streamed none of it)")
+    return {"needed_GiB": need_bytes / 2**30, "free_GiB": free_b / 2**30, "total_GiB": total_b / 2**30}
+
+
 def timed_run(eng, a, k, barrier, rdzv, min_warm_s=0.0):
     t_w = time.perf_counter()
     for _ in range(a.warmup):
@@ -318,10 +362,22 @@ def streamed_run(g, a, M, N, k, storage, device, snp_offset, rdzv, uid_fn=None, 
     th16 = g.synth_thresholds16(M, 3, seed=a.rfit_seed, snp_offset=snp_offset)
     eng = g.GpcaEngine(device=device, precision=g._lib.PREC_I8_EXACT, storage=g._lib.STORE_2BIT if storage == "2bit" else g._lib.STORE_INT8,
                        digit_planes=a.digit_planes if storage == "2bit" else 0)
+    rank = rdzv.rank if rdzv is not None else 0
+    mem = memory_preflight(eng, f"the panel ring of {M} SNPs x {N} samples ({storage}, streamed)",
+                           shard_bytes_needed(M, N, storage, k, a.oversample, streamed=True, panel_rows=a.panel_rows, ring=a.ring), rank)
     eng.stream_open(g.PanelSource.synth16(th16, a.rfit_seed, snp_offset=snp_offset), M, N, panel_rows=a.panel_rows, ring_slots=a.ring,
                     fused=not a.unfused)
     del th16
+    solo = None
     if uid_fn is not None:
+        # this rank's shard as a stream of its own first (no exchange, no panel cache): the weak-scaling reference of this very run
+        eng.snp_stats(g.QcConfig.none(), fetch=False)
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+        eng.synchronize(); rdzv.barrier()
+        t0 = time.perf_counter()
+        eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
+        eng.synchronize()
+        solo = rdzv.allgather(time.perf_counter() - t0)
         uid_fn(eng)            # the communicator first: its device buffers exist before the panel cache sizes itself on what is free
     n_cached = eng.stream_set_cache(-1 if cache_gb < 0 else int(cache_gb * 2**30)) if cache_gb else 0
     t0 = time.perf_counter()
@@ -341,12 +397,26 @@ def streamed_run(g, a, M, N, k, storage, device, snp_offset, rdzv, uid_fn=None, 
         eng.rsvd(k, a.oversample, a.power_iters, a.rfit_seed)
     barrier()
     dt = time.perf_counter() - t0
-    if rdzv is not None:
-        dt = rdzv.max(dt)
     tim = eng.timings()
+    if rdzv is not None:
+        ar = tim.get("allreduce")
+        every = rdzv.allgather({"dt": dt, "allreduce_ms_per_step": (ar["total_ms"] / steps) if ar else None})
+        per_rank = [e_["dt"] for e_ in every]
+        dt = max(per_rank)                         # the contract's max over ranks
+        ranks_seen = eng.comm_count_ranks()
+        tim["_ranks"] = {"per_rank_ms_per_step": [t / steps * 1e3 for t in per_rank],
+                         "per_rank_ms_per_step_min": min(per_rank) / steps * 1e3, "per_rank_ms_per_step_max": max(per_rank) / steps * 1e3,
+                         "per_rank_allreduce_ms_per_step": [e_["allreduce_ms_per_step"] for e_ in every],
+                         "same_shard_without_exchange_ms_per_step_per_rank": [t * 1e3 for t in solo] if solo else None,
+                         ("ranks_seen_by_rccl" if a.exchange == "rccl" else "ranks_seen_by_the_host_hook"): ranks_seen,
+                         "exchange": ("ncclAllReduce (RCCL) on the engine's stream inside libgpca.so" if a.exchange == "rccl" else
+                                      "host-staged hook over the launcher's hub (rehearsal: not the product's transport)"),
+                         "note": "the solo reference streams without the panel cache; allreduce spans include the wait for the slowest rank"}
+        tim["_ranks"].update(weak_scaling_fields(dt / steps * 1e3, tim["_ranks"]["same_shard_without_exchange_ms_per_step_per_rank"] or []))
     ev = eng.eigenvalues()
     eng.close()
     tim["_panels_cached"] = n_cached
+    tim["_memory"] = mem
     return dt, tim, ev, t_stats
 
 
@@ -379,6 +449,8 @@ def streamed_main(a, g, rank, world, local_rank, rdzv):
             connect(g, a, eng, rdzv, rank, world, snp_offset)
     dt, tim, ev, t_stats = streamed_run(g, a, M_local, N, k, a.storage, local_rank, snp_offset, rdzv, uid_fn, cache_gb=a.cache_gb)
     n_cached = tim.pop("_panels_cached")
+    mem = tim.pop("_memory", None)
+    rank_info = tim.pop("_ranks", None)
     if rank == 0:
         M_total = M_local * world
         per_step = dt / a.steps
@@ -403,7 +475,12 @@ def streamed_main(a, g, rank, world, local_rank, rdzv):
                             "frac": by / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "note": "sweep-level (all panels, waits for the generator included); the per-launch roofline of the same kernels is "
                                     "the resident bench line"},
-               "streaming": ssum, "snp_stats_s": t_stats, "top_eigenvalues": [float(x) for x in ev[:3]], "cpu_baseline": None}
+               "streaming": ssum, "snp_stats_s": t_stats, "top_eigenvalues": [float(x) for x in ev[:3]], "cpu_baseline": None,
+               "device_memory_preflight": mem}
+        if rank_info is not None:
+            out["multi_gpu"] = rank_info
+            out["config"]["workload"] += ("; weak scaling vs the same shard streamed on one GPU in this run (multi_gpu.weak_scaling_efficiency), "
+                                          "NOT vs a --gpus 1 line")
         print(json.dumps(out), flush=True)
     if rdzv is not None:
         rdzv.barrier()
@@ -417,7 +494,8 @@ def workload_name(world, M_local, M_total, N, k, l, a):
     what = ("BASELINE.json configs[3]: " if (M_total, N) == (10_000_000, 100_000) else
             "BASELINE.json configs[3]'s per-GPU shard (1.25M x 100k) on every rank, weak scaling: " if (M_local, N) == (1_250_000, 100_000) else "")
     return (f"{what}synthetic {M_total} SNPs x {N} samples int8 genotypes (3 populations, Hardy-Weinberg proportions, device generator), SNP rows "
-            f"sharded {M_local} per GPU over {world} GPUs, the N x l sketch and one l x l Gram all-reduced per call, {tail}")
+            f"sharded {M_local} per GPU over {world} GPUs, the N x l sketch and one l x l Gram all-reduced per call, {tail}; weak scaling vs the "
+            f"same shard on one GPU in this run (multi_gpu.weak_scaling_efficiency), NOT vs the --gpus 1 line, which is configs[1]")
 
 
 def connect(g, a, eng, rdzv, rank, world, snp_offset):
@@ -542,6 +620,9 @@ def main():
         eng = g.GpcaEngine(device=local_rank, precision=PREC["i8" if packed else prec], storage=store, digit_planes=planes)
         try:
             engines[:] = [eng]
+            if prec == a.precision:     # the headline shard must fit BEFORE anything is generated (extras report their own errors)
+                results["_memory"] = memory_preflight(eng, f"the resident shard of {M_local} SNPs x {N} samples ({'2bit' if store == g._lib.STORE_2BIT else 'int8'})",
+                                                      shard_bytes_needed(M_local, N, "2bit" if store == g._lib.STORE_2BIT else "int8", k, a.oversample), rank)
             if big:
                 eng.load_from_source(g.PanelSource.synth16(th, a.rfit_seed, snp_offset=snp_offset), M_local, N)
             else:
@@ -572,6 +653,7 @@ def main():
                 rank_info["exchange_volume_per_step"] = (f"{a.power_iters + 1} x {N} x {32 if l <= 32 else 64} f64 (sketch) + one "
                                                          f"{32 if l <= 32 else 64}^2 + 16 f64 (Gram + status) + 16 f64 (status), in-place all-reduce")
                 rank_info["launcher"] = "torch.distributed.run (ranks given)" if "GPCA_RDZV" not in os.environ else "bench.py's own (genomic_pca_amd/launch.py)"
+                rank_info.update(weak_scaling_fields(dt / a.steps * 1e3, rank_info["same_shard_without_exchange_ms_per_step_per_rank"] or []))
             results[prec] = (dt, timings, eng.eigenvalues())
             if prec == a.precision:
                 head_rank_info = rank_info
@@ -616,6 +698,7 @@ def main():
         out["roofline"]["step_level"] = {"algorithmic_bytes": step_bytes, "definition": "SURVEY.md 8(d): 4 passes x %.2f B per genotype per call, per GPU" % per_b,
                                          "achieved_GBs": step_bytes / per_step / 1e9, "frac": step_bytes / per_step / 1e9 / HBM_PEAK_GBS,
                                          "sweeps_the_engine_makes": 2 + 2 * a.power_iters}
+        out["device_memory_preflight"] = results.get("_memory")
         if head_rank_info is not None:
             out["multi_gpu"] = head_rank_info
         if "f32" in results and a.precision != "f32":
@@ -645,7 +728,7 @@ def main():
             #  averages of a rocprofv3 --stats run of this command)  the headline matrix shape again, never resident: 8 panels of 131 072 rows regenerated by the device generator on every sweep
             a2 = argparse.Namespace(**vars(a)); a2.panel_rows = 131072; a2.ring = 3; a2.digit_planes = 0
             dts, tims, evs, _ = streamed_run(g, a2, M_local, N, k, a.storage, local_rank, 0, None, steps=min(a.steps, 3), warmup=1)
-            tims.pop("_panels_cached")
+            tims.pop("_panels_cached"); tims.pop("_memory", None)
             out["streamed_panels"] = {"note": "same shape out-of-core (BASELINE.json configs[4] mode at configs[1] size): panels come from the "
                                               "device generator (GPCA_PANEL_SYNTH16; a different synthetic draw than the resident matrix)",
                                       "value": M_local * N / (dts / min(a.steps, 3)), "unit": "SNPs*samples/s",
@@ -672,7 +755,7 @@ def main():
               a5 = argparse.Namespace(**vars(a)); a5.panel_rows = 0; a5.ring = 3; a5.unfused = False; a5.digit_planes = 0
               M5, N5, k5 = 6_250_000, 500_000, 40
               dt5, tim5, ev5, t_stats5 = streamed_run(g, a5, M5, N5, k5, "2bit", local_rank, 0, None, steps=1, warmup=0, cache_gb=-1.0)
-              n_cached5 = tim5.pop("_panels_cached")
+              n_cached5 = tim5.pop("_panels_cached"); tim5.pop("_memory", None)
               return {
                 "workload": "BASELINE.json configs[4] per-GPU shard, out of core: 6.25M SNPs x 500k samples (781 GB of 2-bit codes per pass, never "
                             "resident), k = 40, l = 50, panels of 131 072 rows from the device generator (GPCA_PANEL_SYNTH16) through a ring of 3",

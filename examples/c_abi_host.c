@@ -34,8 +34,10 @@ static int run_gpu(void) {
     int64_t i, n;
     int rc, c;
     int32_t cached = 0;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.device = -1; cfg.precision = GPCA_PREC_I8_EXACT; cfg.storage = GPCA_STORE_INT8;
+    double ev0[K];
+    int32_t store = -1, prec = -1;
+    memset(&cfg, 0, sizeof cfg);                    /* a zeroed config = the fast exact path, residency chosen by the library */
+    cfg.device = -1;
     for (i = 0; i < M; ++i) {                       /* two populations with different allele frequencies */
         double p0, p1;
         s = s * 1664525u + 1013904223u; p0 = 0.1 + 0.4 * (s >> 8) / 16777216.0;
@@ -55,6 +57,20 @@ static int run_gpu(void) {
         fprintf(stderr, "resident path failed: [%d] %s\n", rc, gpca_last_error(h)); return 1;
     }
     printf("resident : %lld PCA SNPs, eigenvalues %.6f %.6f %.6f\n", (long long)gpca_num_pca_snps(h), ev[0], ev[1], ev[2]);
+    /* {0} selected GPCA_PREC_I8_EXACT, and GPCA_STORE_AUTO resolved to int8 rows for 384 samples (2-bit codes start at 1 024): the same
+     * bits as the explicit choice */
+    if (gpca_get_storage(h, &store, &prec) != GPCA_OK || store != GPCA_STORE_INT8 || prec != GPCA_PREC_I8_EXACT) { fprintf(stderr, "default config: storage %d precision %d\n", (int)store, (int)prec); return 1; }
+    {
+        gpca_handle* h2 = NULL;
+        gpca_config ex;
+        memset(&ex, 0, sizeof ex);
+        ex.device = -1; ex.precision = GPCA_PREC_I8_EXACT; ex.storage = GPCA_STORE_INT8;
+        if (gpca_create(&ex, &h2) != GPCA_OK || gpca_upload_genotypes_i8(h2, g, M, N, N) != GPCA_OK || gpca_snp_stats(h2, &qc, NULL, NULL, NULL) != GPCA_OK ||
+            gpca_rsvd(h2, K, 10, 2, 7) != GPCA_OK || gpca_get_eigenvalues(h2, ev0) != GPCA_OK) { fprintf(stderr, "explicit config failed: %s\n", gpca_last_error(h2)); return 1; }
+        gpca_destroy(h2);
+        for (c = 0; c < K; ++c) if (ev[c] != ev0[c]) { fprintf(stderr, "default config != explicit exact path\n"); return 1; }
+        puts("default  : gpca_config {0} = GPCA_PREC_I8_EXACT, GPCA_STORE_AUTO -> int8 rows here; same bits as the explicit exact path");
+    }
     memset(&src, 0, sizeof src);
     rows.g = g; rows.n = N; rows.calls = 0;
     src.kind = GPCA_PANEL_HOST_I8; src.fill = fill_rows; src.user = &rows;

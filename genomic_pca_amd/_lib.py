@@ -21,10 +21,12 @@ GPCA_ERR_STATE = -7
 GPCA_ERR_NO_DEVICE = -8
 GPCA_ERR_INVALID_GENOTYPE = -9
 GPCA_UNIQUE_ID_BYTES = 128
-PREC_F32_MFMA = 0
+PREC_DEFAULT = 0       # = PREC_I8_EXACT: what a zeroed gpca_config selects
 PREC_I8_EXACT = 1
-STORE_INT8 = 0
+PREC_F32_MFMA = 2
+STORE_AUTO = 0         # 2-bit codes from 1 024 samples on, int8 below (decided when the genotypes arrive)
 STORE_2BIT = 1
+STORE_INT8 = 2
 CFG_SIMPLE_KERNELS = 1     # gpca_config.reserved[0] flags (include/gpca.h)
 CFG_NO_COMPACT = 2
 CFG_NO_NARROW = 4
@@ -102,12 +104,14 @@ PROTOTYPES = {
     "gpca_rsvd_condensed": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]),
     "gpca_refine": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "gpca_dims": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gpca_get_storage": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gpca_snp_stats": (C.c_int, [_H, C.POINTER(gpca_qc_config), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_get_snp_qc_detail": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "gpca_set_standardization": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_get_standardization": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpca_hwe_chi_squared_p_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "gpca_host_eigh_desc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gpca_device_eigh_desc": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpca_standardize_block": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gpca_num_pca_snps": (C.c_int64, [_H]),
     "gpca_num_qc_samples": (C.c_int64, [_H]),

@@ -71,20 +71,23 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= ndev) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: device ordinal out of range"); }
     h->device = dev;
-    h->precision = cfg ? cfg->precision : GPCA_PREC_F32_MFMA;
-    h->storage = cfg ? cfg->storage : GPCA_STORE_INT8;
-    if (h->storage != GPCA_STORE_INT8 && h->storage != GPCA_STORE_2BIT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown storage mode"); }
+    // A zeroed config (or none) is the fast exact path with automatic residency -- the boundary's default is the path both command
+    // lines and the Python mirror default to, not the slowest one (it was: 28 ms against 10 ms per call at configs[1]).
+    h->precision = (!cfg || cfg->precision == GPCA_PREC_DEFAULT) ? GPCA_PREC_I8_EXACT : cfg->precision;
+    h->storage_cfg = cfg ? cfg->storage : GPCA_STORE_AUTO;
+    if (h->storage_cfg != GPCA_STORE_AUTO && h->storage_cfg != GPCA_STORE_INT8 && h->storage_cfg != GPCA_STORE_2BIT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown storage mode"); }
     if (h->precision != GPCA_PREC_F32_MFMA && h->precision != GPCA_PREC_I8_EXACT) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: unknown precision mode"); }
+    h->storage = h->storage_cfg == GPCA_STORE_2BIT ? GPCA_STORE_2BIT : GPCA_STORE_INT8;     // (AUTO: provisional until rows arrive)
     {
         const int dp = cfg ? cfg->digit_planes : 0;
         if (dp != 0 && dp != 3 && dp != 4) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes must be 0, 3 or 4"); }
-        if (dp == 3 && !(h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT)) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes = 3 is implemented for GPCA_PREC_I8_EXACT with GPCA_STORE_2BIT"); }
-        h->nd = dp == 3 ? 3 : 4;
+        if (dp == 3 && !(h->precision == GPCA_PREC_I8_EXACT && h->storage_cfg == GPCA_STORE_2BIT)) { delete h; return fail(nullptr, GPCA_ERR_BAD_ARG, "gpca_create: digit_planes = 3 is implemented for GPCA_PREC_I8_EXACT with GPCA_STORE_2BIT"); }
+        h->nd_cfg = dp;
         // digit_planes = 0 leaves the choice to the library: four planes on int8 rows (HBM-bound: the planes cost nothing there), THREE
         // on 2-bit rows, whose kernels are matrix-core bound (a quarter less work).  Round 3 ran the whole parity suite and
         // scripts/planes3_parity.py under both settings: three planes sit within 3e-7 (max|dPC|) / 5e-8 (eigenvalues) of the f64
         // checker on every shape -- closer than the f32-MFMA path (7e-7 / 2e-7).  digit_planes = 4 asks for four.
-        if (dp == 0 && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT) h->nd = 3;
+        h->nd = dp == 3 ? 3 : ((dp == 0 && h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT) ? 3 : 4);
     }
     // The kernel choice is the CALLER's (gpca_config.reserved[0..2], include/gpca.h), never the process environment's:
     // reserved[0] = GPCA_CFG_* flags, reserved[1] / reserved[2] = resident-wave targets of K1 / K2 (0 = the tuned defaults).
@@ -97,7 +100,6 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
         h->spin_sync = (flags & GPCA_CFG_NO_SPIN_SYNC) == 0;
         if (gqw) h->gq_waves_target = std::max(4, (int)gqw);
         if (gtw) h->gtt_waves_target = std::max(4, (int)gtw);
-        if (h->simple_kernels && h->nd == 3 && !(cfg && cfg->digit_planes == 3)) h->nd = 3;     // (the reference packed K2 takes either plane count)
     }
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
         delete h; return fail(nullptr, GPCA_ERR_HIP, "gpca_create: hipSetDevice/hipStreamCreate failed");
@@ -113,6 +115,7 @@ extern "C" int gpca_create(const gpca_config* cfg, gpca_handle** out) {
     // > 64 KiB of dynamic LDS is an opt-in the runtime records per device: once per handle, on this handle's device
     int e = init_device_kernels_i8();
     if (e == 0) e = init_device_kernels_common();
+    if (e == 0) e = init_device_kernels_eig();
     if (e != 0) {
         std::string m = std::string("gpca_create: cannot reserve the LDS the DMA kernels need (hipFuncSetAttribute: ") + hipGetErrorString((hipError_t)e) + ")";
         (void)hipStreamDestroy(h->st); delete h; return fail(nullptr, GPCA_ERR_HIP, m);

@@ -123,8 +123,12 @@ struct gpca_handle {
     KernelOpts ko;
     StreamState sm;
     int device = 0;
-    int precision = GPCA_PREC_F32_MFMA;
-    int storage = GPCA_STORE_INT8;
+    int precision = GPCA_PREC_I8_EXACT;
+    int storage = GPCA_STORE_INT8;         // the residency in use: GPCA_STORE_INT8 or GPCA_STORE_2BIT, never AUTO
+    int storage_cfg = GPCA_STORE_AUTO;     // what the caller asked for; AUTO is resolved by alloc_genotypes when rows arrive
+    int nd_cfg = 0;                        // gpca_config.digit_planes (0 = follow the residency)
+    int auto_pin = 0;                      // AUTO: residency forced for the allocation in progress (an int8 upload with values 2-bit codes cannot
+                                           // carry; gpca_copy_rows from a source of the other kind); 0 = follow the sample count
     hipStream_t st = nullptr;
     std::string err;
 
@@ -152,12 +156,14 @@ struct gpca_handle {
     int k = 0, l = 0, L = 0;
     bool have_rsvd = false;
     float *dQ = nullptr, *dT = nullptr, *dTb = nullptr, *dYpart = nullptr, *d_cpart = nullptr, *d_s32 = nullptr;
-    double* h_pin = nullptr;     // pinned host staging for the l x l blocks of the final eigenproblem (W | Z | flag)
+    double* h_pin = nullptr;     // pinned host staging: the result block of the device eigen step; gpca_transform's selection matrix
     int spin_sync = 1;           // busy-poll the stream at the two syncs of gpca_rsvd (GPCA_CFG_NO_SPIN_SYNC: hipStreamSynchronize)
     int* d_cholflag = nullptr;   // first failed CholeskyQR pivot + 1 (0 = ok), written by k_chol_inv
     double *d_scratch64 = nullptr, *dY = nullptr, *d_c = nullptr, *d_part64 = nullptr, *dW = nullptr, *dZ = nullptr, *d_s64 = nullptr;
     double* d_tr64 = nullptr; size_t cap_tr64 = 0;   // [N][k] compacted output of gpca_transform
     double* d_scores64 = nullptr; float* d_scores32 = nullptr; float* d_load32 = nullptr; int* d_sign = nullptr;
+    double* d_eigres = nullptr;      // [kEigResCount] result block of the device eigen step (singular values, eigenvalues, flags): read back once per call
+    double* d_cand_val = nullptr; int64_t* d_cand_idx = nullptr;   // [scores_num_parts][kMaxSketch] candidates of the scores' sign rule
     size_t cap_Q = 0, cap_T = 0, cap_Tb = 0, cap_Ypart = 0, cap_cpart = 0, cap_Y = 0, cap_part64 = 0, cap_scores = 0, cap_load = 0;
     std::vector<double> eig, sv;
     GttPlan plan{};
@@ -276,7 +282,8 @@ inline void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 inline hipError_t malloc_genotypes(const gpca_handle*, void** p, size_t bytes) { return hipMalloc(p, bytes); }
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-constexpr int kMaxSketch = 128;   // most columns (k + oversample) a sketch may have: L = 32, 64 (specialised helpers) or 128 (wide_sketch.hip)
+static_assert(gpca::kMaxSketchCols == 128, "kernels.h");
+constexpr int kMaxSketch = gpca::kMaxSketchCols;   // most columns (k + oversample) a sketch may have: L = 32, 64 (specialised helpers) or 128 (wide_sketch.hip)
 
 // ---- timing ---------------------------------------------------------------------------------------
 void fold_timings(gpca_handle* h);   // resolve pending records into per-name totals and recycle their events

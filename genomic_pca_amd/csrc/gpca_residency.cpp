@@ -17,7 +17,7 @@ void free_ws(gpca_handle* h) {
     free_eigensnp(h);
     dfree(h->dQ); dfree(h->dT); dfree(h->dTb); dfree(h->dYpart); dfree(h->d_cpart); dfree(h->d_s32); dfree(h->dY); dfree(h->d_c);
     dfree(h->d_part64); dfree(h->dW); dfree(h->dZ); dfree(h->d_s64); dfree(h->d_scores64); dfree(h->d_scores32);
-    dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_scratch64); dfree(h->d_tr64); h->cap_tr64 = 0;
+    dfree(h->d_load32); dfree(h->d_sign); dfree(h->d_eigres); dfree(h->d_cand_val); dfree(h->d_cand_idx); dfree(h->d_scratch64); dfree(h->d_tr64); h->cap_tr64 = 0;
     dfree(h->dQd); dfree(h->dTd); dfree(h->dYpart64); dfree(h->d_apart); h->cap_apart = 0; dfree(h->d_cholflag); if (h->h_pin) { (void)hipHostFree(h->h_pin); h->h_pin = nullptr; } dfree(h->d_qscale); dfree(h->d_qinv); dfree(h->d_tscale); dfree(h->d_tinv);
     dfree(h->d_amax_run); dfree(h->d_rmax); h->rmax_valid = false; dfree(h->d_yint); h->cap_yint = 0;
     h->cap_Qd = h->cap_Td = h->cap_Ypart64 = 0;
@@ -142,6 +142,11 @@ static int alloc_genotypes(gpca_handle* h, int64_t M, int64_t N, bool resident =
     free_stats(h); free_ws(h); dfree(h->dG); dfree(h->dG2);
     h->M = M; h->N = N; h->Mpad = round_up(M, kGQRowsPerWave); h->pack_flags = 0;
     h->cap_rows_pad = resident ? h->Mpad : 0;
+    if (h->storage_cfg == GPCA_STORE_AUTO) {
+        // the residency follows the rows (include/gpca.h, GPCA_STORE_AUTO): 2-bit codes from 1 024 samples on, int8 below
+        h->storage = h->auto_pin ? h->auto_pin : (N >= kSamplePad2bit ? GPCA_STORE_2BIT : GPCA_STORE_INT8);
+        if (h->nd_cfg == 0) h->nd = (h->precision == GPCA_PREC_I8_EXACT && h->storage == GPCA_STORE_2BIT) ? 3 : 4;
+    }
     if (h->storage == GPCA_STORE_2BIT) {
         h->ldg = round_up(N, kSamplePad2bit); h->ld2 = h->ldg / 4; h->ld8 = h->ldg;
         // row pitch an odd multiple of 256 B, like the int8 rows below: 1.9 % on the packed K1 (in-process A/B, both engine orders:
@@ -197,6 +202,13 @@ extern "C" int gpca_upload_genotypes_i8(gpca_handle* h, const int8_t* src, int64
         int rc = e == hipSuccess ? finish_pack_flags(h, d_flags, h->st) : GPCA_OK;
         (void)hipFree(scratch); (void)hipFree(d_flags);
         HIPCHK(e);
+        if (rc == GPCA_OK && h->storage_cfg == GPCA_STORE_AUTO && (h->pack_flags & 2u)) {
+            // AUTO chose 2-bit codes and the rows hold a value outside {0, 1, 2, -127}: codes could only store it as "missing", int8
+            // rows keep it (the statistics then see what prepare.rs:1267-1279 sees).  Once more, as int8.
+            h->auto_pin = GPCA_STORE_INT8;
+            rc = gpca_upload_genotypes_i8(h, src, M, N, ld);
+            h->auto_pin = 0;
+        }
         return rc;
     }
     if (h->ld8 != N) HIPCHK(hipMemsetAsync(h->dG, 0, (size_t)M * (size_t)h->ld8, h->st));
@@ -568,6 +580,12 @@ extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, 
     drain_pulls(dst);        // (pulls in flight on src only read it: they may go on)
     gpca_handle* h = dst;
     if (src->sm.on || (!src->dG && !src->dG2)) return fail(h, GPCA_ERR_STATE, "gpca_copy_rows: the source matrix is not resident");
+    if (dst->storage_cfg == GPCA_STORE_AUTO && dst->storage != src->storage) {      // an AUTO destination takes the source's residency
+        if (dst->sm.on) stream_close(dst);
+        dfree(dst->dG); dfree(dst->dG2); dst->cap_rows_pad = 0;
+        dst->storage = src->storage;
+        if (dst->nd_cfg == 0) dst->nd = (dst->precision == GPCA_PREC_I8_EXACT && dst->storage == GPCA_STORE_2BIT) ? 3 : 4;
+    }
     if (dst->device != src->device || dst->storage != src->storage) return fail(h, GPCA_ERR_BAD_ARG, "gpca_copy_rows: handles differ in device or storage mode");
     if (row0 < 0 || rows <= 0 || row0 + rows > src->M) return fail(h, GPCA_ERR_BAD_ARG, "gpca_copy_rows: row range outside the source matrix");
     HIPCHK(hipSetDevice(h->device));
@@ -592,7 +610,10 @@ extern "C" int gpca_copy_rows(gpca_handle* dst, gpca_handle* src, int64_t row0, 
         }
         if (new_pad > rows) HIPCHK(hipMemsetAsync((packed ? (char*)dst->dG2 : (char*)dst->dG) + (size_t)rows * pitch, 0, (size_t)(new_pad - rows) * pitch, dst->st));
     } else {
-        CHK(alloc_genotypes(dst, rows, src->N));
+        dst->auto_pin = dst->storage_cfg == GPCA_STORE_AUTO ? src->storage : 0;
+        const int arc = alloc_genotypes(dst, rows, src->N);
+        dst->auto_pin = 0;
+        CHK(arc);
     }
     if (packed) HIPCHK(hipMemcpyAsync(dst->dG2, src->dG2 + (size_t)row0 * src->ld2, (size_t)rows * src->ld2, hipMemcpyDeviceToDevice, dst->st));
     else HIPCHK(hipMemcpyAsync(dst->dG, src->dG + (size_t)row0 * src->ld8, (size_t)rows * src->ld8, hipMemcpyDeviceToDevice, dst->st));
@@ -632,6 +653,14 @@ extern "C" int gpca_get_device_memory(gpca_handle* h, int64_t* free_bytes, int64
     HIPCHK(hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = (int64_t)f;
     if (total_bytes) *total_bytes = (int64_t)t;
+    return GPCA_OK;
+}
+
+extern "C" int gpca_get_storage(gpca_handle* h, int32_t* storage, int32_t* precision) {
+    if (!h) return GPCA_ERR_BAD_ARG;
+    LOCK_SHARED(h);
+    if (storage) *storage = (h->storage_cfg == GPCA_STORE_AUTO && !have_genotypes(h)) ? GPCA_STORE_AUTO : h->storage;
+    if (precision) *precision = h->precision;
     return GPCA_OK;
 }
 

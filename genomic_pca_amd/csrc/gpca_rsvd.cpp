@@ -124,6 +124,34 @@ extern "C" int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, do
     return GPCA_OK;
 }
 
+// test hook (GPU): the device solver of gpca_rsvd (small_eig.hip) on a caller's symmetric n x n matrix, same conventions as above
+extern "C" int gpca_device_eigh_desc(gpca_handle* h, const double* a_sym, int32_t n, double* w, double* v) {
+    if (!h || !a_sym || !w || !v || n < 1 || n > kMaxSketch) return GPCA_ERR_BAD_ARG;
+    LOCK(h);
+    const int L = n <= 32 ? 32 : (n <= 64 ? 64 : kMaxSketch);
+    double *dA = nullptr, *dZz = nullptr, *dR = nullptr, *dV = nullptr;
+    std::vector<double> A((size_t)L * L, 0.0), R((size_t)kEigResCount);
+    for (int a = 0; a < n; ++a) for (int c = 0; c < n; ++c) A[(size_t)a * L + c] = a_sym[(size_t)a * n + c];
+    int rc = GPCA_OK;
+    auto run = [&]() -> int {
+        HIPCHK(hipMalloc((void**)&dA, A.size() * 8)); HIPCHK(hipMalloc((void**)&dZz, 2 * (size_t)L * n * 8));
+        HIPCHK(hipMalloc((void**)&dR, R.size() * 8)); HIPCHK(hipMalloc((void**)&dV, (size_t)n * n * 8));
+        HIPCHK(hipMemcpyAsync(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->st));
+        launch_small_eigh(h->st, dA, 0, n, L, n, 1, 1.0, nullptr, dZz, dR, dV);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(R.data(), dR, R.size() * 8, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipMemcpyAsync(v, dV, (size_t)n * n * 8, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        return GPCA_OK;
+    };
+    rc = run();
+    dfree(dA); dfree(dZz); dfree(dR); dfree(dV);
+    if (rc != GPCA_OK) return rc;
+    std::copy(R.begin() + kEigResW, R.begin() + kEigResW + n, w);
+    if (R[kEigResFlag + 1] != 0.0) return fail(h, GPCA_ERR_NOT_CONVERGED, "gpca_device_eigh_desc: the QL sweeps hit their cap");
+    return GPCA_OK;
+}
+
 // ---- rsvd stages -----------------------------------------------------------------------------------------------
 static int stage_sum_c(gpca_handle* h, int64_t parts) {
     launch_sum_partials_f32(h->st, h->d_cpart, parts, h->L, h->d_c, h->d_scratch64);
@@ -404,6 +432,8 @@ static int ensure_workspace(gpca_handle* h) {
         HIPCHK(hipMalloc((void**)&h->dZ, 2 * LL * 8));
         HIPCHK(hipHostMalloc((void**)&h->h_pin, (3 * LL + 16) * 8, hipHostMallocDefault)); HIPCHK(hipMalloc((void**)&h->d_sign, kMaxSketch * 4));
         HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
+        HIPCHK(hipMalloc((void**)&h->d_eigres, kEigResCount * 8));
+        HIPCHK(hipMalloc((void**)&h->d_cand_val, (size_t)128 * kMaxSketch * 8)); HIPCHK(hipMalloc((void**)&h->d_cand_idx, (size_t)128 * kMaxSketch * 8));
         HIPCHK(hipMalloc((void**)&h->d_cholflag, 4));
     }
     if (h->precision == GPCA_PREC_I8_EXACT) {
@@ -455,6 +485,54 @@ static int rsvd_preflight(gpca_handle* h, int32_t k, int32_t oversample, int32_t
     h->have_rsvd = false;
     CHK(ensure_workspace(h));
     HIPCHK(hipMemsetAsync(h->d_cholflag, 0, 4, h->st));
+    return GPCA_OK;
+}
+
+// ---- the small dense step and what hangs on it, enqueued without a host wait (small_eig.hip, kernels.hip) -----------------------
+// eigen-decomposition of the l x l Gram (at src: the matrix itself, or `nslices` partial sums of it) -> dZ = [Z0 | Z1] (L x k each), d_eigres
+static int enqueue_small_eigh(gpca_handle* h, const double* src, int nslices, int zmode, double denom) {
+    launch_small_eigh(h->st, src, nslices, h->l, h->L, h->k, zmode, denom, h->d_cholflag, h->dZ, h->d_eigres, nullptr);
+    HIPCHK(hipGetLastError());
+    return GPCA_OK;
+}
+// scores = Y Z0 with the sign rule (dY holds the orthonormal basis or the refined sample factor); loadings = X[pca rows] (Z1 o sign) when asked
+static int enqueue_scores_loadings(gpca_handle* h, const float* Xload, bool loadings) {
+    const int L = h->L, k = h->k;
+    const size_t zk = (size_t)L * k;
+    if (L <= 64) {
+        launch_scores(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, h->d_cand_val, h->d_cand_idx);
+        HIPCHK(hipGetLastError());
+        launch_scores_sign(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_cand_val, h->d_cand_idx, scores_num_parts(h->N), h->d_sign);
+        HIPCHK(hipGetLastError());
+        if (loadings) launch_rightmul_gather_f32(h->st, Xload, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32, h->d_sign);
+    } else {                                                     // wide sketches: the plain any-L kernels
+        launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);
+        HIPCHK(hipGetLastError());
+        launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
+        launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
+        HIPCHK(hipGetLastError());
+        if (loadings) {
+            launch_scale_cols(h->st, h->dZ + zk, (float*)nullptr, L, k, h->d_sign);
+            launch_rightmul_gather_f32(h->st, Xload, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return GPCA_OK;
+}
+// the call's host wait: the result block comes back through pinned staging behind everything enqueued so far.  take = false: wait only.
+static int finish_small_eigh(gpca_handle* h, bool take) {
+    double* res = h->h_pin;
+    HIPCHK(hipMemcpyAsync(res, h->d_eigres, sizeof(double) * kEigResCount, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(stream_wait(h));
+    if (!take) return GPCA_OK;
+    const int flag = (int)res[kEigResFlag];
+    if (flag) {   // (computed redundantly on the replicated Y: the same on every rank)
+        char buf[160];
+        snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not finite (overflow or NaN in the sketch)", flag - 1, h->l);
+        return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
+    }
+    h->sv.assign(res + kEigResSv, res + kEigResSv + h->l);
+    h->eig.assign(res + kEigResEig, res + kEigResEig + h->k);
     return GPCA_OK;
 }
 
@@ -595,13 +673,15 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
         EXCHANGE(h->dY, h->N * (int64_t)L);
         LOCAL(stage_orth(h, it + 1 == power_iters ? 2 : 1));
     }
-    // 3. projection B = A Q, small eigenproblem of B^T B
+    // 3. projection B = A Q, the l x l eigenproblem of B^T B, scores, loadings: all enqueued, no host step in between.
     LOCAL(stage_AQ(h, 0));
+    const double* gsrc = h->dW; int gslices = 0;
     auto gram_b = [&]() -> int {
         const int64_t parts = gram_num_parts(h->M);
         launch_gram_f32(h->st, h->dT, h->M, L, h->d_part64);
         HIPCHK(hipGetLastError());
-        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
+        if (mr) launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);      // the exchange needs the rank's sum in one place
+        else launch_sum_partials_f64_stage1(h->st, h->d_part64, parts, (int64_t)L * L, h->d_scratch64, &gsrc, &gslices);   // (the eigen kernel folds the slices)
         HIPCHK(hipGetLastError());
         return GPCA_OK;
     };
@@ -614,31 +694,22 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
             lrc = fail(h, GPCA_ERR_HIP, "gpca_rsvd: status copy failed");
     }
     EXCHANGE(h->dW, (int64_t)L * L + (mr ? 16 : 0));
-    // The only host step: the l x l eigenproblem.  Pinned staging + a busy-polled stream keep the round trip short
-    // (pageable copies and a sleeping hipStreamSynchronize cost ~220 us here); everything after it is enqueued at once.
-    std::vector<double> C((size_t)l * l), V((size_t)l * l), w((size_t)l);
-    double* Wfull = h->h_pin;
-    double* Zpin = h->h_pin + (size_t)kMaxSketch * kMaxSketch;                    // [scores Z (L x k) | loadings Z (L x k)]
-    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * (size_t)kMaxSketch * kMaxSketch);
-    bool status_here = false;     // the summed status slots have landed in h_status[16..32)
-    auto fetch_w = [&]() -> int {
-        HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
-        if (mr) HIPCHK(hipMemcpyAsync(h->h_status + 16, h->dW + (size_t)L * L, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-        HIPCHK(hipMemcpyAsync(flagpin, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
-        HIPCHK(stream_wait(h));
-        status_here = true;
-        if (*flagpin) {   // (computed redundantly on the replicated Y: the same on every rank)
-            char buf[160];
-            snprintf(buf, sizeof buf, "CholeskyQR: pivot %d of the %d-column sketch is not finite (overflow or NaN in the sketch)", *flagpin - 1, l);
-            return fail(h, GPCA_ERR_NOT_CONVERGED, buf);
-        }
-        return GPCA_OK;
+    // variance over the samples that took part: all N, or the subset of gpca_set_sample_mask (the other rows of the sketch are zero)
+    const double n_eff = h->d_smask ? (double)h->n_smask : (double)h->N;
+    // 4. C = V diag(w) V^T on the device (small_eig.hip); scores = Q V_k diag(s), sign (largest |score| positive), loadings = B V_k diag(sign / s)
+    auto tail = [&]() -> int {
+        CHK(enqueue_small_eigh(h, gsrc, gslices, 0, n_eff - 1.0));
+        return enqueue_scores_loadings(h, h->dT, true);
     };
-    LOCAL(fetch_w());
+    LOCAL(tail());
+    // The call's one host wait: singular values, eigenvalues, the pivot flag and (sharded runs) the agreed status arrive together.
+    if (mr && hipMemcpyAsync(h->h_status + 16, h->dW + (size_t)L * L, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st) != hipSuccess)
+        return lrc != GPCA_OK ? lrc : fail(h, GPCA_ERR_HIP, "gpca_rsvd: status fetch failed");
+    {
+        const int frc = finish_small_eigh(h, lrc == GPCA_OK);      // (waits for the stream; a rank that failed earlier only waits)
+        if (lrc == GPCA_OK) lrc = frc;
+    }
     if (mr) {
-        // a rank that failed earlier skipped the fetch: it still reads what the ranks agreed on
-        if (!status_here && (hipMemcpyAsync(h->h_status + 16, h->dW + (size_t)L * L, 16 * sizeof(double), hipMemcpyDeviceToHost, h->st) != hipSuccess ||
-                             stream_wait(h) != hipSuccess)) return lrc != GPCA_OK ? lrc : fail(h, GPCA_ERR_HIP, "gpca_rsvd: status fetch failed");
         const std::string own_now = h->err;
         const int agreed = status_verdict(h, h->h_status + 16, lrc, h->status_own, "gpca_rsvd (after the last exchange)");
         if (agreed != GPCA_OK) return agreed;
@@ -647,32 +718,6 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     if (lrc != GPCA_OK) return lrc;
 #undef LOCAL
 #undef EXCHANGE
-    for (int a2 = 0; a2 < l; ++a2) for (int c = 0; c < l; ++c) C[(size_t)a2 * l + c] = 0.5 * (Wfull[(size_t)a2 * L + c] + Wfull[(size_t)c * L + a2]);
-    host_eigh_desc(C, V, w, l);
-    h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
-    for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
-    // variance over the samples that took part: all N, or the subset of gpca_set_sample_mask (the other rows of the sketch are zero)
-    const double n_eff = h->d_smask ? (double)h->n_smask : (double)h->N;
-    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (n_eff - 1.0);
-    // 4. scores = Q V_k diag(s) ; sign ; loadings = B V_k diag(sign/s)   (the sign is applied to the loadings' Z on the device)
-    const size_t zk = (size_t)L * k;
-    for (size_t e = 0; e < 2 * zk; ++e) Zpin[e] = 0.0;
-    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) {
-        Zpin[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
-        Zpin[zk + (size_t)j * k + c] = h->sv[(size_t)c] > 0 ? V[(size_t)j * l + c] / h->sv[(size_t)c] : 0.0;
-    }
-    HIPCHK(hipMemcpyAsync(h->dZ, Zpin, sizeof(double) * 2 * zk, hipMemcpyHostToDevice, h->st));
-    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);   // dY = Q in f64
-    HIPCHK(hipGetLastError());
-    launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
-    HIPCHK(hipGetLastError());
-    launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
-    HIPCHK(hipGetLastError());
-    launch_scale_cols(h->st, h->dZ + zk, (float*)nullptr, L, k, h->d_sign);
-    HIPCHK(hipGetLastError());
-    launch_rightmul_gather_f32(h->st, h->dT, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);
-    HIPCHK(hipGetLastError());
-    HIPCHK(stream_wait(h));
     h->have_rsvd = true; h->loadings_valid = true;
     return GPCA_OK;
 }
@@ -849,22 +894,6 @@ static int prep_custom_T(gpca_handle* h) {
     return stage_sum_c(h, omega_num_parts(h->Mpad));
 }
 
-// l x l Gram of a tall factor -> host eigen-decomposition (descending); leaves V (l x l, columns) and w
-static int small_eigen(gpca_handle* h, int l, std::vector<double>& V, std::vector<double>& w) {
-    const int L = h->L;
-    double* Wfull = h->h_pin;
-    int* flagpin = reinterpret_cast<int*>(h->h_pin + 3 * (size_t)kMaxSketch * kMaxSketch);
-    HIPCHK(hipMemcpyAsync(Wfull, h->dW, sizeof(double) * L * L, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(hipMemcpyAsync(flagpin, h->d_cholflag, 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(stream_wait(h));
-    if (*flagpin) return fail(h, GPCA_ERR_NOT_CONVERGED, "CholeskyQR: a pivot of the sketch is not finite (overflow or NaN in the sketch)");
-    std::vector<double> C((size_t)l * l);
-    V.assign((size_t)l * l, 0.0); w.assign((size_t)l, 0.0);
-    for (int a = 0; a < l; ++a) for (int c = 0; c < l; ++c) C[(size_t)a * l + c] = 0.5 * (Wfull[(size_t)a * L + c] + Wfull[(size_t)c * L + a]);
-    host_eigh_desc(C, V, w, l);
-    return GPCA_OK;
-}
-
 // Initial global PCs from the row-standardised condensed features C* = W^T X (never formed): randomized PCA of C* with its
 // products factored through the genotype GEMMs -- C*^T Z = A^T (W Z), C* Q = W^T (A Q).  Leaves the N x k sample scores
 // (gpca_get_scores / _f64) and the eigenvalues of C*; loadings are not defined for this call.
@@ -907,24 +936,12 @@ extern "C" int gpca_rsvd_condensed(gpca_handle* h, int32_t k, int32_t oversample
     CHK(through_W_forward());
     launch_gram_f64(h->st, h->dP, R, L, h->d_part64);
     HIPCHK(hipGetLastError());
-    launch_sum_partials_f64(h->st, h->d_part64, gram_num_parts(R), (int64_t)L * L, h->dW, h->d_scratch64);
+    const double* gsrc = nullptr; int gslices = 0;
+    launch_sum_partials_f64_stage1(h->st, h->d_part64, gram_num_parts(R), (int64_t)L * L, h->d_scratch64, &gsrc, &gslices);
     HIPCHK(hipGetLastError());
-    std::vector<double> V, w;
-    CHK(small_eigen(h, l, V, w));
-    h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
-    for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
-    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
-    double* Zpin = h->h_pin + (size_t)kMaxSketch * kMaxSketch;
-    const size_t zk = (size_t)L * k;
-    for (size_t e = 0; e < zk; ++e) Zpin[e] = 0.0;
-    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Zpin[(size_t)j * k + c] = V[(size_t)j * l + c] * h->sv[(size_t)c];
-    HIPCHK(hipMemcpyAsync(h->dZ, Zpin, sizeof(double) * zk, hipMemcpyHostToDevice, h->st));
-    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);     // scores = Q V diag(s)
-    HIPCHK(hipGetLastError());
-    launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
-    launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
-    HIPCHK(hipGetLastError());
-    HIPCHK(stream_wait(h));
+    CHK(enqueue_small_eigh(h, gsrc, gslices, 0, (double)(h->N - 1)));      // scores = Q V diag(s), eigenvalues of C*
+    CHK(enqueue_scores_loadings(h, nullptr, false));
+    CHK(finish_small_eigh(h, true));
     h->have_rsvd = true; h->loadings_valid = false; h->rsvd_on_child = false;
     return GPCA_OK;
 }
@@ -967,27 +984,12 @@ extern "C" int gpca_refine(gpca_handle* h, const double* S0, int32_t k) {
     CHK(stage_AtT_local(h));                              // dY = S = A^T L   (N x L f64)
     launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
     HIPCHK(hipGetLastError());
-    launch_sum_partials_f64(h->st, h->d_part64, gram_num_parts(h->N), (int64_t)L * L, h->dW, h->d_scratch64);
+    const double* gsrc = nullptr; int gslices = 0;
+    launch_sum_partials_f64_stage1(h->st, h->d_part64, gram_num_parts(h->N), (int64_t)L * L, h->d_scratch64, &gsrc, &gslices);
     HIPCHK(hipGetLastError());
-    std::vector<double> V, w;
-    CHK(small_eigen(h, l, V, w));
-    h->sv.assign((size_t)l, 0.0); h->eig.assign((size_t)k, 0.0);
-    for (int j = 0; j < l; ++j) h->sv[(size_t)j] = w[(size_t)j] > 0 ? std::sqrt(w[(size_t)j]) : 0.0;
-    for (int c = 0; c < k; ++c) h->eig[(size_t)c] = w[(size_t)c] / (double)(h->N - 1);
-    double* Zpin = h->h_pin + (size_t)kMaxSketch * kMaxSketch;
-    const size_t zk = (size_t)L * k;
-    for (size_t e = 0; e < 2 * zk; ++e) Zpin[e] = 0.0;
-    for (int j = 0; j < l; ++j) for (int c = 0; c < k; ++c) Zpin[(size_t)j * k + c] = Zpin[zk + (size_t)j * k + c] = V[(size_t)j * l + c];
-    HIPCHK(hipMemcpyAsync(h->dZ, Zpin, sizeof(double) * 2 * zk, hipMemcpyHostToDevice, h->st));
-    launch_rightmul_f64(h->st, h->dY, h->N, L, h->dZ, k, h->d_scores64, (float*)nullptr);             // scores = S W
-    HIPCHK(hipGetLastError());
-    launch_col_sign(h->st, h->d_scores64, h->N, k, h->d_sign);
-    launch_scale_cols(h->st, h->d_scores64, h->d_scores32, h->N, k, h->d_sign);
-    launch_scale_cols(h->st, h->dZ + zk, (float*)nullptr, L, k, h->d_sign);
-    HIPCHK(hipGetLastError());
-    launch_rightmul_gather_f32(h->st, h->d_lqr, h->d_pca_rows, h->n_pca, L, h->dZ + zk, k, h->d_load32);   // loadings = L W
-    HIPCHK(hipGetLastError());
-    HIPCHK(stream_wait(h));
+    CHK(enqueue_small_eigh(h, gsrc, gslices, 1, (double)(h->N - 1)));      // S^T S = W Sigma^2 W^T: scores = S W, loadings = L W
+    CHK(enqueue_scores_loadings(h, h->d_lqr, true));
+    CHK(finish_small_eigh(h, true));
     h->have_rsvd = true; h->loadings_valid = true; h->rsvd_on_child = false;
     return GPCA_OK;
 }

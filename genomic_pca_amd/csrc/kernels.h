@@ -23,6 +23,20 @@ struct KernelOpts {
 // Return a hipError_t value (0 = ok).
 int init_device_kernels_i8();
 int init_device_kernels_common();
+int init_device_kernels_eig();
+
+// ---- the small dense step on the device (small_eig.hip) ----------------------------------------------------------------------
+constexpr int kMaxSketchCols = 128;                  // = kMaxSketch (gpca_internal.h)
+// layout of the result block `res` of launch_small_eigh (doubles): what the host reads back ONCE, at the end of the call
+constexpr int kEigResSv = 0;                         // [128] singular values sqrt(max(w, 0)), descending
+constexpr int kEigResEig = kMaxSketchCols;           // [128] w_c / denom for c < k
+constexpr int kEigResW = 2 * kMaxSketchCols;         // [128] eigenvalues w, descending
+constexpr int kEigResFlag = 3 * kMaxSketchCols;      // [0] the CholeskyQR pivot flag, [1] QL sweep cap hit
+constexpr int kEigResCount = 3 * kMaxSketchCols + 8;
+// Symmetric eigenproblem of the leading n x n block of W (pitch L; nslices > 0: W = the sum of `nslices` partial matrices [L * L] apart),
+// symmetrised; descending.  Z [2][L][k]: zmode 0 -> Z0 = V_k diag(sv), Z1 = V_k diag(1 / sv); zmode 1 -> Z0 = Z1 = V_k.  Vout may be NULL.
+void launch_small_eigh(hipStream_t st, const double* src, int nslices, int n, int L, int k, int zmode, double denom, const int* cholflag,
+                       double* Z, double* res, double* Vout);
 
 // Blocked layouts of the skinny GEMM operands (gemm_f32.hip): a lane's 8 / 16 k-steps are contiguous.
 //   Tb [group = row/16][lt][lane = 32*(row&1) + col%32][u = (row%16)/2]      (8 floats per lane)
@@ -96,6 +110,9 @@ void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, in
 constexpr int64_t kSumScratchElems = 64 * 4096;
 void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out, double* scratch);
 void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out, double* scratch);
+// first stage only: *slices partial sums of [E] doubles at *src, for a consumer that folds the (<= 64, or <= 256 for E <= 64) slices
+// itself (launch_small_eigh, k_chol_inv); P <= 64 parts are their own slices and nothing is launched
+void launch_sum_partials_f64_stage1(hipStream_t st, const double* part, int64_t P, int64_t E, double* scratch, const double** src, int* slices);
 int64_t gram_num_parts(int64_t rows);
 void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part);
 void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part);
@@ -118,9 +135,17 @@ void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, 
 // out[n][kc] = sum_j X[n][j] Z[j][kc]   (Z: [L][K] f64)
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
                          float* out32);
-// rows gathered through an index list (loadings of kept SNPs)
+// rows gathered through an index list (loadings of kept SNPs); sign (may be NULL): column c of Z is multiplied by sign[c]
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
-                                const double* Z, int K, float* out32);
+                                const double* Z, int K, float* out32, const int* sign = nullptr);
+// Sample scores with their sign rule in two launches (L <= 64): launch_scores writes the unsigned scores X Z and, per workgroup and
+// column, the first row with maximal |score| (value + row: scores_num_parts(rows) candidates); launch_scores_sign folds the candidates
+// (every workgroup for itself: they are few), flips the columns whose winner is negative (in place, plus the f32 copy) and leaves
+// sign[c] = +-1 for the loadings.
+int64_t scores_num_parts(int64_t rows);
+void launch_scores(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64, double* cand_val, int64_t* cand_idx);
+void launch_scores_sign(hipStream_t st, double* out64, float* out32, int64_t rows, int K, const double* cand_val, const int64_t* cand_idx,
+                        int64_t parts, int* sign);
 int64_t colsum_num_parts(int64_t rows);
 void launch_colsum_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part);
 // sign[c] = sign of the first element of column c with maximal |x|

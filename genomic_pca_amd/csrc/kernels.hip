@@ -639,6 +639,12 @@ void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64
 void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out, double* scratch) {
     launch_sum_partials_t<double>(st, part, P, E, out, scratch);
 }
+void launch_sum_partials_f64_stage1(hipStream_t st, const double* part, int64_t P, int64_t E, double* scratch, const double** src, int* slices) {
+    const int S = sum_slices(P, E);
+    if (S == 1) { *src = part; *slices = (int)P; return; }      // (P <= 64: the parts are the slices)
+    hipLaunchKernelGGL((k_sum_partials<double>), dim3((unsigned)((E + 63) / 64), S), dim3(256), 0, st, part, P, E, scratch, S);
+    *src = scratch; *slices = S;
+}
 
 // Gram: part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c]  (f64 accumulate).
 // 256 threads = 4 row-groups x 64 threads; a thread owns a 4x4 (L=32) or 8x8 (L=64) patch of the L x L output and walks
@@ -1037,18 +1043,18 @@ void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, c
 template <int L, int NJ>
 __global__ __launch_bounds__(256) void k_rightmul_mfma(const float* __restrict__ X, const int64_t* __restrict__ row_ids,
                                                        int64_t nrows, const double* __restrict__ Z, int K,
-                                                       float* __restrict__ out32, int64_t tiles_per_wave) {
+                                                       float* __restrict__ out32, int64_t tiles_per_wave, const int* __restrict__ sign) {
     constexpr int E = L / 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     double zb[E][NJ];
 #pragma unroll
-    for (int s2 = 0; s2 < E; ++s2)
+    for (int jt = 0; jt < NJ; ++jt) {
+        const int col = 16 * jt + i;
+        const double sg = (sign && col < K) ? (double)sign[col] : 1.0;      // (+-1: exact)
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            const int col = 16 * jt + i;
-            zb[s2][jt] = col < K ? Z[(E * kq + s2) * K + col] : 0.0;
-        }
+        for (int s2 = 0; s2 < E; ++s2) zb[s2][jt] = col < K ? Z[(E * kq + s2) * K + col] * sg : 0.0;
+    }
     __shared__ float osm[4][16 * 64];                   // per-wave output tile, written back as one contiguous run
     const int64_t ntiles = (nrows + 15) >> 4;
     const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * tiles_per_wave;
@@ -1095,19 +1101,112 @@ __global__ __launch_bounds__(256) void k_rightmul_mfma(const float* __restrict__
     }
 }
 void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L,
-                                const double* Z, int K, float* out32) {
+                                const double* Z, int K, float* out32, const int* sign) {
     if (nrows == 0) return;
-    if (L > 64) { launch_rightmul_any_gather_f32(st, X, row_ids, nrows, L, Z, K, out32); return; }
+    if (L > 64) { launch_rightmul_any_gather_f32(st, X, row_ids, nrows, L, Z, K, out32); return; }      // (wide sketches: the caller scales Z by the sign first)
     const int64_t ntiles = (nrows + 15) / 16;
     int64_t tpw = ntiles / (4 * 2048);            // ~2048 workgroups, at least one tile per wave
     if (tpw < 1) tpw = 1;
     const int64_t waves = (ntiles + tpw - 1) / tpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
     const int nj = (K + 15) / 16;
-#define GPCA_RM(LL, NN) hipLaunchKernelGGL((k_rightmul_mfma<LL, NN>), grid, blk, 0, st, X, row_ids, nrows, Z, K, out32, tpw)
+#define GPCA_RM(LL, NN) hipLaunchKernelGGL((k_rightmul_mfma<LL, NN>), grid, blk, 0, st, X, row_ids, nrows, Z, K, out32, tpw, sign)
     if (L == 32) { if (nj == 1) GPCA_RM(32, 1); else if (nj == 2) GPCA_RM(32, 2); else if (nj == 3) GPCA_RM(32, 3); else GPCA_RM(32, 4); }
     else { if (nj == 1) GPCA_RM(64, 1); else if (nj == 2) GPCA_RM(64, 2); else if (nj == 3) GPCA_RM(64, 3); else GPCA_RM(64, 4); }
 #undef GPCA_RM
+}
+
+// ---- sample scores and their sign rule (L <= 64) ---------------------------------------------------------------------------
+// scores = X Z (X = the orthonormal basis, f64 [rows][L]; Z [L][K]); a column's sign is fixed so that its entry of largest
+// magnitude is positive (the first such row on a tie).  k_scores writes the unsigned product and one candidate per workgroup and
+// column -- the workgroups walk 256-row chunks with a stride, at most kScoreParts of them, so the consumer's fold stays small at any
+// sample count; k_scores_sign folds the candidates in workgroup order (ascending rows within a workgroup's chunks, so "first row"
+// needs the row index, not the fold order), applies the sign in place and writes the f32 copy.  Replaces k_rightmul + k_col_sign
+// (one workgroup per column walking all rows: 17 us) + 2 x k_scale_cols.
+constexpr int kScoreParts = 128;
+int64_t scores_num_parts(int64_t rows) { const int64_t c = (rows + 255) / 256; return c < kScoreParts ? (c < 1 ? 1 : c) : kScoreParts; }
+template <int L>
+__global__ __launch_bounds__(256) void k_scores(const double* __restrict__ X, int64_t nrows, const double* __restrict__ Z, int K,
+                                                double* __restrict__ out64, double* __restrict__ cand_val, int64_t* __restrict__ cand_idx) {
+    extern __shared__ double zsc[];                       // Z [L][K], then per-wave winners: val [4][K], idx [4][K]
+    double* wval = zsc + L * K;
+    long long* widx = reinterpret_cast<long long*>(wval + 4 * K);
+    for (int e = threadIdx.x; e < L * K; e += 256) zsc[e] = Z[e];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    const int64_t nchunks = (nrows + 255) / 256;
+    for (int kc = threadIdx.x; kc < 4 * K; kc += 256) { wval[kc] = 0.0; widx[kc] = -1; }
+    __syncthreads();
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t n = chunk * 256 + threadIdx.x;
+        const bool live = n < nrows;
+        double x[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) x[j] = live ? X[n * L + j] : 0.0;
+        for (int kc = 0; kc < K; ++kc) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; ++j) a += x[j] * zsc[j * K + kc];
+            if (live) out64[n * K + kc] = a;
+            // the wave's winner of this column: largest |a|, lowest row on a tie
+            double bv = live ? a : 0.0; long long bi = live ? (long long)n : -1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(bv, o); const long long oi = __shfl_xor(bi, o);
+                const bool take = oi >= 0 && (bi < 0 || fabs(ov) > fabs(bv) || (fabs(ov) == fabs(bv) && oi < bi));
+                bv = take ? ov : bv; bi = take ? oi : bi;
+            }
+            if (lane == 0 && bi >= 0) {                    // against the wave's winner of earlier chunks (lower rows: they keep a tie)
+                const long long ci = widx[wv * K + kc];
+                if (ci < 0 || fabs(bv) > fabs(wval[wv * K + kc])) { wval[wv * K + kc] = bv; widx[wv * K + kc] = bi; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int kc = threadIdx.x; kc < K; kc += 256) {
+        double bv = 0.0; long long bi = -1;
+        for (int w = 0; w < 4; ++w) {
+            const double ov = wval[w * K + kc]; const long long oi = widx[w * K + kc];
+            const bool take = oi >= 0 && (bi < 0 || fabs(ov) > fabs(bv) || (fabs(ov) == fabs(bv) && oi < bi));
+            bv = take ? ov : bv; bi = take ? oi : bi;
+        }
+        cand_val[(int64_t)blockIdx.x * K + kc] = bv; cand_idx[(int64_t)blockIdx.x * K + kc] = bi;
+    }
+}
+__global__ __launch_bounds__(256) void k_scores_sign(double* __restrict__ X64, float* __restrict__ X32, int64_t total, int K,
+                                                     const double* __restrict__ cand_val, const int64_t* __restrict__ cand_idx, int parts,
+                                                     int* __restrict__ sign) {
+    __shared__ int sg[kMaxSketchCols];
+    for (int kc = threadIdx.x; kc < K; kc += 256) {
+        double bv = 0.0; long long bi = -1;
+        for (int p = 0; p < parts; ++p) {
+            const double ov = cand_val[(int64_t)p * K + kc]; const long long oi = cand_idx[(int64_t)p * K + kc];
+            const bool take = oi >= 0 && (bi < 0 || fabs(ov) > fabs(bv) || (fabs(ov) == fabs(bv) && oi < bi));
+            bv = take ? ov : bv; bi = take ? oi : bi;
+        }
+        const int s1 = (bi >= 0 && bv < 0.0) ? -1 : 1;
+        sg[kc] = s1;
+        if (blockIdx.x == 0) sign[kc] = s1;
+    }
+    __syncthreads();
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const double v = X64[t] * (double)sg[t % K];
+        X64[t] = v;
+        if (X32) X32[t] = (float)v;
+    }
+}
+void launch_scores(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64, double* cand_val, int64_t* cand_idx) {
+    const dim3 grid((unsigned)scores_num_parts(rows)), blk(256);
+    const size_t lds = sizeof(double) * ((size_t)L * K + 4 * (size_t)K) + sizeof(long long) * 4 * (size_t)K;
+    if (L == 32) hipLaunchKernelGGL((k_scores<32>), grid, blk, lds, st, X, rows, Z, K, out64, cand_val, cand_idx);
+    else hipLaunchKernelGGL((k_scores<64>), grid, blk, lds, st, X, rows, Z, K, out64, cand_val, cand_idx);
+}
+void launch_scores_sign(hipStream_t st, double* out64, float* out32, int64_t rows, int K, const double* cand_val, const int64_t* cand_idx,
+                        int64_t parts, int* sign) {
+    const int64_t total = rows * K;
+    int64_t blocks = (total + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);      // (every workgroup folds the candidates: keep them few)
+    hipLaunchKernelGGL(k_scores_sign, dim3((unsigned)blocks), dim3(256), 0, st, out64, out32, total, K, cand_val, cand_idx, (int)parts, sign);
 }
 
 constexpr int kColsumRowsPerBlock = 256;

@@ -252,6 +252,12 @@ class GpcaEngine:
         self._chk(self._lib.gpca_download_genotypes_i8(self._h, _vp(out), N))
         return out
 
+    def storage_in_use(self):
+        """(storage, precision) the handle runs with: STORE_AUTO resolves to STORE_2BIT / STORE_INT8 when the genotypes arrive."""
+        st, pr = C.c_int32(), C.c_int32()
+        self._chk(self._lib.gpca_get_storage(self._h, C.byref(st), C.byref(pr)))
+        return st.value, pr.value
+
     def dims(self):
         M, N = C.c_int64(), C.c_int64()
         self._chk(self._lib.gpca_dims(self._h, C.byref(M), C.byref(N)))

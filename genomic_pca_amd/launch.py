@@ -15,35 +15,98 @@ Two ways in, one code path for the ranks (`from_env`):
 The reference has no multi-process mode (one process, rayon: main.rs:100-106); this is the launcher of the build's own row shards."""
 from __future__ import annotations
 
+import hashlib
 import os
+import socket
+import stat
+import struct
 import subprocess
 import sys
+import tempfile
 import threading
 import time
-from multiprocessing.connection import Client, Listener
+from multiprocessing import AuthenticationError
+from multiprocessing.connection import Client, Connection, answer_challenge, deliver_challenge
 from typing import Any, Callable, List, Optional, Sequence
 
 import numpy as np
 
 _ENV = "GPCA_RDZV"
+_ENV_KEY = "GPCA_RDZV_KEY"       # hex of the run's random authkey, handed to the ranks by run_ranks (never derivable from the address)
 _ERR = "__gpca_rdzv_peer_lost__"
 
 
-def _authkey(address: str) -> bytes:
-    return ("gpca:" + address).encode()
+def _derived_key(address: str) -> bytes:
+    """Handshake key when no parent handed one out (ranks started by torch.distributed.run).  NOT a secret: what keeps other
+    users out in that mode is the socket's home -- a directory only this user can enter -- and the peer-credential check."""
+    return hashlib.sha256(("gpca:" + address).encode()).digest()
+
+
+def _private_dir() -> str:
+    """A directory only this user can enter (0700, owned by us), for the rendezvous socket of ranks that have no parent of ours."""
+    base = os.environ.get("XDG_RUNTIME_DIR") or tempfile.gettempdir()
+    d = os.path.join(base, "gpca-rdzv-%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f"rendezvous: {d} is not a private directory of uid {os.getuid()} (mode {oct(st.st_mode & 0o777)})")
+    return d
 
 
 class Hub:
     """Serves all-gather rounds to `world` clients: every round it takes one message from each rank and answers all of them
-    with the list.  A rank that goes away ends the service: the ranks still waiting receive an error marker."""
+    with the list.  A rank that goes away ends the service: the ranks still waiting receive an error marker.
 
-    def __init__(self, world: int, address: Optional[str] = None):
+    Messages are pickles, so who may connect matters (an abstract socket has no file permissions and is listed in /proc/net/unix):
+      * every accepted connection must come from a process of THIS user (SO_PEERCRED), else it is closed and counted;
+      * then the multiprocessing challenge with the run's key: 32 random bytes that run_ranks hands to its children in
+        the environment; ranks started by someone else (torch.distributed.run) use a filesystem socket inside a 0700 directory
+        instead, with a key derived from its path;
+      * a connection that fails either test is dropped, reported on stderr and never ends the service."""
+
+    def __init__(self, world: int, address: Optional[str] = None, authkey: Optional[bytes] = None):
         self.world = world
         self.address = address or ("\0gpca-rdzv-%d-%d" % (os.getpid(), time.monotonic_ns()))
-        self._listener = Listener(self.address, family="AF_UNIX", backlog=max(8, world), authkey=_authkey(self.address))
+        self.authkey = authkey if authkey is not None else (os.urandom(32) if address is None else _derived_key(self.address))
+        self._sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        if not self.address.startswith("\0"):
+            try:
+                if stat.S_ISSOCK(os.lstat(self.address).st_mode):      # a stale socket of an earlier run of ours (the directory is private)
+                    os.unlink(self.address)
+            except FileNotFoundError:
+                pass
+        self._sock.bind(self.address)
+        self._sock.listen(max(8, world))
         self._thread: Optional[threading.Thread] = None
         self.rounds = 0
+        self.rejected = 0                    # connections turned away (foreign uid, failed challenge, bad announcement)
         self.lost: Optional[int] = None      # rank whose connection ended inside a round
+
+    def _accept(self) -> Any:
+        """One authenticated connection of this user, or None for one that was turned away."""
+        s, _ = self._sock.accept()
+        try:
+            _pid, uid, _gid = struct.unpack("3i", s.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+        except OSError:
+            uid = -1
+        if uid != os.getuid():
+            s.close()
+            self.rejected += 1
+            print(f"gpca rendezvous: turned away a connection from uid {uid} (hub of uid {os.getuid()})", file=sys.stderr, flush=True)
+            return None
+        c = Connection(s.detach())
+        try:
+            deliver_challenge(c, self.authkey)
+            answer_challenge(c, self.authkey)
+        except (AuthenticationError, EOFError, OSError) as e:
+            c.close()
+            self.rejected += 1
+            print(f"gpca rendezvous: turned away a connection that failed the key challenge ({type(e).__name__})", file=sys.stderr, flush=True)
+            return None
+        return c
 
     def start(self) -> "Hub":
         self._thread = threading.Thread(target=self.serve, name="gpca-rdzv-hub", daemon=True)
@@ -53,12 +116,19 @@ class Hub:
     def serve(self) -> None:
         conns: List[Any] = [None] * self.world
         try:
-            for _ in range(self.world):
-                c = self._listener.accept()
-                r = c.recv()
-                if not isinstance(r, int) or not (0 <= r < self.world) or conns[r] is not None:
+            while any(c is None for c in conns):
+                c = self._accept()
+                if c is None:
+                    continue
+                try:
+                    r = c.recv()
+                except (EOFError, OSError):
+                    r = None
+                if not isinstance(r, int) or isinstance(r, bool) or not (0 <= r < self.world) or conns[r] is not None:
                     c.close()
-                    raise RuntimeError(f"rendezvous: unexpected rank announcement {r!r}")
+                    self.rejected += 1
+                    print(f"gpca rendezvous: turned away a connection with the rank announcement {r!r}", file=sys.stderr, flush=True)
+                    continue
                 conns[r] = c
             while True:
                 msgs = []
@@ -76,7 +146,7 @@ class Hub:
                 self.rounds += 1
         except EOFError:
             pass
-        except Exception:                          # noqa: BLE001  (listener closed under us at shutdown)
+        except OSError:                            # the listening socket was closed under us: shutdown
             pass
         finally:
             for c in conns:
@@ -90,28 +160,31 @@ class Hub:
                         c.close()
                     except Exception:              # noqa: BLE001
                         pass
-            try:
-                self._listener.close()
-            except Exception:                      # noqa: BLE001
-                pass
+            self.close()
 
     def close(self) -> None:
         try:
-            self._listener.close()
-        except Exception:                          # noqa: BLE001
+            self._sock.close()
+        except OSError:
             pass
+        if not self.address.startswith("\0"):
+            try:
+                os.unlink(self.address)
+            except OSError:
+                pass
 
 
 class Rendezvous:
     """A rank's end of the hub.  Every method is a collective: all `world` ranks must call it, in the same order."""
 
-    def __init__(self, address: str, rank: int, world: int, connect_timeout_s: float = 180.0):
+    def __init__(self, address: str, rank: int, world: int, connect_timeout_s: float = 180.0, authkey: Optional[bytes] = None):
         self.rank, self.world, self.address = rank, world, address
+        key = authkey if authkey is not None else _derived_key(address)
         t_end = time.monotonic() + connect_timeout_s
         last: Optional[Exception] = None
         while True:
             try:
-                self._c = Client(address, family="AF_UNIX", authkey=_authkey(address))
+                self._c = Client(address, family="AF_UNIX", authkey=key)
                 break
             except (FileNotFoundError, ConnectionRefusedError, OSError) as e:   # the hub (rank 0 under torchrun) is not up yet
                 last = e
@@ -169,10 +242,15 @@ def from_env(environ=os.environ) -> Optional[Rendezvous]:
     rank = int(environ.get("RANK", "0"))
     addr = environ.get(_ENV)
     if addr:
-        return Rendezvous(addr.replace("@", "\0", 1) if addr.startswith("@") else addr, rank, world)
+        key = environ.get(_ENV_KEY)
+        return Rendezvous(addr.replace("@", "\0", 1) if addr.startswith("@") else addr, rank, world, authkey=bytes.fromhex(key) if key else None)
     if world <= 1:
         return None
-    addr = "\0gpca-rdzv-%s-%s" % (environ.get("MASTER_PORT", "0"), environ.get("TORCHELASTIC_RUN_ID", "none"))
+    # no parent of ours: a filesystem socket in a directory only this user can enter (an abstract name built from MASTER_PORT and
+    # the run id could be guessed -- and connected to -- by any local user)
+    name = "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in
+                   "%s-%s" % (environ.get("MASTER_PORT", "0"), environ.get("TORCHELASTIC_RUN_ID", "none")))[:64]
+    addr = os.path.join(_private_dir(), name + ".sock")
     if rank == 0 and _env_hub is None:
         _env_hub = Hub(world, addr).start()
     return Rendezvous(addr, rank, world)
@@ -189,7 +267,12 @@ def run_ranks(world: int, argv: Sequence[str], env_extra: Optional[dict] = None,
             env = dict(os.environ)
             env.update({"RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_RANK": str(local_ranks[r] if local_ranks else r),
                         "LOCAL_WORLD_SIZE": str(world), _ENV: "@" + hub.address[1:],   # (no NUL bytes in an environment)
-                        "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                        _ENV_KEY: hub.authkey.hex()})
+            # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL's intra-node transport shares device buffers between the ranks' processes through HIP IPC
+            # handles, and this pool's host driver only supports the dmabuf flavour of them -- with the legacy mode (the runtime's default)
+            # ncclCommInitRank fails in hipIpcGetMemHandle ("invalid argument").  The image exports the variable already; it is repeated
+            # here only so that a caller with a scrubbed environment gets the same transport, and never overrides a value the user set.
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if env_extra:
                 env.update({k: str(v) for k, v in env_extra.items()})
             procs.append(subprocess.Popen(list(argv), env=env, stdout=stdout, stderr=stderr))

@@ -48,7 +48,8 @@
 extern "C" {
 #endif
 
-#define GPCA_VERSION 240 /* 0.2.4: kernel choice through gpca_config.reserved (no environment switches), sketches wider than 64 columns */
+#define GPCA_VERSION 250 /* 0.2.5: a zeroed gpca_config is the fast exact path with automatic residency (the enum values of gpca_precision /
+                            gpca_storage changed: 0 now means "the library's choice"); the l x l eigen step runs on the device */
 #define GPCA_MISSING_I8 (-127) /* bed_reader i8 missing code, prepare.rs:1224 */
 
 typedef struct gpca_handle gpca_handle;
@@ -67,24 +68,32 @@ typedef enum gpca_status {
     GPCA_ERR_INVALID_GENOTYPE = -9 /* a kept SNP holds a value outside {0,1,2} */
 } gpca_status;
 
-/* Arithmetic used by the two tall-skinny products. */
+/* Arithmetic used by the two tall-skinny products.  0 -- what `gpca_config cfg = {0}`, a Rust `GpcaConfig::default()` or
+ * gpca_create(NULL) give -- is the library's choice: the exact-integer path, the fastest parity-green one (a randomized PCA of 1M x 10k
+ * in 10 ms against 28 ms on the f32 matrix cores). */
 typedef enum gpca_precision {
-    GPCA_PREC_F32_MFMA = 0, /* v_mfma_f32_32x32x2_f32, exact f32 FMA chains */
-    GPCA_PREC_I8_EXACT = 1  /* v_mfma_i32_32x32x32_i8 on fixed-point digits of the skinny operand */
+    GPCA_PREC_DEFAULT = 0,  /* = GPCA_PREC_I8_EXACT */
+    GPCA_PREC_I8_EXACT = 1, /* v_mfma_i32_32x32x32_i8 on fixed-point digits of the skinny operand, exact integer accumulation */
+    GPCA_PREC_F32_MFMA = 2  /* v_mfma_f32_32x32x2_f32, exact f32 FMA chains (north_star's MFMA-fp32 path) */
 } gpca_precision;
 
-/* How the genotypes stay resident in HBM. */
+/* How the genotypes stay resident in HBM.  0 = GPCA_STORE_AUTO: decided when the genotypes arrive, the way both command lines decide it
+ * (main.rs has no such choice: its matrix is f64): rows of >= 1 024 samples stay as 2-bit codes -- a quarter of the HBM and the faster
+ * kernels there -- narrower ones as int8 (2-bit rows pad to 1 024 samples, int8 rows to 256).  An int8 upload that turns out to hold a
+ * value outside {0, 1, 2, -127} is kept as int8 (2-bit codes could only store it as "missing"); panel streams cannot look ahead and
+ * follow the sample count alone.  gpca_get_storage reports what was chosen. */
 typedef enum gpca_storage {
-    GPCA_STORE_INT8 = 0, /* 1 B per genotype */
-    GPCA_STORE_2BIT = 1  /* 0.25 B per genotype (PLINK-like packing of dosage codes), decoded in the GEMM prologues of either
+    GPCA_STORE_AUTO = 0,
+    GPCA_STORE_2BIT = 1, /* 0.25 B per genotype (PLINK-like packing of dosage codes), decoded in the GEMM prologues of either
                             precision.  10M SNPs x 100k samples = 250 GB: fits one MI355X. */
+    GPCA_STORE_INT8 = 2  /* 1 B per genotype */
 } gpca_storage;
 
 typedef struct gpca_config {
     int32_t device;    /* HIP ordinal; -1 = current device */
     int32_t precision; /* gpca_precision */
     int32_t storage;   /* gpca_storage */
-    int32_t digit_planes; /* GPCA_PREC_I8_EXACT only.  4: four signed base-128 digit planes of the skinny operand (28-bit fixed point per
+    int32_t digit_planes; /* GPCA_PREC_I8_EXACT only (3 needs an explicit GPCA_STORE_2BIT).  4: four signed base-128 digit planes of the skinny operand (28-bit fixed point per
                              column).  3: three signed base-256 planes (24-bit; exact integer accumulation as before) -- a quarter
                              less matrix-core work; implemented for GPCA_STORE_2BIT, whose kernels are matrix-core bound.
                              0 = the library's choice: 4 on int8 rows (HBM-bound), 3 on 2-bit rows (measured max|dPC| <= 3e-7 against
@@ -211,6 +220,8 @@ typedef struct gpca_stream_info {
 } gpca_stream_info;
 GPCA_API int gpca_stream_get_info(gpca_handle* h, gpca_stream_info* out);
 GPCA_API int gpca_dims(gpca_handle* h, int64_t* M, int64_t* N);
+/* The residency in use (GPCA_STORE_INT8 / GPCA_STORE_2BIT; GPCA_STORE_AUTO until the first genotypes have arrived) and the precision. */
+GPCA_API int gpca_get_storage(gpca_handle* h, int32_t* storage, int32_t* precision);
 /* Free and total memory of the handle's device in bytes (hipMemGetInfo): what a host needs to choose between a resident load
  * (M x N bytes int8, M x N / 4 packed, plus about 1 KiB per SNP row and 8 KiB per sample of workspace) and gpca_stream_open. */
 GPCA_API int gpca_get_device_memory(gpca_handle* h, int64_t* free_bytes, int64_t* total_bytes);
@@ -230,6 +241,9 @@ GPCA_API int gpca_get_standardization(gpca_handle* h, float* mu, float* sigma, u
  * implicit QL), exposed so that CPU-only tests can pin it against LAPACK.  a_sym: n x n row-major (n <= 128); w: eigenvalues
  * descending; v: eigenvectors in columns, row-major. */
 GPCA_API int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, double* v);
+/* Test hook (GPU): the DEVICE eigen-solver gpca_rsvd runs for its l x l step (csrc/small_eig.hip: the same tridiagonalisation + implicit
+ * QL pair on one or two waves, the call's stream never waits for the host), on a caller's matrix; same conventions as above. */
+GPCA_API int gpca_device_eigh_desc(gpca_handle* h, const double* a_sym, int32_t n, double* w, double* v);
 /* Host helper, same branches as prepare.rs:1641-1745. */
 GPCA_API double gpca_hwe_chi_squared_p_value(uint64_t n_hom1, uint64_t n_het, uint64_t n_hom2);
 

@@ -31,9 +31,21 @@ def test_no_undeclared_exports(gpca):
 
 def test_version_and_strings(gpca):
     lib = gpca.load()
-    assert lib.gpca_version() == 240
+    assert lib.gpca_version() == 250
     assert lib.gpca_status_string(0) == b"ok"
     assert b"missing genotype" in lib.gpca_status_string(-5)
+
+
+def test_enum_values_are_pinned_and_zero_is_the_fast_default():
+    """The boundary's zero value is the library's choice -- a Rust `GpcaConfig::default()` or a C `{0}` must not land on the slowest
+    path (VERDICT r4 #6).  The numbers are ABI: pinned here against the header text and the Python mirror."""
+    import re
+    from genomic_pca_amd import _lib
+    src = open(os.path.join(ROOT, "include", "gpca.h")).read()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(GPCA_(?:PREC|STORE)_[A-Z0-9_]+)\s*=\s*(\d+)", src)}
+    assert vals == {"GPCA_PREC_DEFAULT": 0, "GPCA_PREC_I8_EXACT": 1, "GPCA_PREC_F32_MFMA": 2, "GPCA_STORE_AUTO": 0, "GPCA_STORE_2BIT": 1, "GPCA_STORE_INT8": 2}
+    assert (_lib.PREC_DEFAULT, _lib.PREC_I8_EXACT, _lib.PREC_F32_MFMA) == (0, 1, 2) and (_lib.STORE_AUTO, _lib.STORE_2BIT, _lib.STORE_INT8) == (0, 1, 2)
+    assert "#define GPCA_VERSION 250" in src
 
 
 def test_header_cites_the_reference_interfaces():
@@ -123,7 +135,7 @@ def test_header_is_plain_c99_and_links(tmp_path, gpca):
         pytest.skip("GPU present: covered by test_c_client_full_path")
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "no CPU fallback" in out.stdout and "libgpca version 240" in out.stdout
+    assert "no CPU fallback" in out.stdout and "libgpca version 250" in out.stdout
 
 
 @pytest.mark.gpu
@@ -134,6 +146,7 @@ def test_c_client_full_path(tmp_path, gpca):
     out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ok" in out.stdout.splitlines()[-1] and "streamed :" in out.stdout
+    assert "default  : gpca_config {0} = GPCA_PREC_I8_EXACT" in out.stdout
 
 
 def test_rccl_constants_match_the_installed_header():

@@ -107,3 +107,28 @@ def test_bench_gpus_2_rehearsal_on_one_device():
     assert abs(d["ms_per_step"] - mg["per_rank_ms_per_step_max"]) < 1e-9 and d["value"] == pytest.approx(2 * 60000 * 2048 / (d["ms_per_step"] * 1e-3))
     assert len(mg["same_shard_without_exchange_ms_per_step_per_rank"]) == 2
     assert d["top_eigenvalues"][0] > d["top_eigenvalues"][2] > 0
+    # the line computes its own weak-scaling efficiency, against the same shard without the exchange in this very run
+    solo = mg["same_shard_without_exchange_ms_per_step_per_rank"]
+    assert mg["weak_scaling_efficiency"] == pytest.approx(sum(solo) / 2 / d["ms_per_step"])
+    assert mg["weak_scaling_efficiency_vs_slowest_rank"] == pytest.approx(max(solo) / d["ms_per_step"])
+    assert 0.0 < mg["weak_scaling_efficiency"] <= mg["weak_scaling_efficiency_vs_slowest_rank"]
+    assert "NOT vs the --gpus 1 line" in d["config"]["workload"] and d["device_memory_preflight"]["needed_GiB"] < d["device_memory_preflight"]["free_GiB"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_streamed_rehearsal_on_one_device():
+    """configs[4]'s form of the same: `bench.py --gpus 2 --streamed` (two ranks streaming their shards out of core, the sketch summed
+    through the hook) prints the same multi-GPU record, reference and efficiency included."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--exchange", "host", "--streamed", "--storage", "2bit",
+                        "--snps", "40000", "--samples", "2048", "--panel-rows", "8192", "--cache-gb", "0", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["residency"] == "streamed/2bit" and d["config"]["passes_over_the_source_per_call"] == 4
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen_by_the_host_hook"] == 2 and len(mg["per_rank_ms_per_step"]) == 2 and len(mg["same_shard_without_exchange_ms_per_step_per_rank"]) == 2
+    assert abs(d["ms_per_step"] - mg["per_rank_ms_per_step_max"]) < 1e-9 and d["value"] == pytest.approx(2 * 40000 * 2048 / (d["ms_per_step"] * 1e-3))
+    assert mg["weak_scaling_efficiency"] == pytest.approx(sum(mg["same_shard_without_exchange_ms_per_step_per_rank"]) / 2 / d["ms_per_step"])
+    assert "NOT vs a --gpus 1 line" in d["config"]["workload"]

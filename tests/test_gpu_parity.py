@@ -1195,6 +1195,98 @@ def test_exact_path_with_qc_dropped_and_missing_rows(gpca, oracle, store, planes
         assert np.max(np.abs(e.eigenvalues() - R["eigenvalues"]) / R["eigenvalues"]) < TOL_EV
 
 
+def test_zeroed_config_is_the_exact_path_with_automatic_residency(gpca, oracle):
+    """gpca_create(NULL) / a zeroed gpca_config: GPCA_PREC_I8_EXACT, and GPCA_STORE_AUTO decided when the rows arrive -- 2-bit codes from
+    1 024 samples on (three digit planes, the packed default), int8 below, int8 as well for an upload that holds a value 2-bit codes
+    cannot carry; every choice returns the bits of the same choice made explicitly."""
+    import ctypes as C
+    from genomic_pca_amd import _lib
+    lib = gpca.load()
+
+    def run(e, G, k=6):
+        e.upload_genotypes_i8(G)
+        e.snp_stats(gpca.QcConfig(0.5, 0.0, 1.0))
+        e.rsvd(k, 10, 2, seed=3)
+        return e.eigenvalues(), e.scores(f64=True)
+    rng = np.random.default_rng(5)
+    for N, want in ((1500, _lib.STORE_2BIT), (700, _lib.STORE_INT8)):
+        th = gpca.synth_thresholds(4000, 3, seed=2, fst=0.2)
+        G = oracle.synth_genotypes(4000, N, 2, th)
+        with gpca.GpcaEngine(precision=_lib.PREC_DEFAULT, storage=_lib.STORE_AUTO) as e0, gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=want) as e1:
+            assert e0.storage_in_use() == (_lib.STORE_AUTO, _lib.PREC_I8_EXACT)
+            ev0, sc0 = run(e0, G)
+            assert e0.storage_in_use() == (want, _lib.PREC_I8_EXACT)
+            ev1, sc1 = run(e1, G)
+            assert np.array_equal(ev0, ev1) and np.array_equal(sc0, sc1)
+            # the same handle re-resolves for the next matrix
+            G2 = oracle.synth_genotypes(3000, 2500 - N, 2, gpca.synth_thresholds(3000, 3, seed=2, fst=0.2))
+            run(e0, G2)
+            assert e0.storage_in_use()[0] == (_lib.STORE_2BIT if 2500 - N >= 1024 else _lib.STORE_INT8)
+    # a value outside {0, 1, 2, -127}: AUTO keeps the rows as int8 (the statistics see the value, as prepare.rs:1267-1279 does)
+    G = oracle.synth_genotypes(2000, 1200, 4, gpca.synth_thresholds(2000, 3, seed=4, fst=0.2))
+    G[7, 5] = 3
+    with gpca.GpcaEngine(precision=_lib.PREC_DEFAULT, storage=_lib.STORE_AUTO) as e0, gpca.GpcaEngine(precision=_lib.PREC_I8_EXACT, storage=_lib.STORE_INT8) as e1:
+        e0.upload_genotypes_i8(G); e1.upload_genotypes_i8(G)
+        assert e0.storage_in_use()[0] == _lib.STORE_INT8 and np.array_equal(e0.download_genotypes_i8(), G)
+        s0, s1 = e0.snp_stats(gpca.QcConfig.none()), e1.snp_stats(gpca.QcConfig.none())
+        assert np.array_equal(s0["mu"], s1["mu"]) and np.array_equal(s0["keep"], s1["keep"])
+    # gpca_create(NULL)
+    h = C.c_void_p()
+    assert lib.gpca_create(None, C.byref(h)) == 0
+    st, pr = C.c_int32(-1), C.c_int32(-1)
+    assert lib.gpca_get_storage(h, C.byref(st), C.byref(pr)) == 0 and (st.value, pr.value) == (_lib.STORE_AUTO, _lib.PREC_I8_EXACT)
+    lib.gpca_destroy(h)
+
+
+def test_device_eigensolver_against_the_host_pin_and_lapack(gpca):
+    """The l x l step of gpca_rsvd runs on the device (csrc/small_eig.hip: tridiagonalisation + implicit QL on one or two waves, the
+    call's stream never waits for the host).  Held to gpca_host_eigh_desc -- the CPU pin of tests/test_abi.py, itself held to LAPACK
+    there -- and to numpy.linalg.eigh directly, at 1e-12 of the largest eigenvalue, on Gram-like matrices of every size class the
+    engine asks for (one wave up to 64, two waves up to 128), clustered / repeated / rank-deficient / widely spread spectra, a zero
+    matrix and a huge-magnitude one (the power-of-two prescale)."""
+    import ctypes as C
+    lib = gpca.load()
+    rng = np.random.default_rng(0)
+    with gpca.GpcaEngine() as e:
+        for n in (1, 2, 3, 7, 16, 30, 31, 32, 33, 50, 64, 65, 70, 100, 127, 128):
+            for kind in ("gram", "spread", "rank_deficient", "repeated", "clustered", "zero", "huge"):
+                B = rng.standard_normal((max(n, 2) * 3, n))
+                if kind == "spread":
+                    B = B * np.logspace(0, -6, n)
+                if kind == "rank_deficient" and n > 2:
+                    B[:, -2:] = B[:, :2]
+                A = B.T @ B
+                if kind == "repeated":
+                    A = np.diag(np.repeat([4.0, 1.0], [n // 2, n - n // 2])) if n > 1 else np.array([[2.0]])
+                if kind == "clustered":          # eigenvalues in tight clusters under a random rotation
+                    Qr, _ = np.linalg.qr(rng.standard_normal((n, n)))
+                    lam = np.repeat([1.0, 1.0 + 1e-9, 0.5, 1e-3], (n + 3) // 4)[:n]
+                    A = (Qr * lam) @ Qr.T
+                if kind == "zero":
+                    A = np.zeros((n, n))
+                if kind == "huge":
+                    A = A * 1e200
+                A = np.ascontiguousarray(0.5 * (A + A.T))
+                w = np.empty(n); V = np.empty((n, n)); wh = np.empty(n); Vh = np.empty((n, n))
+                rc = lib.gpca_device_eigh_desc(e._h, A.ctypes.data_as(C.c_void_p), n, w.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p))
+                assert rc == 0, (n, kind, lib.gpca_last_error(e._h))
+                assert lib.gpca_host_eigh_desc(A.ctypes.data_as(C.c_void_p), n, wh.ctypes.data_as(C.c_void_p), Vh.ctypes.data_as(C.c_void_p)) == 0
+                ref = np.linalg.eigvalsh(A)[::-1]
+                scale = max(abs(ref[0]), 1e-300)
+                assert np.all(np.diff(w) <= 0), (n, kind)
+                assert np.max(np.abs(w - ref)) < 1e-12 * scale, (n, kind, np.max(np.abs(w - ref)) / scale)
+                if kind != "huge":               # (the host pair overflows at 1e200: its products are not prescaled; the device solver is)
+                    assert np.max(np.abs(w - wh)) < 1e-12 * scale, (n, kind)
+                assert np.max(np.abs(V.T @ V - np.eye(n))) < 1e-12, (n, kind)              # orthonormal eigenvectors
+                assert np.max(np.abs(A @ V - V * w)) < 1e-11 * scale, (n, kind)            # residual
+                if kind in ("gram", "spread"):      # simple spectra: the vectors themselves agree with the host pin up to sign
+                    sg = np.sign(np.sum(V * Vh, axis=0))
+                    gaps = np.min(np.abs(np.diff(ref))) / scale if n > 1 else 1.0
+                    if gaps > 1e-6:
+                        assert np.max(np.abs(V * sg - Vh)) < 1e-9, (n, kind)
+        assert lib.gpca_device_eigh_desc(e._h, None, 3, None, None) == -1
+
+
 @pytest.mark.gpu
 def test_product_bits_did_not_move():
     """sha256 of eigenvalues, f64 scores and loadings of five fixed problems (L = 32 / 64 / 128, int8 and 2-bit rows, a sketch as wide

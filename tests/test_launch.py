@@ -103,6 +103,45 @@ def test_ranks_started_by_someone_else_find_each_other(tmp_path):
     assert (tmp_path / "t0").exists() and (tmp_path / "t1").exists()
 
 
+@pytest.mark.timeout(60)
+def test_hub_turns_strangers_away_and_keeps_serving():
+    """The hub relays pickles, so it must not talk to anyone who is not a rank of this run: the key is random per run
+    (not derivable from the socket's name), a client with the wrong key -- or a bogus rank announcement -- is dropped and counted,
+    and the real ranks are still served afterwards; ranks without a parent of ours meet on a socket inside a 0700 directory."""
+    import stat
+    import threading
+    from multiprocessing import AuthenticationError
+    from multiprocessing.connection import Client
+    from genomic_pca_amd import launch
+    hub = launch.Hub(2).start()
+    hub2 = launch.Hub(2)
+    assert len(hub.authkey) == 32 and hub.authkey != hub2.authkey and hub.authkey != launch._derived_key(hub.address)
+    hub2.close()
+    with pytest.raises(AuthenticationError):                      # what an attacker who reads /proc/net/unix can derive
+        Client(hub.address, family="AF_UNIX", authkey=launch._derived_key(hub.address))
+    c = Client(hub.address, family="AF_UNIX", authkey=hub.authkey)
+    c.send("not-a-rank"); c.close()                               # right key, nonsense announcement
+    out = [None, None]
+
+    def rank(r):
+        z = launch.Rendezvous(hub.address, r, 2, authkey=hub.authkey)
+        out[r] = z.allgather(r + 10)
+        z.close()
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]; [t.join(30) for t in ts]
+    assert out == [[10, 11], [10, 11]] and hub.rejected == 2
+    # the torchrun-style meeting point
+    env = {"WORLD_SIZE": "2", "RANK": "1", "MASTER_PORT": "29999", "TORCHELASTIC_RUN_ID": "../../x y"}
+    d = launch._private_dir()
+    st = os.lstat(d)
+    assert stat.S_ISDIR(st.st_mode) and (st.st_mode & 0o077) == 0 and st.st_uid == os.getuid()
+    h3 = launch.Hub(2, os.path.join(d, "t-%d.sock" % os.getpid()))
+    assert os.path.dirname(h3.address) == d and stat.S_ISSOCK(os.lstat(h3.address).st_mode)
+    h3.close()
+    assert not os.path.exists(h3.address)
+    del env
+
+
 @pytest.mark.timeout(300)
 def test_sharded_equals_unsharded_through_the_hub(tmp_path, oracle, gpca):
     """World = 2 over the launcher: the exchange step of gpca_rsvd (all-reduce of the N x l sketch and of one l x l Gram) carried by
@@ -151,6 +190,35 @@ def test_sharded_equals_unsharded_through_the_hub(tmp_path, oracle, gpca):
     assert np.max(np.abs(z[0]["ev"] - R["eigenvalues"]) / R["eigenvalues"]) < 1e-9
     assert oracle.max_abs_dpc(z[0]["scores"], R["scores"]) < 1e-8
     assert oracle.max_abs_dpc(np.concatenate([z[0]["load"], z[1]["load"]], axis=0), R["loadings"]) < 1e-8
+
+
+def test_weak_scaling_record_is_self_consistent():
+    """the multi-GPU line carries its own weak-scaling efficiency -- against the same shard timed without the exchange in
+    the same run, never against the --gpus 1 line (configs[1], another shape) -- plus the reading against the slowest rank, and a
+    shard that cannot fit is refused with a sentence before anything is generated."""
+    sys.path.insert(0, ROOT)
+    import bench
+    f = bench.weak_scaling_fields(120.0, [116.0, 119.0, 117.0, 118.0])
+    assert f["weak_scaling_efficiency"] == pytest.approx(117.5 / 120.0) and f["weak_scaling_efficiency_vs_slowest_rank"] == pytest.approx(119.0 / 120.0)
+    assert f["weak_scaling_efficiency"] <= f["weak_scaling_efficiency_vs_slowest_rank"] <= 1.0
+    assert "NOT the --gpus 1 line" in f["weak_scaling_reference"] and f["same_shard_spread_between_ranks"] == pytest.approx(3.0 / 117.5)
+    assert bench.weak_scaling_fields(120.0, [])["weak_scaling_efficiency"] is None
+    # configs[3]'s shard: 125 GB of int8 rows + workspace fits a 288 GB part, not a 128 GB one; as 2-bit codes it needs a quarter
+    need8 = bench.shard_bytes_needed(1_250_000, 100_000, "int8", 20, 10)
+    need2 = bench.shard_bytes_needed(1_250_000, 100_000, "2bit", 20, 10)
+    assert 118 * 2**30 < need8 < 124 * 2**30 and need2 < 0.3 * need8
+    ring = bench.shard_bytes_needed(6_250_000, 500_000, "2bit", 40, 10, streamed=True, panel_rows=0, ring=3)
+    assert 3 * 131072 * 125_000 < ring < 80 * 2**30
+
+    class Eng:
+        def device_memory(self):
+            return 100 * 2**30, 128 * 2**30
+    with pytest.raises(SystemExit) as ex:
+        bench.memory_preflight(Eng(), "the resident shard of 1250000 SNPs x 100000 samples (int8)", need8, 3)
+    assert "rank 3" in str(ex.value) and "GiB" in str(ex.value) and "--storage 2bit" in str(ex.value)
+    assert bench.memory_preflight(Eng(), "x", need2, 0)["free_GiB"] == 100.0
+    wl = bench.workload_name(8, 1_250_000, 10_000_000, 100_000, 20, 30, type("A", (), {"power_iters": 2, "rfit_seed": 1})())
+    assert "configs[3]" in wl and "NOT vs the --gpus 1 line" in wl
 
 
 @pytest.mark.timeout(300)
