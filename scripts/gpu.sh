@@ -11,6 +11,7 @@
 #   ab=<ENV=a>,<ENV=b>[,reps]        scripts/ab_env.py, both orders               -> gpurun_out/ab_<tag>.log
 #   kbench=<name>[,args]             hipcc scripts/kbench/<name>.hip and run it   -> gpurun_out/kbench_<name>_<tag>.log
 #   py=<script.py>[,args]            python <script> args                         -> gpurun_out/py_<tag>.log (appended)
+#   sh=<script.sh>[,args]            bash <script> args                           -> gpurun_out/sh_<tag>.log (appended)
 tag=$1; shift
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -51,6 +52,10 @@ for step in "$@"; do
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $KBENCH_FLAGS -o /tmp/$kb scripts/kbench/$kb.hip 2> gpurun_out/kbench_${kb}_build.err || { tail -5 gpurun_out/kbench_${kb}_build.err; exit 1; }
       timeout -k 10 300 /tmp/$kb $kargs >> gpurun_out/kbench_${kb}_$tag.log 2>&1
       rc=$?; tail -40 gpurun_out/kbench_${kb}_$tag.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
+    sh)         # a shell script of the repo (a harness that builds and runs several variants)  -> gpurun_out/sh_<tag>.log
+      IFS=, read -r sc sargs <<< "$arg"
+      timeout -k 10 600 bash $sc $sargs >> gpurun_out/sh_$tag.log 2>&1
+      rc=$?; tail -40 gpurun_out/sh_$tag.log; fault gpurun_out/sh_$tag.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
     py)
       IFS=, read -r sc pargs <<< "$arg"
       timeout -k 10 900 python $sc $pargs >> gpurun_out/py_$tag.log 2>&1
