@@ -176,6 +176,8 @@ __global__ __launch_bounds__(1024) void k_finish_scale(const double* __restrict_
 // The 16 loads of a lane are unconditional (row index clamped, the value zeroed afterwards) and issued together: with a
 // predicated load per element the compiler waited for each one before asking for the next (16 serial latencies per lane,
 // 3.8 TB/s on the 256 MB of a T' pass); ND is a template parameter so that the digit loop carries no runtime branch.
+// the tail of the orthonormalisation that k_quantize<double> can carry (launch_quantize_f64_finishq); amax_part = NULL: nothing to carry
+struct QFold { const double* amax_part; const double* csum_part; int64_t P; int ldp; double S; double* s64; float* s32; double* scale; double* inv; };
 template <int ND>
 __device__ __forceinline__ void split_digits(int v, unsigned (&w)[kDigits][4], int j) {
 #pragma unroll
@@ -188,12 +190,51 @@ __device__ __forceinline__ void split_digits(int v, unsigned (&w)[kDigits][4], i
 }
 template <typename T, int ND>
 __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64_t rows, int64_t rows_pad,
-                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int64_t ldx) {
+                                                  const double* __restrict__ inv, int8_t* __restrict__ Xd, int layout, int64_t ldx,
+                                                  const double* __restrict__ cscratch, int cslices, double* __restrict__ cout, QFold qf) {
+    __shared__ double sinv[32];
+    if (qf.amax_part) {
+        // The orthonormal basis' tail rides along (it was k_finish_q, one more launch): every workgroup folds the column abs-max partials of
+        // k_apply_right_tail for its 32 columns itself (max is exact in any order: every workgroup gets the same scale); the first one also
+        // folds the column sums s = Q^T 1 in a fixed order and publishes scale / inv / s for the kernels that follow.
+        __shared__ double rm[256], rs[256];
+        const int cc = threadIdx.x & 31, pg = threadIdx.x >> 5;
+        double m = 0.0, a = 0.0;
+        int64_t p = pg;
+        for (; p < qf.P; p += 64) {                        // eight loads in flight per thread (one L2 round trip each: the fold is all latency)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = qf.amax_part[(p + 8 * u < qf.P ? p + 8 * u : p) * qf.ldp + cc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmax(m, v[u]);
+        }
+        if (blockIdx.x == 0)
+            for (int64_t p2 = pg; p2 < qf.P; p2 += 64) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = qf.csum_part[(p2 + 8 * u < qf.P ? p2 + 8 * u : p2) * qf.ldp + cc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (p2 + 8 * u < qf.P) ? v[u] : 0.0;
+            }
+        rm[threadIdx.x] = m; rs[threadIdx.x] = a;
+        __syncthreads();
+        if (pg == 0) {
+            for (int g = 1; g < 8; ++g) { m = fmax(m, rm[g * 32 + cc]); a += rs[g * 32 + cc]; }
+            const double iv = m > 0.0 ? qf.S / m : 0.0;
+            sinv[cc] = iv;
+            if (blockIdx.x == 0) { qf.scale[cc] = m > 0.0 ? m / qf.S : 0.0; qf.inv[cc] = iv; qf.s64[cc] = a; qf.s32[cc] = (float)a; }
+        }
+        __syncthreads();
+    }
+    if (cscratch && blockIdx.x == 0) {      // the second stage of c = b^T T rides along (the first ran beside the scale's fold: k_post_k1)
+        __shared__ double red[4][64];
+        sum_partials_body<double>(cscratch, cslices, 32, cout, 1, 0, 0, red);
+    }
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk * 32 >= rows_pad) return;
     const int cc = lane & 31, hh = lane >> 5;
-    const double sc = inv[cc];
+    const double sc = qf.amax_part ? sinv[cc] : inv[cc];
     const int64_t rbase = layout ? (blk >> 2) * 128 + 64 * hh + 16 * (blk & 3) : blk * 32 + 16 * hh;
     T xv[16];
 #pragma unroll
@@ -216,11 +257,50 @@ __global__ __launch_bounds__(256) void k_quantize(const T* __restrict__ X, int64
         *reinterpret_cast<uint4*>(Xd + ((blk * kDigits + d) * 64 + lane) * 16) = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
 }
 template <typename T>
-static void launch_k_quantize(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd, int64_t ldx) {
+static void launch_k_quantize(hipStream_t st, const T* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd, int64_t ldx,
+                              const double* cscratch = nullptr, int cslices = 0, double* c = nullptr, QFold qf = QFold{}) {
     const int64_t blocks = rows_pad / 32;
     const dim3 grid((unsigned)((blocks + 3) / 4)), blk(256);
-    if (nd == 3) hipLaunchKernelGGL((k_quantize<T, 3>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx);
-    else hipLaunchKernelGGL((k_quantize<T, kDigits>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx);
+    if (nd == 3) hipLaunchKernelGGL((k_quantize<T, 3>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx, cscratch, cslices, c, qf);
+    else hipLaunchKernelGGL((k_quantize<T, kDigits>), grid, blk, 0, st, X, rows, rows_pad, inv, Xd, layout, ldx, cscratch, cslices, c, qf);
+}
+// the digit planes of 32 columns of the orthonormal basis X (f64) with k_finish_q's work folded in: the partials of k_apply_right_tail
+// (amax_part / csum_part [P][ldp], already offset to these columns) -> scale / inv / s64 / s32 of these columns.  For P <= kFinishQFoldMax.
+void launch_quantize_f64_finishq(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, int8_t* Xd, int layout, int nd, int64_t ldx,
+                                 const double* csum_part, const double* amax_part, int64_t P, int ldp, double* s64, float* s32, double* scale, double* inv) {
+    QFold qf{amax_part, csum_part, P, ldp, digit_scale(nd), s64, s32, scale, inv};
+    launch_k_quantize<double>(st, X, rows, rows_pad, inv, Xd, layout, nd, ldx, nullptr, 0, nullptr, qf);
+}
+// K1's tail: the first stage of c over the units' partials (workgroups 0 .. S - 1: sum_partials_body, E = 32) and the fold of the waves'
+// column abs-max into the digit scale (workgroup S), side by side in one launch
+__global__ __launch_bounds__(256) void k_post_k1(const float* __restrict__ cpart, int64_t units, double* __restrict__ cscratch, int S,
+                                                 const double* __restrict__ apart, int64_t P, double* __restrict__ scale, double* __restrict__ inv, double DS) {
+    __shared__ double red[4][64];
+    if ((int)blockIdx.x < S) { sum_partials_body<float>(cpart, units, 32, cscratch, S, 0, blockIdx.x, red); return; }
+    double* rf = &red[0][0];                               // 256 doubles
+    const int cc = threadIdx.x & 31, pg = threadIdx.x >> 5;   // 8 part-groups
+    double a = 0.0;
+    int64_t p = pg;
+    for (; p + 24 < P; p += 32) {                          // four loads in flight per thread
+        const double v0 = apart[p * 32 + cc], v1 = apart[(p + 8) * 32 + cc], v2 = apart[(p + 16) * 32 + cc], v3 = apart[(p + 24) * 32 + cc];
+        a = fmax(fmax(a, fmax(v0, v1)), fmax(v2, v3));
+    }
+    for (; p < P; p += 8) { const double v = apart[p * 32 + cc]; a = v > a ? v : a; }
+    rf[threadIdx.x] = a;
+    __syncthreads();
+    if (pg != 0) return;
+    for (int g = 1; g < 8; ++g) { const double v = rf[g * 32 + cc]; a = v > a ? v : a; }
+    scale[cc] = a > 0.0 ? a / DS : 0.0;
+    inv[cc] = a > 0.0 ? DS / a : 0.0;
+}
+int post_k1_slices(int64_t units) { return sum_slices(units, 32); }
+void launch_post_k1(hipStream_t st, const float* cpart, int64_t units, double* cscratch, const double* apart, int64_t P, double* scale, double* inv, int nd) {
+    const int S = post_k1_slices(units);
+    hipLaunchKernelGGL(k_post_k1, dim3((unsigned)(S + 1)), dim3(256), 0, st, cpart, units, cscratch, S, apart, P, scale, inv, digit_scale(nd));
+}
+void launch_quantize_f32_cfold(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd,
+                               int64_t ldx, const double* cscratch, int cslices, double* c) {
+    launch_k_quantize<float>(st, X, rows, rows_pad, inv, Xd, layout, nd, ldx, cscratch, cslices, c);
 }
 
 template <typename T>

@@ -570,6 +570,7 @@ extern "C" int gpca_enable_timings(gpca_handle* h, int32_t on) {
     if (!h) return GPCA_ERR_BAD_ARG;
     LOCK(h);
     h->timing_on = on != 0;
+    h->timing_every = on > 1 ? on : 1; h->timing_calls = 0;
     if (h->child) h->child->timing_on = h->timing_on;
     return GPCA_OK;
 }

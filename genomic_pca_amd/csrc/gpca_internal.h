@@ -171,6 +171,7 @@ struct gpca_handle {
     Gtt8Plan plan8{};
     // exact-integer path
     int8_t *dQd = nullptr, *dTd = nullptr;
+    bool c_fold_pending = false;     // K1's tail ran as launch_post_k1: the digit scale is made, c's second stage waits in d_scratch64 for the quantisation
     double* d_apart = nullptr; size_t cap_apart = 0; bool apart_valid = false; int64_t apart_parts = 0;   // column abs-max partials of T' from the K1 epilogue
     const double* apart_src[4] = {nullptr, nullptr, nullptr, nullptr};   // where the partials of each 32-column block sit (kMaxSketch / 32 blocks)
     float* d_rmax = nullptr; bool rmax_valid = false;   // max_i r[i]: the sketch's digit scale is 6.67 * rmax (k_omega); recomputed when r changes
@@ -232,12 +233,16 @@ struct gpca_handle {
 
     // timings (off by default; bounded: pending records are folded into `agg` once kMaxTimingRecs are outstanding)
     bool timing_on = false;
+    int timing_every = 1;        // gpca_enable_timings(h, n > 1): only every n-th gpca_rsvd call records its events (an event pair costs the stream ~5 us of idle time)
+    int64_t timing_calls = 0;
+    bool timing_skip = false;    // the gpca_rsvd call in progress is not one of the sampled ones
     int open_timers = 0;         // ScopedTimers alive (their records must not be folded away under them)
     std::vector<TimingRec> recs;
     std::vector<hipEvent_t> ev_pool;
     std::vector<gpca_kernel_timing> agg;
 };
 constexpr size_t kMaxTimingRecs = 32768;
+constexpr size_t kPostK1Scratch = 256 * 32;     // doubles of d_scratch64 per 32-column block of the sketch (<= 256 slices x 32 columns; kSumScratchElems holds 32 of them)
 // every entry point: take the handle's lock and make its device the calling thread's current one (a host thread that drives
 // several handles on different GPUs, or that last touched another device, would otherwise launch on the wrong one)
 #define LOCK(h) std::lock_guard<std::recursive_mutex> lock_guard_(h->mu); (void)hipSetDevice(h->device); drain_pulls(h)
@@ -290,7 +295,7 @@ void fold_timings(gpca_handle* h);   // resolve pending records into per-name to
 struct ScopedTimer {
     gpca_handle* h; bool on; size_t idx = 0; hipStream_t st;
     ScopedTimer(gpca_handle* h_, const char* name, double flops, double bytes, hipStream_t st_ = nullptr, bool enable = true)
-        : h(h_), on(h_->timing_on && enable), st(st_ ? st_ : h_->st) {
+        : h(h_), on(h_->timing_on && !h_->timing_skip && enable), st(st_ ? st_ : h_->st) {
         if (!on) return;
         // (never while another timer is open: a fold clears recs and recycles the open record's events -- nested timers are the
         //  sweep timers of the streamed passes around their panel_fill / per-launch records)

@@ -205,11 +205,13 @@ static int stage_AtT_local(gpca_handle* h, bool planes_ready = false) {
         for (int hf = 0; hf < halves && !planes_ready; ++hf) {      // (planes_ready: the sketch's digit planes came straight out of k_omega)
             const float* Th = h->dT + 32 * hf;
             double* tsc = h->d_tscale + 32 * hf; double* tin = h->d_tinv + 32 * hf;
-            if (h->apart_valid) launch_quantize_f32_premax(h->st, Th, h->Mpad, h->Mpad, h->apart_src[hf], h->apart_parts, tsc, tin, h->dTd + hf * td_half, 0, h->nd, L);
+            if (h->c_fold_pending) launch_quantize_f32_cfold(h->st, Th, h->Mpad, h->Mpad, tin, h->dTd + hf * td_half, 0, h->nd, L, h->d_scratch64 + (size_t)hf * kPostK1Scratch,
+                                                             post_k1_slices(h->Mpad / 32), h->d_c + 32 * hf);      // (scale by launch_post_k1; c's second stage rides along)
+            else if (h->apart_valid) launch_quantize_f32_premax(h->st, Th, h->Mpad, h->Mpad, h->apart_src[hf], h->apart_parts, tsc, tin, h->dTd + hf * td_half, 0, h->nd, L);
             else launch_quantize_f32(h->st, Th, h->Mpad, h->Mpad, h->d_part64, tsc, tin, h->dTd + hf * td_half, 0, h->nd, L);
             HIPCHK(hipGetLastError());
         }
-        h->apart_valid = false;
+        h->apart_valid = false; h->c_fold_pending = false;
         const bool streamed = h->sm.on;
         const size_t yint_half = (size_t)h->N * 32;
         {
@@ -291,12 +293,19 @@ static int stage_AQ(gpca_handle* h, int scale_out) {
                 return GPCA_OK;
             }));
         }
+        h->apart_valid = scale_out != 0 && (packed || !h->simple_kernels || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
+        // c = b^T T of every half: one partial per 32-row unit, summed in a fixed two-stage tree.  Resident matrices whose K1 left the waves'
+        // column abs-max: the first stage runs beside the fold of those into the digit scale (one launch), the second rides the
+        // quantisation that follows in stage_AtT_local -- two launches between K1 and K2 instead of four, the same bits.
+        h->c_fold_pending = scale_out != 0 && !streamed && h->apart_valid;
         if (scale_out)
-            for (int hf = 0; hf < halves; ++hf) {   // c = b^T T of this half: one partial per 32-row unit, summed in a fixed order
-                launch_sum_partials_f32(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, 32, h->d_c + 32 * hf, h->d_scratch64);
+            for (int hf = 0; hf < halves; ++hf) {
+                if (h->c_fold_pending)
+                    launch_post_k1(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, h->d_scratch64 + (size_t)hf * kPostK1Scratch, h->d_apart + hf * ahalf, h->gqplan.waves,
+                                   h->d_tscale + 32 * hf, h->d_tinv + 32 * hf, h->nd);
+                else launch_sum_partials_f32(h->st, h->d_cpart + hf * chalf, h->Mpad / 32, 32, h->d_c + 32 * hf, h->d_scratch64);
                 HIPCHK(hipGetLastError());
             }
-        h->apart_valid = scale_out != 0 && (packed || !h->simple_kernels || narrow_shape(h));   // (k_gq_i8 has no abs-max epilogue)
         for (int hf = 0; hf < kMaxSketch / 32; ++hf) h->apart_src[hf] = streamed ? h->d_amax_run + 32 * hf : h->d_apart + hf * ahalf;
         h->apart_parts = streamed ? 1 : h->gqplan.waves;
         return GPCA_OK;
@@ -384,9 +393,12 @@ static int stage_orth(gpca_handle* h, int rounds = 2) {
         const int64_t parts = gram_num_parts(h->N);
         launch_gram_f64(h->st, h->dY, h->N, L, h->d_part64);
         HIPCHK(hipGetLastError());
-        launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
-        HIPCHK(hipGetLastError());
-        launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
+        if (L == 32 && parts <= 64) launch_chol_inv_fold(h->st, h->d_part64, (int)parts, l, L, h->dZ, h->d_cholflag);     // (the fold of the partial Grams rides in front)
+        else {
+            launch_sum_partials_f64(h->st, h->d_part64, parts, (int64_t)L * L, h->dW, h->d_scratch64);
+            HIPCHK(hipGetLastError());
+            launch_chol_inv(h->st, h->dW, l, L, h->dZ, h->d_cholflag);
+        }
         HIPCHK(hipGetLastError());
         if (round + 1 < rounds) launch_apply_right_inplace(h->st, h->dY, h->N, L, h->dZ, nullptr, h->ldg);
         else launch_apply_right_tail(h->st, h->dY, h->N, L, h->dZ, h->dQ, h->ldg, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L);
@@ -394,8 +406,18 @@ static int stage_orth(gpca_handle* h, int rounds = 2) {
     }
     // dY now holds the orthonormal basis in f64: s = Q^T 1 and (exact-integer path) the digit scale of Q, then its planes
     const bool i8 = h->precision == GPCA_PREC_I8_EXACT;
-    launch_finish_q(h->st, h->d_part64, h->d_part64 + tail_num_parts(h->ldg) * L, tail_num_parts(h->ldg), L, h->d_s64, h->d_s32,
-                    i8 ? h->d_qscale : nullptr, i8 ? h->d_qinv : nullptr, h->nd);
+    const int64_t tparts = tail_num_parts(h->ldg);
+    const double* csum_part = h->d_part64;
+    const double* amax_part = h->d_part64 + tparts * L;
+    if (i8 && tparts <= kFinishQFoldMax) {      // one launch per 32 columns: the quantisation folds the tail's partials itself
+        for (int hf = 0; hf < L / 32; ++hf) {
+            launch_quantize_f64_finishq(h->st, h->dY + 32 * hf, h->N, h->ldg, h->dQd + (size_t)hf * h->ldg * 32 * kDigits, h->storage == GPCA_STORE_2BIT ? 1 : 0, h->nd, L,
+                                        csum_part + 32 * hf, amax_part + 32 * hf, tparts, L, h->d_s64 + 32 * hf, h->d_s32 + 32 * hf, h->d_qscale + 32 * hf, h->d_qinv + 32 * hf);
+            HIPCHK(hipGetLastError());
+        }
+        return GPCA_OK;
+    }
+    launch_finish_q(h->st, csum_part, amax_part, tparts, L, h->d_s64, h->d_s32, i8 ? h->d_qscale : nullptr, i8 ? h->d_qinv : nullptr, h->nd);
     HIPCHK(hipGetLastError());
     if (i8) {
         for (int hf = 0; hf < L / 32; ++hf) {
@@ -433,7 +455,7 @@ static int ensure_workspace(gpca_handle* h) {
         HIPCHK(hipHostMalloc((void**)&h->h_pin, (3 * LL + 16) * 8, hipHostMallocDefault)); HIPCHK(hipMalloc((void**)&h->d_sign, kMaxSketch * 4));
         HIPCHK(hipMalloc((void**)&h->d_scratch64, kSumScratchElems * 8));
         HIPCHK(hipMalloc((void**)&h->d_eigres, kEigResCount * 8));
-        HIPCHK(hipMalloc((void**)&h->d_cand_val, (size_t)128 * kMaxSketch * 8)); HIPCHK(hipMalloc((void**)&h->d_cand_idx, (size_t)128 * kMaxSketch * 8));
+        HIPCHK(hipMalloc((void**)&h->d_cand_val, (size_t)64 * kMaxSketch * 8)); HIPCHK(hipMalloc((void**)&h->d_cand_idx, (size_t)64 * kMaxSketch * 8));      // (scores_num_parts <= 48)
         HIPCHK(hipMalloc((void**)&h->d_cholflag, 4));
     }
     if (h->precision == GPCA_PREC_I8_EXACT) {
@@ -610,10 +632,13 @@ extern "C" int gpca_rsvd(gpca_handle* h, int32_t k, int32_t oversample, int32_t 
     if (!h) return GPCA_ERR_BAD_ARG;
     LOCK(h);
     h->rsvd_on_child = false;
+    // sampled timings (gpca_enable_timings(h, n)): a call that is not the n-th records no events
+    struct SkipGuard { gpca_handle* h; ~SkipGuard() { h->timing_skip = false; } } skip_guard{h};
+    if (!h->is_child) h->timing_skip = h->timing_on && h->timing_every > 1 && (h->timing_calls++ % h->timing_every) != 0;
     if (wants_child(h, k, oversample) && ensure_child(h) == GPCA_OK) {
         // QC dropped most rows: the whole call runs on the kept rows gathered into a matrix of their own
         gpca_handle* c = h->child;
-        c->timing_on = h->timing_on;
+        c->timing_on = h->timing_on; c->timing_skip = h->timing_skip;
         const int rc = gpca_rsvd(c, k, oversample, power_iters, seed);
         if (rc != GPCA_OK) { h->err = c->err; h->have_rsvd = false; return rc; }
         h->k = c->k; h->l = c->l; h->L = c->L; h->eig = c->eig; h->sv = c->sv;

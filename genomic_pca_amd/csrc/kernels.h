@@ -110,6 +110,32 @@ void launch_reduce_y(hipStream_t st, const float* Ypart, int W, int64_t Npad, in
 constexpr int64_t kSumScratchElems = 64 * 4096;
 void launch_sum_partials_f32(hipStream_t st, const float* part, int64_t P, int64_t E, double* out, double* scratch);
 void launch_sum_partials_f64(hipStream_t st, const double* part, int64_t P, int64_t E, double* out, double* scratch);
+// slices of the part axis the first stage uses (a function of (P, E) only: the summation tree is the same for every run and partition)
+int sum_slices(int64_t P, int64_t E);
+#ifdef __HIPCC__
+// The body of the two-stage sum (one workgroup of 256 threads = columns 64 bx .. + 63, slice by of S): out[by][e] = sum over the slice's
+// parts in a fixed tree.  Shared by k_sum_partials and by the kernels that carry one of its stages along (k_post_k1, k_quantize).
+template <typename T>
+__device__ __forceinline__ void sum_partials_body(const T* __restrict__ part, int64_t P, int64_t E, double* __restrict__ out, int S, int bx, int by,
+                                                  double (*red)[64]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t e = (int64_t)bx * 64 + lane;
+    const int64_t per = (P + S - 1) / S;
+    const int64_t p0 = by * per, p1 = (p0 + per < P) ? p0 + per : P;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (e < E) {
+        int64_t p = p0 + wv;
+        for (; p + 12 < p1; p += 16) {
+            a0 += (double)part[p * E + e]; a1 += (double)part[(p + 4) * E + e];
+            a2 += (double)part[(p + 8) * E + e]; a3 += (double)part[(p + 12) * E + e];
+        }
+        for (; p < p1; p += 4) a0 += (double)part[p * E + e];
+    }
+    red[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wv == 0 && e < E) out[(int64_t)by * E + e] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+#endif
 // first stage only: *slices partial sums of [E] doubles at *src, for a consumer that folds the (<= 64, or <= 256 for E <= 64) slices
 // itself (launch_small_eigh, k_chol_inv); P <= 64 parts are their own slices and nothing is launched
 void launch_sum_partials_f64_stage1(hipStream_t st, const double* part, int64_t P, int64_t E, double* scratch, const double** src, int* slices);
@@ -130,6 +156,8 @@ void launch_finish_q(hipStream_t st, const double* csum_part, const double* amax
                      double* scale, double* inv, int nd = 4);
 // W = R^T R (n x n, pitch ld <= 64), Z = R^-1; *flag = j + 1 on a non-positive pivot (first failure wins)
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag);
+// the same from the Gram's P <= 64 partial sums [P][32 * 32] (ld = 32 only): the fold rides in front of the factorisation, no k_sum_partials launch
+void launch_chol_inv_fold(hipStream_t st, const double* part, int P, int n, int ld, double* Z, int* flag);
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qb,
                                 int64_t rows_pad);
 // out[n][kc] = sum_j X[n][j] Z[j][kc]   (Z: [L][K] f64)
@@ -225,9 +253,22 @@ void launch_gq_2bit(hipStream_t st, const uint8_t* G2, int64_t ld2, const GqPlan
                     const double* qscale, const float* r, const float* b, const float* s, float* Tout, float* cpart,
                     double* apart, int scale_out, int nd = 4, int64_t ldt = 32);
 void launch_quantize_f64_prescaled(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd = 4, int64_t ldx = 32);
+// the same with launch_finish_q folded in for these 32 columns (every workgroup folds the P abs-max partials itself: for P <= kFinishQFoldMax)
+constexpr int64_t kFinishQFoldMax = 512;
+void launch_quantize_f64_finishq(hipStream_t st, const double* X, int64_t rows, int64_t rows_pad, int8_t* Xd, int layout, int nd, int64_t ldx,
+                                 const double* csum_part, const double* amax_part, int64_t P, int ldp, double* s64, float* s32, double* scale, double* inv);
 // quantise X whose column abs-max partials [P][32] were already produced by the kernel that wrote it (K1 epilogue)
 void launch_quantize_f32_premax(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* apart, int64_t P,
                                 double* scale, double* inv, int8_t* Xd, int layout, int nd = 4, int64_t ldx = 32);
+// What follows a K1 sweep of a power iteration, in two launches instead of four (resident matrices):
+//   launch_post_k1:           first stage of c = b^T T over the units' partials cpart [units][32] (S = post_k1_slices(units) slices into
+//                             cscratch) BESIDE the fold of the waves' column abs-max apart [P][32] into the digit scale (one more workgroup);
+//   launch_quantize_f32_cfold: the digit planes of T' as launch_quantize_f32_premax's second half, and -- its first workgroup -- the
+//                             second stage of c (cscratch -> c[32]).  Same summation tree as launch_sum_partials_f32: the same bits.
+int post_k1_slices(int64_t units);
+void launch_post_k1(hipStream_t st, const float* cpart, int64_t units, double* cscratch, const double* apart, int64_t P, double* scale, double* inv, int nd);
+void launch_quantize_f32_cfold(hipStream_t st, const float* X, int64_t rows, int64_t rows_pad, const double* inv, int8_t* Xd, int layout, int nd,
+                               int64_t ldx, const double* cscratch, int cslices, double* c);
 // K2 for packed genotypes: stage-wise cooperative LDS-DMA (ring of four stage buffers); returns a hipError_t value
 int launch_gtt_p(hipStream_t st, const uint8_t* G2, int64_t ld2, int64_t Mpad, int64_t Npad, const int8_t* Td, double* Ypart,
                  const Gtt8Plan& plan, int nd = 4, const KernelOpts& ko = KernelOpts());

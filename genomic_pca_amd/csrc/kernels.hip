@@ -13,11 +13,16 @@
 // (prepare.rs:1884-2016) disappears from the hot loop.
 #include "kernels.h"
 #include "philox.hpp"
+#include "omega_math.h"
 
 #ifndef GPCA_OMEGA_ABLATE
 #define GPCA_OMEGA_ABLATE 0     // scripts/kbench/kbench_omega.hip
 #endif
 namespace gpca {
+
+__device__ const OmegaLnEntry kOmegaLnTable[kOmegaLnEntries] = {
+#include "omega_table.inc"
+};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -382,6 +387,9 @@ __global__ __launch_bounds__(64 * NW) void k_omega(int64_t M, int64_t Mpad, int 
     //   * the wave's partial of c = b^T Omega is a conflict-free column walk instead of 6 cross-lane steps per column.
     __shared__ float zt[NW][64][LP];
     __shared__ float rs[NW][64], bs[NW][64];
+    __shared__ OmegaLnEntry lntab[kOmegaLnEntries];      // (omega_math.h: the ln table, one 16-byte LDS read per draw)
+    for (int e = threadIdx.x; e < kOmegaLnEntries; e += 64 * NW) lntab[e] = kOmegaLnTable[e];
+    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * NW + wv;
     const int64_t i0 = wave * 64, i = i0 + lane;
@@ -401,21 +409,13 @@ __global__ __launch_bounds__(64 * NW) void k_omega(int64_t M, int64_t Mpad, int 
             philox_out o = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)jq, GPCA_STREAM_OMEGA,
                                          (uint32_t)seed, (uint32_t)(seed >> 32));
 #endif
-            const double sc = 1.0 / 4294967296.0;
-            const double u0 = ((double)o.v[0] + 1.0) * sc, u1 = ((double)o.v[1] + 1.0) * sc;
-            const double u2 = ((double)o.v[2] + 1.0) * sc, u3 = ((double)o.v[3] + 1.0) * sc;
 #if GPCA_OMEGA_ABLATE & 1
-            z[0] = u0; z[1] = u1; z[2] = u2; z[3] = u3;
-            const double twopi = 0;
+            z[0] = o.v[0]; z[1] = o.v[1]; z[2] = o.v[2]; z[3] = o.v[3];
 #else
-            const double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
-            // sin / cos of 2 pi u through sincospi(2 u): one shared, exact argument reduction instead of two reductions of the
-            // rounded product (agrees with the oracle's cos(twopi * u) to ~1e-16, far below the f32 rounding of Omega)
-            double s1, c1, s3, c3;
-            sincospi(2.0 * u1, &s1, &c1);
-            sincospi(2.0 * u3, &s3, &c3);
-            z[0] = r0 * c1; z[1] = r0 * s1;
-            z[2] = r1 * c3; z[3] = r1 * s3;
+            // Box-Muller on the 32-bit uniforms (u = (v + 1) 2^-32), the oracle's recipe (gpca_oracle.c:omega4) through transcendentals
+            // written for a 33-bit integer argument (omega_math.h): within 2e-16 of long-double libm, a third of the device library's cost
+            omg_box_muller(o.v[0], o.v[1], lntab, z[0], z[1]);
+            omg_box_muller(o.v[2], o.v[3], lntab, z[2], z[3]);
 #endif
         }
 #pragma unroll
@@ -595,28 +595,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_sum_partials(const T* __restrict__ part, int64_t P, int64_t E,
                                                       double* __restrict__ out, int S) {
     __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
-    const int s = blockIdx.y;
-    const int64_t per = (P + S - 1) / S;
-    const int64_t p0 = s * per, p1 = (p0 + per < P) ? p0 + per : P;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (e < E) {
-        int64_t p = p0 + wv;
-        for (; p + 12 < p1; p += 16) {
-            a0 += (double)part[p * E + e]; a1 += (double)part[(p + 4) * E + e];
-            a2 += (double)part[(p + 8) * E + e]; a3 += (double)part[(p + 12) * E + e];
-        }
-        for (; p < p1; p += 4) a0 += (double)part[p * E + e];
-    }
-    red[wv][lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (wv == 0 && e < E) out[(int64_t)s * E + e] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    sum_partials_body<T>(part, P, E, out, S, blockIdx.x, blockIdx.y, red);
 }
 // slices of the part axis in stage 1.  Few elements per part (E <= 64: the c = b^T T partials, one per 32-row unit, 31 250 of them at
 // a million SNPs) put a single column of workgroups on the grid: up to 256 slices there instead of 64 (14 us -> ~5 us for 4 MB).
 // S depends on (P, E) only, so the summation tree -- and with it every bit of the result -- is the same for every run and partition.
-static int sum_slices(int64_t P, int64_t E) {
+int sum_slices(int64_t P, int64_t E) {
     const int64_t cap = E <= 64 ? 256 : 64;
     int64_t s = (P + 63) / 64;
     return (int)(s < 1 ? 1 : (s > cap ? cap : s));
@@ -646,85 +630,32 @@ void launch_sum_partials_f64_stage1(hipStream_t st, const double* part, int64_t 
     *src = scratch; *slices = S;
 }
 
-// Gram: part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c]  (f64 accumulate).
-// 256 threads = 4 row-groups x 64 threads; a thread owns a 4x4 (L=32) or 8x8 (L=64) patch of the L x L output and walks
-// every 4th row of the tile (8 LDS reads per 16 FMAs); the four row-groups are combined through LDS at the end.
+// Gram: part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c]  (f64 accumulate, k_gram_mfma below).
 // Rows per block adapt to the problem so that ~1024 blocks are in flight (N = 10^4 used to get 20 blocks).
 static int64_t gram_rows_per_block(int64_t rows) {
-    // the sample-side Grams of CholeskyQR (N rows, 6 per call) sit on the critical path between two GEMM passes: at most
-    // 64 parts there, so that one k_sum_partials launch finishes the reduction (two stages cost a launch + gap more
-    // than the thinner grid does)
-    if (rows <= 262144) { const int64_t q = (rows + 63) / 64; return q < 32 ? 32 : (q + 31) / 32 * 32; }
+    // The sample-side Grams of CholeskyQR (N rows, four per call) sit on the critical path between two GEMM passes, and their partial
+    // sums are folded by the ONE workgroup that factors the result (k_chol_inv_fold32): 32 parts up to 8k rows, rising to at most 64, which
+    // one k_sum_partials launch still finishes (the matrix-core Gram of 10 000 x 32 takes 5 us with 63 workgroups, 11 with 16).
+    if (rows <= 262144) {
+        int64_t parts = rows / 256;
+        parts = parts < 32 ? 32 : (parts > 64 ? 64 : parts);
+        const int64_t q = (rows + parts - 1) / parts;
+        return q < 32 ? 32 : (q + 31) / 32 * 32;
+    }
     int64_t r = (rows + 1023) / 1024;
     r = (r + 31) / 32 * 32;
     return r < 32 ? 32 : (r > 2048 ? 2048 : r);
 }
 int64_t gram_num_parts(int64_t rows) { const int64_t rpb = gram_rows_per_block(rows); return (rows + rpb - 1) / rpb; }
 
-template <typename T, int L>
-__global__ __launch_bounds__(256) void k_gram(const T* __restrict__ X, int64_t rows, int64_t rpb, double* __restrict__ part) {
-    constexpr int P = L / 8;                 // patch edge: 4 (L=32) or 8 (L=64); 8 x 8 patches cover L x L with 64 threads
-    __shared__ double tile[32][L + 1];
-    __shared__ double red[3][64][P * P];
-    const int tg = threadIdx.x & 63, rgp = threadIdx.x >> 6;
-    const int a0 = (tg >> 3) * P, c0 = (tg & 7) * P;
-    double acc[P][P];
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int j = 0; j < P; ++j) acc[i][j] = 0.0;
-    const int64_t r0 = (int64_t)blockIdx.x * rpb;
-    const int64_t r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
-    for (int64_t rb = r0; rb < r1; rb += 32) {
-        for (int e = threadIdx.x; e < 32 * L; e += 256) {
-            const int rr = e / L, cc = e % L;
-            tile[rr][cc] = (rb + rr < r1) ? (double)X[(rb + rr) * L + cc] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int rr = rgp; rr < 32; rr += 4) {
-            double xa[P], xc[P];
-#pragma unroll
-            for (int i = 0; i < P; ++i) { xa[i] = tile[rr][a0 + i]; xc[i] = tile[rr][c0 + i]; }
-#pragma unroll
-            for (int i = 0; i < P; ++i)
-#pragma unroll
-                for (int j = 0; j < P; ++j) acc[i][j] += xa[i] * xc[j];
-        }
-        __syncthreads();
-    }
-    if (rgp > 0) {
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-#pragma unroll
-            for (int j = 0; j < P; ++j) red[rgp - 1][tg][i * P + j] = acc[i][j];
-    }
-    __syncthreads();
-    if (rgp == 0) {
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const double v = ((acc[i][j] + red[0][tg][i * P + j]) + red[1][tg][i * P + j]) + red[2][tg][i * P + j];
-                part[(int64_t)blockIdx.x * L * L + (a0 + i) * L + c0 + j] = v;
-            }
-    }
-}
-void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part) {
-    const int64_t rpb = gram_rows_per_block(rows);
-    const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
-    if (L == 32) hipLaunchKernelGGL((k_gram<double, 32>), grid, blk, 0, st, X, rows, rpb, part);
-    else if (L == 64) hipLaunchKernelGGL((k_gram<double, 64>), grid, blk, 0, st, X, rows, rpb, part);
-    else launch_gram_any_f64(st, X, rows, rpb, gram_num_parts(rows), L, part);
-}
-// Gram of the tall f32 factor (B = A Q, M rows) on the f64 matrix cores: W = X^T X as 16x16x4 MFMAs.  Lane (i = lane & 15,
+// Gram of a tall factor (f32: B = A Q, M rows; f64: the sample-side sketch, N rows) on the f64 matrix cores: W = X^T X as 16x16x4 MFMAs.  Lane (i = lane & 15,
 // k = lane >> 4) converts X[n + k][16 g + i] once and uses it both as the A element (X^T tile g) and as the B element
 // (X tile g); only the upper-triangular tiles are computed, the lower ones are mirrored on store.  Four waves take
 // interleaved 4-row groups and are combined through LDS in a fixed order.  (The VALU version spent 132 us on the
 // 128 MB factor -- LDS-read bound; this one is HBM-bound.)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <int L>
-__global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, int64_t rows, int64_t rpb,
+template <typename TX, int L>
+__global__ __launch_bounds__(256) void k_gram_mfma(const TX* __restrict__ X, int64_t rows, int64_t rpb,
                                                    double* __restrict__ part) {
     constexpr int G = L / 16, NT = G * (G + 1) / 2;
     __shared__ double red[3][NT][64][4];
@@ -737,13 +668,13 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
     const int64_t r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
     // 16 rows per wave and trip (4 MFMA k-steps); the next trip's rows are requested before this trip's MFMAs.  (Three trips ahead
     // measured the same 41.7 us at a million rows: half of that is the f64 matrix pipe itself -- 750k 16x16x4 MFMAs at 64 cycles.)
-    float xc[4][G], xn[4][G];
-    auto load_rows = [&](int64_t n, float (&dst)[4][G]) {
+    TX xc[4][G], xn[4][G];
+    auto load_rows = [&](int64_t n, TX (&dst)[4][G]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t row = n + 4 * u + k;
 #pragma unroll
-            for (int g = 0; g < G; ++g) dst[u][g] = row < r1 ? X[row * L + 16 * g + i] : 0.f;
+            for (int g = 0; g < G; ++g) dst[u][g] = row < r1 ? X[row * L + 16 * g + i] : (TX)0;
         }
     };
     load_rows(r0 + 16 * wv, xc);
@@ -788,11 +719,20 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
                 if (ga != gc) out[c * L + a] = v;
             }
 }
+void launch_gram_f64(hipStream_t st, const double* X, int64_t rows, int L, double* part) {
+    const int64_t rpb = gram_rows_per_block(rows);
+    const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
+    // the f64 matrix cores (v_mfma_f64_16x16x4), as for the f32 factor below: the VALU kernel k_gram<double, L> (an LDS row tile, 8 reads per 16
+    // FMAs) took 12.5 us for 10 000 x 32 -- four of them sit between the GEMM sweeps of a call
+    if (L == 32) hipLaunchKernelGGL((k_gram_mfma<double, 32>), grid, blk, 0, st, X, rows, rpb, part);
+    else if (L == 64) hipLaunchKernelGGL((k_gram_mfma<double, 64>), grid, blk, 0, st, X, rows, rpb, part);
+    else launch_gram_any_f64(st, X, rows, rpb, gram_num_parts(rows), L, part);
+}
 void launch_gram_f32(hipStream_t st, const float* X, int64_t rows, int L, double* part) {
     const int64_t rpb = gram_rows_per_block(rows);
     const dim3 grid((unsigned)gram_num_parts(rows)), blk(256);
-    if (L == 32) hipLaunchKernelGGL((k_gram_mfma<32>), grid, blk, 0, st, X, rows, rpb, part);
-    else if (L == 64) hipLaunchKernelGGL((k_gram_mfma<64>), grid, blk, 0, st, X, rows, rpb, part);
+    if (L == 32) hipLaunchKernelGGL((k_gram_mfma<float, 32>), grid, blk, 0, st, X, rows, rpb, part);
+    else if (L == 64) hipLaunchKernelGGL((k_gram_mfma<float, 64>), grid, blk, 0, st, X, rows, rpb, part);
     else launch_gram_any_f32(st, X, rows, rpb, gram_num_parts(rows), L, part);
 }
 
@@ -973,6 +913,38 @@ __global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ Wg, 
     __shared__ double rs[NN * NN];
     chol_inv_wave<NN>(Wg, n, Zg, flag, rs, (int)threadIdx.x);
 }
+// The same with the fold of the Gram's partial sums in front (k_sum_partials was a launch of its own between k_gram and this one, four
+// times a call): 256 threads sum part[p][e] over the <= 64 parts, four elements and sixteen parts of each in flight per thread, into the
+// LDS block the factorisation then reads -- and reuses for its rows, the wave has every column in registers by then.  Wave 0 factors,
+// the others leave.  256 threads, not 1 024: the factorisation keeps four 32-entry f64 arrays in registers, and a 1 024-thread
+// workgroup is compiled for 128 VGPRs -- it spilled them (33 us; 16 us for the 64-thread kernel + 5 for the sum).  32 x 32 only.
+__global__ __launch_bounds__(256) void k_chol_inv_fold32(const double* __restrict__ part, int P, int n, double* __restrict__ Zg, int* __restrict__ flag) {
+    __shared__ double rs[32 * 32];
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < P; p0 += 16) {
+        double v[4][16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double* pp = part + (size_t)(p0 + u < P ? p0 + u : p0) * 1024 + threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q][u] = pp[256 * q];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += (p0 + u < P) ? v[q][u] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rs[threadIdx.x + 256 * q] = a[q];
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    chol_inv_wave<32>(rs, n, Zg, flag, rs, (int)threadIdx.x);
+}
+// part: P <= 64 partial Gram matrices [32 * 32] (k_gram_mfma's output)
+void launch_chol_inv_fold(hipStream_t st, const double* part, int P, int n, int ld, double* Z, int* flag) {
+    (void)ld;
+    hipLaunchKernelGGL(k_chol_inv_fold32, dim3(1), dim3(256), 0, st, part, P, n, Z, flag);
+}
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
     if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
     else if (ld == 64) hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
@@ -1021,9 +993,6 @@ __global__ __launch_bounds__(256) void k_rightmul(const TX* __restrict__ X, cons
     const int total = (int)rows_here * K;
     float* dst = out32 + n0 * K;
     for (int e = threadIdx.x; e < total; e += 256) dst[e] = osm[(e / K) * KP + (e % K)];
-}
-int init_device_kernels_common() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
 }
 static size_t rightmul_lds(int L, int K, bool f32out) { return sizeof(double) * L * K + (f32out ? sizeof(float) * 256 * (size_t)(K | 1) : 0); }
 void launch_rightmul_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64,
@@ -1123,64 +1092,82 @@ void launch_rightmul_gather_f32(hipStream_t st, const float* X, const int64_t* r
 // sample count; k_scores_sign folds the candidates in workgroup order (ascending rows within a workgroup's chunks, so "first row"
 // needs the row index, not the fold order), applies the sign in place and writes the f32 copy.  Replaces k_rightmul + k_col_sign
 // (one workgroup per column walking all rows: 17 us) + 2 x k_scale_cols.
-constexpr int kScoreParts = 128;
+constexpr int kScoreParts = 48;                       // (x 64 columns x 16 B of candidates = 48 KiB of LDS in k_scores_sign)
 int64_t scores_num_parts(int64_t rows) { const int64_t c = (rows + 255) / 256; return c < kScoreParts ? (c < 1 ? 1 : c) : kScoreParts; }
 template <int L>
 __global__ __launch_bounds__(256) void k_scores(const double* __restrict__ X, int64_t nrows, const double* __restrict__ Z, int K,
                                                 double* __restrict__ out64, double* __restrict__ cand_val, int64_t* __restrict__ cand_idx) {
-    extern __shared__ double zsc[];                       // Z [L][K], then per-wave winners: val [4][K], idx [4][K]
-    double* wval = zsc + L * K;
-    long long* widx = reinterpret_cast<long long*>(wval + 4 * K);
+    extern __shared__ double zsc[];                       // Z [L][K] | a 256 x 17 tile of the chunk's scores (16 columns at a time) | the workgroup's winners
+    double* tile = zsc + L * K;
+    double* win_val = tile + 256 * 17;                    // [64]
+    long long* win_idx = reinterpret_cast<long long*>(win_val + 64);   // [64]
+    __shared__ double seg_val[256];
+    __shared__ int seg_row[256];
     for (int e = threadIdx.x; e < L * K; e += 256) zsc[e] = Z[e];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 64) { win_val[threadIdx.x] = 0.0; win_idx[threadIdx.x] = -1; }
     __syncthreads();
     const int64_t nchunks = (nrows + 255) / 256;
-    for (int kc = threadIdx.x; kc < 4 * K; kc += 256) { wval[kc] = 0.0; widx[kc] = -1; }
-    __syncthreads();
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const int64_t n = chunk * 256 + threadIdx.x;
+        const int64_t n0 = chunk * 256, n = n0 + threadIdx.x;
         const bool live = n < nrows;
         double x[L];
 #pragma unroll
         for (int j = 0; j < L; ++j) x[j] = live ? X[n * L + j] : 0.0;
-        for (int kc = 0; kc < K; ++kc) {
-            double a = 0.0;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            const int kn = K - k0 < 16 ? K - k0 : 16;
+            for (int kc = 0; kc < kn; ++kc) {
+                double a = 0.0;
 #pragma unroll
-            for (int j = 0; j < L; ++j) a += x[j] * zsc[j * K + kc];
-            if (live) out64[n * K + kc] = a;
-            // the wave's winner of this column: largest |a|, lowest row on a tie
-            double bv = live ? a : 0.0; long long bi = live ? (long long)n : -1;
+                for (int j = 0; j < L; ++j) a += x[j] * zsc[j * K + k0 + kc];
+                if (live) out64[n * K + k0 + kc] = a;
+                tile[threadIdx.x * 17 + kc] = a;
+            }
+            __syncthreads();
+            // a column's winner: the largest |score|, the lowest row on a tie (a wave-shuffle argmax per column cost six LDS-crossbar round
+            // trips per column and chunk: 32 us for 10 000 x 20; one thread per column walking all 256 staged rows: 48 us).  Thread t
+            // scans the 16 rows of segment t / 16 for column t % 16, then one thread per column folds the 16 segment winners, rows ascending;
+            // the workgroup's earlier chunks hold lower rows, so they keep a tie.
+            {
+                const int kc = threadIdx.x & 15, seg = threadIdx.x >> 4;
+                const int rows_here = nrows - n0 < 256 ? (int)(nrows - n0) : 256;
+                double cv = 0.0; int cr = -1;
+                if (kc < kn) {
+                    double av[16];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ov = __shfl_xor(bv, o); const long long oi = __shfl_xor(bi, o);
-                const bool take = oi >= 0 && (bi < 0 || fabs(ov) > fabs(bv) || (fabs(ov) == fabs(bv) && oi < bi));
-                bv = take ? ov : bv; bi = take ? oi : bi;
+                    for (int r = 0; r < 16; ++r) av[r] = tile[(16 * seg + r) * 17 + kc];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (16 * seg + r < rows_here && (cr < 0 || fabs(av[r]) > fabs(cv))) { cv = av[r]; cr = 16 * seg + r; }
+                }
+                seg_val[threadIdx.x] = cv; seg_row[threadIdx.x] = cr;
             }
-            if (lane == 0 && bi >= 0) {                    // against the wave's winner of earlier chunks (lower rows: they keep a tie)
-                const long long ci = widx[wv * K + kc];
-                if (ci < 0 || fabs(bv) > fabs(wval[wv * K + kc])) { wval[wv * K + kc] = bv; widx[wv * K + kc] = bi; }
+            __syncthreads();
+            if ((int)threadIdx.x < kn) {
+                double cv = win_val[k0 + threadIdx.x]; long long ci = win_idx[k0 + threadIdx.x];
+                for (int sg2 = 0; sg2 < 16; ++sg2) {
+                    const double a = seg_val[16 * sg2 + threadIdx.x]; const int r = seg_row[16 * sg2 + threadIdx.x];
+                    if (r >= 0 && (ci < 0 || fabs(a) > fabs(cv))) { cv = a; ci = n0 + r; }
+                }
+                win_val[k0 + threadIdx.x] = cv; win_idx[k0 + threadIdx.x] = ci;
             }
+            __syncthreads();
         }
     }
-    __syncthreads();
-    for (int kc = threadIdx.x; kc < K; kc += 256) {
-        double bv = 0.0; long long bi = -1;
-        for (int w = 0; w < 4; ++w) {
-            const double ov = wval[w * K + kc]; const long long oi = widx[w * K + kc];
-            const bool take = oi >= 0 && (bi < 0 || fabs(ov) > fabs(bv) || (fabs(ov) == fabs(bv) && oi < bi));
-            bv = take ? ov : bv; bi = take ? oi : bi;
-        }
-        cand_val[(int64_t)blockIdx.x * K + kc] = bv; cand_idx[(int64_t)blockIdx.x * K + kc] = bi;
-    }
+    for (int kc = threadIdx.x; kc < K; kc += 256) { cand_val[(int64_t)blockIdx.x * K + kc] = win_val[kc]; cand_idx[(int64_t)blockIdx.x * K + kc] = win_idx[kc]; }
 }
 __global__ __launch_bounds__(256) void k_scores_sign(double* __restrict__ X64, float* __restrict__ X32, int64_t total, int K,
                                                      const double* __restrict__ cand_val, const int64_t* __restrict__ cand_idx, int parts,
                                                      int* __restrict__ sign) {
+    // the candidates (parts x K <= 128 x 64 pairs) come into LDS with every thread loading its share -- a thread walking its column's
+    // candidates one dependent load at a time waited 40 L2 round trips: 17 us for 40 parts
+    extern __shared__ double cv_s[];                      // values [parts * K], then indices
+    long long* ci_s = reinterpret_cast<long long*>(cv_s + parts * K);
     __shared__ int sg[kMaxSketchCols];
+    for (int e = threadIdx.x; e < parts * K; e += 256) { cv_s[e] = cand_val[e]; ci_s[e] = cand_idx[e]; }
+    __syncthreads();
     for (int kc = threadIdx.x; kc < K; kc += 256) {
         double bv = 0.0; long long bi = -1;
         for (int p = 0; p < parts; ++p) {
-            const double ov = cand_val[(int64_t)p * K + kc]; const long long oi = cand_idx[(int64_t)p * K + kc];
+            const double ov = cv_s[p * K + kc]; const long long oi = ci_s[p * K + kc];
             const bool take = oi >= 0 && (bi < 0 || fabs(ov) > fabs(bv) || (fabs(ov) == fabs(bv) && oi < bi));
             bv = take ? ov : bv; bi = take ? oi : bi;
         }
@@ -1197,16 +1184,17 @@ __global__ __launch_bounds__(256) void k_scores_sign(double* __restrict__ X64, f
 }
 void launch_scores(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64, double* cand_val, int64_t* cand_idx) {
     const dim3 grid((unsigned)scores_num_parts(rows)), blk(256);
-    const size_t lds = sizeof(double) * ((size_t)L * K + 4 * (size_t)K) + sizeof(long long) * 4 * (size_t)K;
+    const size_t lds = sizeof(double) * ((size_t)L * K + 256 * 17 + 64) + sizeof(long long) * 64;      // (L = K = 64: 68 KiB, opted in by init_device_kernels_common)
     if (L == 32) hipLaunchKernelGGL((k_scores<32>), grid, blk, lds, st, X, rows, Z, K, out64, cand_val, cand_idx);
     else hipLaunchKernelGGL((k_scores<64>), grid, blk, lds, st, X, rows, Z, K, out64, cand_val, cand_idx);
 }
 void launch_scores_sign(hipStream_t st, double* out64, float* out32, int64_t rows, int K, const double* cand_val, const int64_t* cand_idx,
                         int64_t parts, int* sign) {
     const int64_t total = rows * K;
-    int64_t blocks = (total + 255) / 256;
-    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);      // (every workgroup folds the candidates: keep them few)
-    hipLaunchKernelGGL(k_scores_sign, dim3((unsigned)blocks), dim3(256), 0, st, out64, out32, total, K, cand_val, cand_idx, (int)parts, sign);
+    int64_t blocks = (total + 1023) / 1024;                          // four elements per thread
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);         // (every workgroup loads the candidates: keep them few)
+    const size_t lds = (sizeof(double) + sizeof(long long)) * (size_t)parts * K;
+    hipLaunchKernelGGL(k_scores_sign, dim3((unsigned)blocks), dim3(256), lds, st, out64, out32, total, K, cand_val, cand_idx, (int)parts, sign);
 }
 
 constexpr int kColsumRowsPerBlock = 256;
@@ -1411,6 +1399,13 @@ __global__ __launch_bounds__(256) void k_f32_to_f64(const float* __restrict__ in
 }
 void launch_f32_to_f64(hipStream_t st, const float* in, double* out, int64_t n) {
     hipLaunchKernelGGL(k_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+}
+
+// > 64 KiB of dynamic LDS is an opt-in the runtime records per device
+int init_device_kernels_common() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rightmul<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scores<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    return (int)e;
 }
 
 }  // namespace gpca

@@ -1,73 +1,51 @@
-// The small dense step of the randomized PCA on the device: the symmetric eigenproblem of the l x l Gram of the
-// projection B = A Q, and everything that used to hang on its result on the host -- the descending sort, singular values, eigenvalues,
-// the two l x k factors that turn Q into scores and B into loadings.  One workgroup; the call's stream never waits for the host
-// (main.rs:648-660 is one opaque call in the reference too).
+// The small dense step of the randomized PCA on the device ("one-sided Jacobi in a single workgroup, f64"): the
+// symmetric eigenproblem of the l x l Gram of the projection B = A Q, and everything that used to hang on its result on the host -- the
+// descending sort, singular values, eigenvalues, the two l x k factors that turn Q into scores and B into loadings.  One workgroup; the
+// call's stream never waits for the host (main.rs:648-660 is one opaque call in the reference too).
 //
-// Algorithm: Householder tridiagonalisation + implicit QL (the EISPACK tred2 / tql2 pair, the same pair gpca_host_eigh_desc runs on
-// the CPU as the pin of tests/test_abi.py), arranged for ONE wave (lane j owns rows / columns j and, for 64 < n <= 128, j + 64):
-//   * the matrix lives in LDS with an odd row pitch (a column walk across lanes and a row walk across lanes are both conflict-free);
-//     the diagonal and sub-diagonal live in registers, entry i in lane i, read with v_readlane (i is wave-uniform) and written
-//     with a compare-and-select: the serial parts of both phases touch no LDS and carry no predicated region;
-//   * tred2: both triangles are kept current, so the matrix-vector product and the rank-2 update of a step walk the lane's own row;
-//     the step's two scalar sums are DPP wave reductions;
-//   * tql2: lane t owns ROW t of the eigenvector matrix, so a plane rotation touches only the lane's own two elements.  The
-//     rotation parameters are a serial chain every lane computes redundantly (1 / sqrt by the hardware estimate + one cubic step
-//     instead of hypot + two divisions); the next rotation's d[i], e[i] and matrix element are fetched one rotation ahead;
-//   * the wave reaches every exit: the QL loop is bounded (200 sweeps per eigenvalue, as on the host), NaN input compares false
-//     in the deflation test and falls through.
-// First form (round 5, two waves, d / e in LDS, lane-0 writes): 353 us at n = 30, 6 ms at n = 128, at a shader clock of 2.40 GHz --
-// every rotation waited for an LDS write to land (profiles/r5_kbench_summary.md).
-// The input is scaled by a power of two (exact) so that its largest entry is in [0.5, 1): the sums of squares of the rotation chain
-// can neither overflow nor underflow for any finite Gram matrix.
+// Algorithm: cyclic two-sided Jacobi in the round-robin (Brent-Luk) order, arranged so that NO rotation needs another thread's data:
+//   * the matrix (padded with zero rows / columns to L = 32, 64 or 128) is cut into 2 x 2 blocks and a thread OWNS block (I, J) of A and
+//     of the eigenvector matrix V in registers; a step rotates the index pairs (2I, 2I + 1) for all I at once, so the row rotation of a
+//     block needs (c, s) of pair I, its column rotation (c, s) of pair J, and both act inside the block;
+//   * the 2 x 2 diagonal block of a pair holds a_pp, a_pq, a_qq: every thread reads the diagonal blocks of ITS row pair and ITS column pair
+//     from the exchange buffer and computes both rotations itself (the same numbers in every thread of a block row / column; 1 / sqrt and
+//     1 / x from the hardware estimates + a cubic / one Newton step, branch-free so that the two chains interleave): no (c, s) to post,
+//     no barrier for them;
+//   * the next pairing is made adjacent again by moving every element to its new place THROUGH LDS (rows and columns of A, columns of
+//     V, one fixed permutation every step; every other pair of rows is skewed by one double so that the scattered 8-byte stores of a
+//     wave spread over all bank slots), after which every thread reads its new block back.  The exchange buffers alternate, so ONE
+//     barrier per step is enough (L = 128 has room for one buffer: four barriers per step); L - 1 steps per sweep, ~8 sweeps; a sweep
+//     in which no pair was above 2e-15 before its rotation was the last one;
+//   * padded indices never mix with real ones (their off-diagonal entries are exactly zero), so their unit eigenvectors are told from
+//     genuine zero eigenvalues by where their columns live.
+// The input is scaled by a power of two (exact) so that its largest entry is in [0.5, 1): squares can neither overflow nor underflow, and
+// "negligible" is an absolute 1e-17.  Every thread reaches every exit: NaN compares false (no rotation, the sweep count ends at once),
+// and the sweep count is capped.
+//
+// Why not QL: the first two forms of this file were the EISPACK tred2 / tql2 pair the host pin (gpca_host_eigh_desc) runs, on one or two
+// waves.  A lone wave issues one instruction every ~5 cycles and waits 8 for a dependent f64 result, 20 for v_rsq_f64, ~75 for an LDS
+// round trip (scripts/kbench/probe_lat.hip): the 923 serial plane rotations of n = 30 cost ~370 cycles each however they were arranged --
+// 250 us a call against 126 us for the host round trip they replace, and 7 ms at n = 128 (profiles/r5_kbench_summary.md).  Jacobi spends
+// more flops and keeps four to sixteen waves busy: 138 us at n = 30 (248 steps of ~1 200 cycles: two rotation chains ~550, the LDS
+// exchange and its barrier the rest), 0.9 ms at n = 64; at n = 128 the exchange is LDS-bandwidth bound (8.5 ms: open).
 #include "kernels.h"
 
 #ifndef GPCA_EIG_ABL
-#define GPCA_EIG_ABL 0          // harness only (wrong results): 1 no d / e write-back in a rotation, 2 no matrix traffic, 4 no operand prefetch, 8 raw v_rsq
-#endif
+#define GPCA_EIG_ABL 0          // harness only (wrong results, exactly 8 sweeps): 1 fixed rotation instead of the chains, 2 no V update / exchange,
+#endif                          // 4 no exchange of A
 #ifndef GPCA_EIG_STAMP
 #define GPCA_EIG_STAMP 0        // scripts/kbench/kbench_eig.hip: s_memrealtime (100 MHz) at the phase boundaries into res[kEigResFlag + 2 ..]
 #endif
 #if GPCA_EIG_STAMP
-__device__ unsigned long long g_eig_stamp[16];      // [2 s]: s_memrealtime (100 MHz), [2 s + 1]: s_memtime (shader clock) at stamp s
+__device__ unsigned long long g_eig_stamp[16];      // [2 s]: s_memrealtime (100 MHz), [2 s + 1]: s_memtime (shader clock) at stamp s; [10] sweeps, [11] steps
 #define EIG_STAMP(SLOT) { if (threadIdx.x == 0) { g_eig_stamp[2 * (SLOT)] = __builtin_amdgcn_s_memrealtime(); g_eig_stamp[2 * (SLOT) + 1] = __builtin_amdgcn_s_memtime(); } }
 #else
 #define EIG_STAMP(SLOT)
-#endif
-#if GPCA_EIG_STAMP
-#define EIG_COUNT(SLOT, N) { if (threadIdx.x == 0) g_eig_stamp[10 + (SLOT)] += (N); }
-#else
-#define EIG_COUNT(SLOT, N)
 #endif
 
 namespace gpca {
 
 #define EIGDEV __device__ __forceinline__
-EIGDEV void eig_wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-// value of lane `i` (wave-uniform index): two v_readlane into SGPRs
-EIGDEV double eig_rl(double v, int i) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i));
-}
-// A vector of up to 64 * NB entries lives in registers, entry i in lane i % 64 of r[i / 64].
-template <int NB> EIGDEV double eig_get(const double (&r)[NB], int i) {
-    if (NB == 1) return eig_rl(r[0], i);
-    return i < 64 ? eig_rl(r[0], i) : eig_rl(r[NB - 1], i - 64);
-}
-template <int NB> EIGDEV void eig_set(double (&r)[NB], int i, double v, int lane) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) r[b] = (lane + 64 * b == i) ? v : r[b];
-}
-template <int CTRL, int ROWMASK> EIGDEV double eig_dpp0(double v) {     // the DPP-selected lane's value, 0 where the selection leaves the row / the row is masked
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-// sum over the 64 lanes, returned in every lane: inclusive scan inside the rows of 16 (row_shr 1, 2, 4, 8), row_bcast:15 into rows 1 and 3,
-// row_bcast:31 into rows 2 and 3, lane 63 read back -- ~20 VALU operations instead of six LDS crossbar round trips
-EIGDEV double eig_wave_sum(double x) {
-    x += eig_dpp0<0x111, 0xf>(x); x += eig_dpp0<0x112, 0xf>(x); x += eig_dpp0<0x114, 0xf>(x); x += eig_dpp0<0x118, 0xf>(x);
-    x += eig_dpp0<0x142, 0xa>(x); x += eig_dpp0<0x143, 0xc>(x);
-    return eig_rl(x, 63);
-}
 // 1 / sqrt(x) for normal positive x: v_rsq_f64 (3e-8 relative, measured: scripts/kbench/kbench_eig.hip) + one cubic (Halley) step:
 // y (1 + h (1/2 + 3/8 h)), h = 1 - x y^2 -- five operations, four deep, full precision (the two Newton steps it replaces: eight, eight deep)
 EIGDEV double eig_rsqrt(double x) {
@@ -76,283 +54,85 @@ EIGDEV double eig_rsqrt(double x) {
     return fma(y * h, fma(0.375, h, 0.5), y);
 }
 
-// Householder reduction to tridiagonal form, ONE wave: lane j owns rows / columns j + 64 b of V (n x n, pitch P, symmetric on entry, both
-// triangles kept current so that every inner product and update walks the lane's own row).  On return V is the accumulated transformation,
-// td = diagonal, e = sub-diagonal (e[0] = 0), both distributed over the lanes.  The input is prescaled (largest entry < 1): JAMA's
-// per-step rescaling is not needed.
-template <int NB>
-EIGDEV void eig_tred2(int n, int P, double* __restrict__ V, double (&td)[NB], double (&e)[NB], int lane) {
-    double hreg[NB];
-    int row[NB];                                               // the lane's rows, clamped into the matrix (lanes beyond n repeat row n - 1: same values, same writes)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { hreg[b] = 0.0; e[b] = 0.0; td[b] = 0.0; row[b] = (lane + 64 * b < n) ? lane + 64 * b : n - 1; }
-    for (int i = n - 1; i > 0; --i) {
-        double u[NB], q[NB], p[NB];
-        double hs = 0.0;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { u[b] = (lane + 64 * b < i) ? V[i * P + row[b]] : 0.0; hs = fma(u[b], u[b], hs); }
-        double h = eig_wave_sum(hs);
-        const double f = eig_get<NB>(u, i - 1);
-        if (h == 0.0) {                                        // nothing to annihilate (or below 1e-162 of the largest entry)
-            eig_set<NB>(e, i, f, lane);
-        } else {
-            double g = sqrt(h);
-            if (f > 0) g = -g;
-            eig_set<NB>(e, i, g, lane);
-            h -= f * g;
-            eig_set<NB>(u, i - 1, f - g, lane);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { if (lane + 64 * b < i) V[row[b] * P + i] = u[b]; p[b] = 0.0; }      // the Householder vector stays in column i
-            // p = A u over the leading i x i block, the lane's own rows.  Eight columns per trip, written out (v_readlane is a convergent
-            // operation: the compiler will not unroll a runtime loop around it, and one LDS round trip per column is the whole cost);
-            // columns past i - 1 are clamped into the matrix and weighted 0
-            for (int k0 = 0; k0 < i; k0 += 8) {
-                double av[NB][8], uk[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int kk = k0 + t < n ? k0 + t : n - 1;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) av[b][t] = V[row[b] * P + kk];
-                    const double x = eig_get<NB>(u, kk);
-                    uk[t] = k0 + t < i ? x : 0.0;
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) p[b] = fma(av[b][t], uk[t], p[b]);
-            }
-            double fs = 0.0;
-            const double hinv = 1.0 / h;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { p[b] = (lane + 64 * b < i) ? p[b] * hinv : 0.0; fs = fma(p[b], u[b], fs); }
-            const double hh = eig_wave_sum(fs) / (h + h);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) q[b] = p[b] - hh * u[b];
-            for (int k0 = 0; k0 < i; k0 += 8) {               // A -= u q^T + q u^T, the lane's own rows (u = q = 0 in the lanes past i - 1 and for the clamped columns)
-                double av[NB][8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int kk = k0 + t < n ? k0 + t : n - 1;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) av[b][t] = V[row[b] * P + kk];
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int kk = k0 + t < n ? k0 + t : n - 1;
-                    const double x = eig_get<NB>(u, kk), y = eig_get<NB>(q, kk);
-                    const double uk = k0 + t < i ? x : 0.0, qk = k0 + t < i ? y : 0.0;
-                    if (k0 + t < i) {
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) V[row[b] * P + kk] = av[b][t] - (u[b] * qk + q[b] * uk);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) if (lane + 64 * b < i) V[i * P + row[b]] = 0.0;
-        eig_set<NB>(hreg, i, h, lane);
-        eig_wsync();
-    }
-    for (int i = 0; i < n - 1; ++i) {                          // accumulate the transformations
-#pragma unroll
-        for (int b = 0; b < NB; ++b) if (lane + 64 * b == i) { td[b] = V[i * P + i]; V[i * P + i] = 1.0; }
-        eig_wsync();
-        const double h = eig_get<NB>(hreg, i + 1);
-        if (h != 0.0) {
-            double uk[NB], wk[NB], g[NB];
-            const double hinv = 1.0 / h;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { uk[b] = (lane + 64 * b <= i) ? V[row[b] * P + (i + 1)] : 0.0; wk[b] = uk[b] * hinv; g[b] = 0.0; }
-            for (int k0 = 0; k0 <= i; k0 += 8) {               // g = u^T (the lane's own column), rows 0 .. i
-                double av[NB][8], ut[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int kk = k0 + t < n ? k0 + t : n - 1;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) av[b][t] = V[kk * P + row[b]];
-                    const double x = eig_get<NB>(uk, kk);
-                    ut[t] = k0 + t <= i ? x : 0.0;
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) g[b] = fma(ut[t], av[b][t], g[b]);
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) g[b] = (lane + 64 * b <= i) ? g[b] : 0.0;     // (the columns past i stay as they are)
-            for (int k0 = 0; k0 <= i; k0 += 8) {
-                double av[NB][8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int kk = k0 + t < n ? k0 + t : n - 1;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) av[b][t] = V[kk * P + row[b]];
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int kk = k0 + t < n ? k0 + t : n - 1;
-                    const double wkk = eig_get<NB>(wk, kk);
-                    if (k0 + t <= i) {
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) V[kk * P + row[b]] = av[b][t] - g[b] * wkk;
-                    }
-                }
-            }
-        }
-        eig_wsync();
-#pragma unroll
-        for (int b = 0; b < NB; ++b) if (lane + 64 * b <= i) V[row[b] * P + (i + 1)] = 0.0;
-        eig_wsync();
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) if (lane + 64 * b == n - 1) { td[b] = V[(n - 1) * P + (n - 1)]; V[(n - 1) * P + (n - 1)] = 1.0; }
-    eig_wsync();
+// 1 / x for normal x: v_rcp_f64 (4e-8 relative) + two Newton steps
+EIGDEV double eig_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
 }
 
-// Implicit QL on the tridiagonal (d, e distributed over the lanes as above); lane t rotates rows t + 64 b of V.  Returns 1 if a sweep count
-// hit the cap.  Inside a sweep nothing is predicated and nothing waits for LDS but the lane's own row: the rotation's operands d[i], e[i]
-// come by v_readlane one rotation ahead, its results go back by a compare-and-select, the history the sweep's last step needs (the sine
-// before the last rotation, the cosine before the last two) is taken by peeling those two rotations off the loop.
-template <int NB>
-EIGDEV int eig_tql2(int n, int P, double* __restrict__ V, double (&d)[NB], double (&e)[NB], int lane) {
-    const double eps = 2.220446049250313e-16;
-    int capped = 0;
-    int row[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) row[b] = (lane + 64 * b < n) ? lane + 64 * b : n - 1;
-    {   // e[i - 1] = e[i], e[n - 1] = 0
-        double en[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            double nx = __shfl_down(e[b], 1);
-            if (lane == 63) nx = (b + 1 < NB) ? eig_rl(e[NB - 1], 0) : 0.0;
-            en[b] = (lane + 64 * b + 1 < n) ? nx : 0.0;
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) e[b] = en[b];
-    }
-    double f = 0.0, tst1 = 0.0;
-    for (int l = 0; l < n; ++l) {
-        tst1 = fmax(tst1, fabs(eig_get<NB>(d, l)) + fabs(eig_get<NB>(e, l)));
-        // an off-diagonal entry at or below thr is zero: eps * tst1 as on the host, and never below 1e-140 of the (prescaled) matrix, so
-        // that p^2 + e^2 of a rotation stays a normal number
-        const double thr = fmax(eps * tst1, 1e-140);
-        int m = n - 1;                                         // first index >= l whose e is negligible (e[n - 1] = 0)
-#pragma unroll
-        for (int b = NB - 1; b >= 0; --b) {
-            const int idx = lane + 64 * b;
-            const unsigned long long mk = __ballot(idx >= l && idx < n && !(fabs(e[b]) > thr));
-            if (mk) m = 64 * b + __ffsll((long long)mk) - 1;
-        }
-        if (m > l) {
-            int iter = 0;
-            double el_cur;
-            do {
-                ++iter;
-                const double g0 = eig_get<NB>(d, l), el0 = eig_get<NB>(e, l);
-                double p = (eig_get<NB>(d, l + 1) - g0) / (2.0 * el0);
-                double r = fabs(p) < 1e150 ? sqrt(fma(p, p, 1.0)) : fabs(p);
-                if (p < 0) r = -r;
-                const double dl_new = el0 / (p + r), dl1 = el0 * (p + r);
-                const double hsh = g0 - dl_new;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int idx = lane + 64 * b;
-                    d[b] = idx == l ? dl_new : (idx == l + 1 ? dl1 : ((idx > l + 1 && idx < n) ? d[b] - hsh : d[b]));
-                }
-                f += hsh;
-                p = eig_get<NB>(d, m);
-                double c = 1.0, s = 0.0, c3 = 1.0, s2 = 0.0;
-                const double el1 = eig_get<NB>(e, l + 1);
-                double xhi[NB];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) xhi[b] = V[row[b] * P + m];
-                double di = eig_get<NB>(d, m - 1), ei = eig_get<NB>(e, m - 1);
-                // A rotation = a serial chain (p, e[i] -> 1 / sqrt -> c, s -> the next p: ten dependent operations, the wave has nothing
-                // else to issue meanwhile) and a tail nothing waits for (the new d[i + 1], e[i + 1], the two matrix elements).  The loop body
-                // is the chain of rotation i beside the TAIL of rotation i + 1, so the scheduler has independent work for the chain's bubbles.
-                double t_c = 1.0, t_s = 0.0, t_sp = 0.0, t_g = 0.0, t_h = 0.0, t_di = 0.0, t_rr = 0.0;     // the pending tail's inputs
-                int t_i = -1;
-                double xlo_p[NB];
-                auto tail = [&]() {                            // rotation t_i's results: e[t_i + 1], d[t_i + 1], V[:, t_i + 1], the running V[:, t_i]
-                    const double e_up = t_sp * t_rr;
-                    const double d_up = t_h + t_s * fma(t_c, t_g, t_s * t_di);
-                    if (!(GPCA_EIG_ABL & 1)) { eig_set<NB>(e, t_i + 1, e_up, lane); eig_set<NB>(d, t_i + 1, d_up, lane); }
-                    else { t_rr += e_up + d_up; }
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) { if (!(GPCA_EIG_ABL & 2)) V[row[b] * P + (t_i + 1)] = fma(t_s, xlo_p[b], t_c * xhi[b]); xhi[b] = fma(t_c, xlo_p[b], -(t_s * xhi[b])); }
-                };
-                auto rotate = [&](int i) {
-                    const int ip = i > l ? i - 1 : l;          // the next rotation's operands, one rotation ahead
-                    const double dn = (GPCA_EIG_ABL & 4) ? di * 0.999 : eig_get<NB>(d, ip), en = (GPCA_EIG_ABL & 4) ? ei * 0.999 : eig_get<NB>(e, ip);
-                    double xlo[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) xlo[b] = (GPCA_EIG_ABL & 2) ? xhi[b] * 0.5 : V[row[b] * P + i];
-                    // chain
-                    const double g = c * ei, h = c * p;
-                    const double sq = fma(p, p, ei * ei);
-                    const double rinv = (GPCA_EIG_ABL & 8) ? __builtin_amdgcn_rsq(sq) : eig_rsqrt(sq);
-                    const double s_prev = s;
-                    s = ei * rinv; c = p * rinv;
-                    p = fma(c, di, -(s * g));
-                    // the previous rotation's tail (independent of everything above)
-                    if (t_i >= 0) tail();
-                    t_i = i; t_c = c; t_s = s; t_sp = s_prev; t_g = g; t_h = h; t_di = di; t_rr = sq * rinv;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) xlo_p[b] = xlo[b];
-                    di = dn; ei = en;
-                };
-                int i = m - 1;
-                EIG_COUNT(0, 1) EIG_COUNT(1, m - l)
-                for (; i >= l + 2; --i) rotate(i);
-                if (i == l + 1) { c3 = c; rotate(l + 1); }
-                s2 = s;
-                rotate(l);
-                tail();
-#pragma unroll
-                for (int b = 0; b < NB; ++b) V[row[b] * P + l] = xhi[b];
-                p = -s * s2 * c3 * el1 * el0 / dl1;
-                el_cur = s * p;
-                eig_set<NB>(e, l, el_cur, lane);
-                eig_set<NB>(d, l, c * p, lane);
-            } while (fabs(el_cur) > thr && iter < 200);
-            if (fabs(el_cur) > thr) capped = 1;
-        }
-        eig_set<NB>(d, l, eig_get<NB>(d, l) + f, lane);
-        eig_set<NB>(e, l, 0.0, lane);
-    }
-    return capped;
+// Off-diagonal entries of the prescaled matrix (largest entry in [0.5, 1)): at or below kJacSkip a pair is left alone; a sweep whose pairs
+// were all at or below kJacDone before their rotations was the last one.
+constexpr double kJacSkip = 1e-17, kJacDone = 2e-15;
+template <int L> struct JacCfg {
+    static constexpr int H = L / 2;                            // index pairs = 2 x 2 blocks per side
+    static constexpr int NT = L == 32 ? 256 : 1024;            // threads
+    static constexpr int NBK = H * H / NT;                     // blocks per thread: 1, 1, 4
+    static constexpr int LP = L + 2;                           // LDS row pitch in doubles (room for the skew below)
+    static constexpr bool DB = L <= 64;                        // exchange buffers of A and of V, each twice (one barrier per step); L = 128: one buffer in all
+    static constexpr int NBUF = DB ? 4 : 1;
+};
+// round-robin with index 0 fixed: the slot the index at slot s moves to after a step (pairs are slots (2i, 2i + 1))
+template <int L> EIGDEV int jac_dest(int s) { return s == 0 ? 0 : (s == 1 ? 2 : ((s & 1) ? s - 2 : (s == L - 2 ? L - 1 : s + 2))); }
+// LDS offset (doubles) of element (r, c): every other pair of rows starts one double later, so that the scattered 8-byte stores of a
+// step (64 lanes: 4 block rows x 16 block columns, column stride 2) fill all sixteen 8-byte bank slots instead of eight
+template <int L> EIGDEV int jac_at(int r, int c) { return r * JacCfg<L>::LP + ((r >> 1) & 1) + c; }
+
+// The rotation that annihilates a_pq of [[app, apq], [apq, aqq]]: J = [[c, s], [-s, c]], t = tan = sign(z) / (|z| + sqrt(1 + z^2)), z = (aqq - app) / (2 apq),
+// written as 2 apq / (d + sign(d) sqrt(d^2 + 4 apq^2)).  c is refined to full precision (it keeps V orthonormal); t is not exact to the last
+// bits and need not be: whatever it leaves of a_pq is rotated again.  big: |apq| was above kJacDone.
+EIGDEV void jac_rot(double app, double a01, double a10, double aqq, double& c, double& s, bool& big) {
+    const double b2 = a01 + a10, dd = aqq - app;               // 2 apq of the symmetrised pair
+#if GPCA_EIG_ABL & 1
+    c = 0.8; s = 0.6; big = false; return;
+#endif
+    // no branch: a thread runs two of these chains (its row pair's and its column pair's) and the scheduler interleaves them only inside
+    // one basic block; a pair at or below kJacSkip computes with sq = 1 and is deselected at the end (NaN input: deselected too)
+    const bool live = fabs(b2) > 2.0 * kJacSkip;
+    const double sq = live ? fma(dd, dd, b2 * b2) : 1.0;
+    const double r = sq * eig_rsqrt(sq);
+    const double den = live ? dd + (dd >= 0.0 ? r : -r) : 1.0;
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = fma(rc, fma(-den, rc, 1.0), rc);                      // one Newton step: 2e-15
+    const double t = b2 * rc;                                  // |t| <= 1
+    const double ci = eig_rsqrt(fma(t, t, 1.0));
+    c = live ? ci : 1.0; s = live ? t * ci : 0.0;
+    big = fabs(b2) > 2.0 * kJacDone;                           // (NaN: false)
 }
 
-// src: the Gram W [L][L] (nslices == 0) or `nslices` partial sums of it [nslices][L * L] (summed here in slice order); only the
+// src: the Gram W [Lw][Lw] (nslices == 0) or `nslices` partial sums of it [nslices][Lw * Lw] (summed here in slice order); only the
 // leading n x n block is used, symmetrised as (W + W^T) / 2.  Outputs:
 //   res[kEigResSv + j]   = sqrt(max(w_j, 0)), j < n (0 beyond)          res[kEigResEig + c] = w_c / denom, c < k
 //   res[kEigResW + j]    = w_j (descending)                             res[kEigResFlag] = *cholflag, res[kEigResFlag + 1] = sweep cap hit
-//   Z [2][L][k]: zmode 0: Z0 = V_k diag(sv), Z1 = V_k diag(1 / sv) (0 where sv = 0); zmode 1: Z0 = Z1 = V_k.  Rows >= n are zero.
+//   Z [2][Lw][k]: zmode 0: Z0 = V_k diag(sv), Z1 = V_k diag(1 / sv) (0 where sv = 0); zmode 1: Z0 = Z1 = V_k.  Rows >= n are zero.
 //   Vout (may be NULL) [n][n]: the eigenvectors in columns, sorted like w.
-template <int NB>      // rows per lane of the one-wave solver: n <= 64 NB
-__global__ __launch_bounds__(256) void k_small_eigh(const double* __restrict__ src, int nslices, int n, int L, int k, int zmode, double denom,
-                                                    const int* __restrict__ cholflag, double* __restrict__ Z, double* __restrict__ res,
-                                                    double* __restrict__ Vout) {
-    extern __shared__ double eig_sm[];
-    const int P = n | 1;
-    double* V = eig_sm;                                        // [n][P]
-    double* wsh = V + (size_t)n * P;                           // [128]: sorted eigenvalues (scaled)
-    int* order = reinterpret_cast<int*>(wsh + 128);            // [128]: column of V that holds eigenvector c
-    __shared__ double redmax[256];
+template <int L>
+__global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __restrict__ src, int nslices, int n, int Lw, int k, int zmode, double denom,
+                                                             const int* __restrict__ cholflag, double* __restrict__ Z, double* __restrict__ res,
+                                                             double* __restrict__ Vout) {
+    using C = JacCfg<L>;
+    constexpr int H = C::H, NT = C::NT, NBK = C::NBK, LP = C::LP, BUF = L * LP;
+    extern __shared__ double eig_sm[];                         // DB: [A0 | V0 | A1 | V1] of L x LP each; else one buffer, A's then V's
+    __shared__ double wsl[128];                                // eigenvalue by slot, then sorted
+    __shared__ int order[128], genuine[128];
+    __shared__ double redmax[NT];
+    __shared__ int big[2];                                     // a pair above kJacDone was rotated in the sweep (two flags, alternating)
     const int tid = threadIdx.x;
 #if GPCA_EIG_STAMP
     if (tid == 0) { g_eig_stamp[10] = 0; g_eig_stamp[11] = 0; }
 #endif
     EIG_STAMP(0)
     const int S = nslices > 0 ? nslices : 1;
-    const size_t LL = (size_t)L * L;
-    // fold the slices into LDS, all 256 threads, four elements and eight slices of each in flight per thread (the sum keeps slice order)
-    for (int e0 = tid; e0 < n * n; e0 += 1024) {
+    const size_t LL = (size_t)Lw * Lw;
+    double* buf0 = eig_sm;
+    // fold the slices into LDS, four elements and eight slices of each in flight per thread (the sum keeps slice order); pad = 0
+    for (int e0 = tid; e0 < BUF; e0 += NT) buf0[e0] = 0.0;
+    __syncthreads();
+    for (int e0 = tid; e0 < n * n; e0 += 4 * NT) {
         const double* p[4];
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int e1 = e0 + 256 * q; const int e2 = e1 < n * n ? e1 : e0; p[q] = src + (size_t)(e2 / n) * L + (e2 % n); }
+        for (int q = 0; q < 4; ++q) { const int e1 = e0 + NT * q; const int e2 = e1 < n * n ? e1 : e0; p[q] = src + (size_t)(e2 / n) * Lw + (e2 % n); }
         for (int s0 = 0; s0 < S; s0 += 8) {
             double v[4][8];
 #pragma unroll
@@ -367,82 +147,187 @@ __global__ __launch_bounds__(256) void k_small_eigh(const double* __restrict__ s
                 for (int q = 0; q < 4; ++q) acc[q] += (s0 + u < S) ? v[q][u] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int e1 = e0 + 256 * q; if (e1 < n * n) V[(e1 / n) * P + (e1 % n)] = acc[q]; }
+        for (int q = 0; q < 4; ++q) { const int e1 = e0 + NT * q; if (e1 < n * n) buf0[jac_at<L>(e1 / n, e1 % n)] = acc[q]; }
     }
     __syncthreads();
-    // symmetrise (W + W^T) / 2 in place, largest finite magnitude for the prescale
+    // symmetrise in place (the upper-triangle thread of a pair writes both), largest finite magnitude for the prescale
     double amax = 0.0;
-    for (int e0 = tid; e0 < n * n; e0 += 256) {
-        const int a = e0 / n, c = e0 - a * n;
-        if (a <= c) {
-            const double v = 0.5 * (V[a * P + c] + V[c * P + a]);
-            V[a * P + c] = v; V[c * P + a] = v;
-            const double av = fabs(v);
-            amax = (av > amax && av < INFINITY) ? av : amax;
+    for (int e0 = tid; e0 < n * n; e0 += NT) {
+        const int r = e0 / n, c = e0 - r * n;
+        if (r <= c) {
+            const double x = 0.5 * (buf0[jac_at<L>(r, c)] + buf0[jac_at<L>(c, r)]);
+            buf0[jac_at<L>(r, c)] = x; buf0[jac_at<L>(c, r)] = x;
+            const double ax = fabs(x);
+            amax = (ax > amax && ax < INFINITY) ? ax : amax;
         }
     }
     redmax[tid] = amax;
+    if (tid < 2) big[tid] = 0;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) { if (tid < st) redmax[tid] = fmax(redmax[tid], redmax[tid + st]); __syncthreads(); }
+    for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) redmax[tid] = fmax(redmax[tid], redmax[tid + st]); __syncthreads(); }
     amax = redmax[0];
     int ex = 0;
     if (amax > 0.0) (void)frexp(amax, &ex);
     const double sc = ldexp(1.0, -ex), unsc = ldexp(1.0, ex);
-    for (int e0 = tid; e0 < n * n; e0 += 256) { const int a = e0 / n, c = e0 - a * n; V[a * P + c] *= sc; }
-    __syncthreads();
-    if (tid >= 64) return;                                     // one wave from here on: no block barrier below
-    const int lane = tid;
-    EIG_STAMP(1)
-    double d[NB], e[NB];
-    eig_tred2<NB>(n, P, V, d, e, lane);
-    EIG_STAMP(2)
-    const int capped = eig_tql2<NB>(n, P, V, d, e, lane);
-    EIG_STAMP(3)
-    // descending order: rank_j = #{i : w_i > w_j or (w_i == w_j and i < j)}  (= the host's stable selection sort)
+    // the thread's blocks and where their elements go / come from in an exchange (the same every step)
+    double a[NBK][4], v[NBK][4], dI[NBK][4], dJ[NBK][4];        // dI / dJ: the 2 x 2 diagonal blocks of the thread's row pair and column pair
+    int wA[NBK][4], wV[NBK][4], rB[NBK][2], rI[NBK][2], rJ[NBK][2];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int j = lane + 64 * b;
-        int rank = 0;
-        for (int i = 0; i < n; ++i) { const double wi = eig_get<NB>(d, i); rank += (wi > d[b] || (wi == d[b] && i < j)) ? 1 : 0; }
-        if (j < n) { rank = rank < n ? rank : n - 1; order[rank] = j; wsh[rank] = d[b]; }      // (NaN input: keep the writes in range)
+    for (int q = 0; q < NBK; ++q) {
+        const int bk = tid + NT * q, I = bk / H, J = bk - I * H;
+#pragma unroll
+        for (int e1 = 0; e1 < 4; ++e1) {
+            const int r = 2 * I + (e1 >> 1), c = 2 * J + (e1 & 1);
+            wA[q][e1] = jac_at<L>(jac_dest<L>(r), jac_dest<L>(c)); wV[q][e1] = jac_at<L>(r, jac_dest<L>(c));
+            v[q][e1] = r == c ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { rB[q][h] = jac_at<L>(2 * I + h, 2 * J); rI[q][h] = jac_at<L>(2 * I + h, 2 * I); rJ[q][h] = jac_at<L>(2 * J + h, 2 * J); }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                a[q][2 * h + g] = buf0[rB[q][h] + g] * sc; dI[q][2 * h + g] = buf0[rI[q][h] + g] * sc; dJ[q][2 * h + g] = buf0[rJ[q][h] + g] * sc;
+            }
     }
-    eig_wsync();
-    for (int j = lane; j < kMaxSketchCols; j += 64) {
-        const double w = j < n ? wsh[j] * unsc : 0.0;
+    __syncthreads();                                           // (everybody has read buf0: it is the first exchange buffer)
+    EIG_STAMP(1)
+    // ---- sweeps ----
+    int capped = 1, sweeps = 0, cur = 0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        for (int step = 0; step < L - 1; ++step) {
+            // (1) the rotations of the thread's row pair and column pair, each from that pair's diagonal block (every thread of a block row /
+            //     column computes the same numbers: no exchange of (c, s), no barrier for them); A <- R_I^T A R_J, V <- V R_J
+            bool anybig = false;
+#pragma unroll
+            for (int q = 0; q < NBK; ++q) {
+                double cI, sI, cJ, sJ; bool b1, b2;
+                jac_rot(dI[q][0], dI[q][1], dI[q][2], dI[q][3], cI, sI, b1);
+                jac_rot(dJ[q][0], dJ[q][1], dJ[q][2], dJ[q][3], cJ, sJ, b2);
+                anybig = anybig || b1 || b2;
+                const double b00 = fma(cI, a[q][0], -(sI * a[q][2])), b01 = fma(cI, a[q][1], -(sI * a[q][3]));
+                const double b10 = fma(sI, a[q][0], cI * a[q][2]), b11 = fma(sI, a[q][1], cI * a[q][3]);
+                a[q][0] = fma(cJ, b00, -(sJ * b01)); a[q][1] = fma(sJ, b00, cJ * b01);
+                a[q][2] = fma(cJ, b10, -(sJ * b11)); a[q][3] = fma(sJ, b10, cJ * b11);
+#if !(GPCA_EIG_ABL & 2)
+                const double v00 = v[q][0], v01 = v[q][1], v10 = v[q][2], v11 = v[q][3];
+                v[q][0] = fma(cJ, v00, -(sJ * v01)); v[q][1] = fma(sJ, v00, cJ * v01);
+                v[q][2] = fma(cJ, v10, -(sJ * v11)); v[q][3] = fma(sJ, v10, cJ * v11);
+#endif
+            }
+            if (anybig) big[sweep & 1] = 1;
+            // (2) the next pairing: every element to its new place through LDS, then the thread's new blocks (and its pairs' diagonal blocks) back
+            double* bA = eig_sm + (C::DB ? 2 * cur * BUF : 0);
+            double* bV = C::DB ? bA + BUF : bA;
+#pragma unroll
+            for (int q = 0; q < NBK; ++q)
+#pragma unroll
+                for (int e1 = 0; e1 < 4; ++e1) {
+                    if (!(GPCA_EIG_ABL & 4)) bA[wA[q][e1]] = a[q][e1];
+                    if (C::DB && !(GPCA_EIG_ABL & 2)) bV[wV[q][e1]] = v[q][e1];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NBK; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        if (!(GPCA_EIG_ABL & 4)) { dI[q][2 * h + g] = bA[rI[q][h] + g]; dJ[q][2 * h + g] = bA[rJ[q][h] + g]; a[q][2 * h + g] = bA[rB[q][h] + g]; }
+                        if (C::DB && !(GPCA_EIG_ABL & 2)) v[q][2 * h + g] = bV[rB[q][h] + g];
+                    }
+            if (C::DB) cur ^= 1;                               // (the next step writes the other pair of buffers: a wave one barrier ahead cannot overwrite what a slower one still reads)
+            else {                                             // L = 128: the same buffer once more for V
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NBK; ++q)
+#pragma unroll
+                    for (int e1 = 0; e1 < 4; ++e1) bV[wV[q][e1]] = v[q][e1];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NBK; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) v[q][2 * h + g] = bV[rB[q][h] + g];
+                __syncthreads();
+            }
+        }
+        ++sweeps;
+        // Every thread has passed the barrier of this sweep's last step: the flag is complete; the other one is reset for the next sweep.
+        // Done when no pair of the sweep was above kJacDone BEFORE its rotation: what those rotations leave behind is below rounding
+        // (no confirming sweep: it would rotate nothing).
+        const int any = big[sweep & 1];
+        __syncthreads();
+        if (tid == 0) big[sweep & 1] = 0;                      // (used again two sweeps on; everybody has read it)
+        if (GPCA_EIG_ABL ? sweep == 7 : !any) { capped = 0; break; }
+    }
+#if GPCA_EIG_STAMP
+    if (tid == 0) { g_eig_stamp[10] = sweeps; g_eig_stamp[11] = (unsigned long long)sweeps * (L - 1); }
+#endif
+    (void)sweeps;
+    EIG_STAMP(3)
+    // ---- results: eigenvalue of slot s = the diagonal, its vector = column s of V (rows in the original order) ----
+    __syncthreads();
+    double* bufV = eig_sm;                                     // [L][LP], plain layout from here on
+#pragma unroll
+    for (int q = 0; q < NBK; ++q) {
+        const int bk = tid + NT * q, I = bk / H, J = bk - I * H;
+        if (I == J) { wsl[2 * I] = a[q][0]; wsl[2 * I + 1] = a[q][3]; }
+#pragma unroll
+        for (int e1 = 0; e1 < 4; ++e1) bufV[(2 * I + (e1 >> 1)) * LP + 2 * J + (e1 & 1)] = v[q][e1];
+    }
+    if (tid < 128) order[tid] = 0;
+    __syncthreads();
+    // a padded index keeps a unit vector outside the first n rows: slot t is genuine when its column has weight inside them
+    if (tid < L) { double ss = 0.0; for (int r = 0; r < n; ++r) { const double x = bufV[r * LP + tid]; ss = fma(x, x, ss); } genuine[tid] = ss > 0.25; }
+    __syncthreads();
+    // descending order over the genuine slots: rank_s = #{t genuine : w_t > w_s or (w_t == w_s and t < s)}  (= the host's stable selection sort)
+    double wmine = 0.0; int rank = -1;
+    if (tid < L && genuine[tid]) {
+        wmine = wsl[tid]; rank = 0;
+        for (int t = 0; t < L; ++t) { const double wt = wsl[t]; if (t != tid && genuine[t] && (wt > wmine || (wt == wmine && t < tid))) ++rank; }
+    }
+    __syncthreads();
+    if (rank >= 0 && rank < n) { order[rank] = tid; wsl[rank] = wmine; }       // (wsl re-used: every thread has read what it needs)
+    __syncthreads();
+    for (int j = tid; j < kMaxSketchCols; j += NT) {
+        const double w = j < n ? wsl[j] * unsc : 0.0;
         res[kEigResW + j] = w;
         res[kEigResSv + j] = w > 0.0 ? sqrt(w) : 0.0;
         res[kEigResEig + j] = j < k ? w / denom : 0.0;
     }
-    if (lane == 0) { res[kEigResFlag] = cholflag ? (double)cholflag[0] : 0.0; res[kEigResFlag + 1] = (double)capped; }
-    for (int e0 = lane; e0 < L * k; e0 += 64) {
+    if (tid == 0) { res[kEigResFlag] = cholflag ? (double)cholflag[0] : 0.0; res[kEigResFlag + 1] = (double)capped; }
+    for (int e0 = tid; e0 < Lw * k; e0 += NT) {
         const int r = e0 / k, c = e0 - r * k;
         double z0 = 0.0, z1 = 0.0;
         if (r < n && c < n) {
-            const double v = V[r * P + order[c]];
+            const double x = bufV[r * LP + order[c]];
             if (zmode == 0) {
-                const double w = wsh[c] * unsc;
+                const double w = wsl[c] * unsc;
                 const double sv = w > 0.0 ? sqrt(w) : 0.0;
-                z0 = v * sv; z1 = sv > 0.0 ? v / sv : 0.0;
-            } else { z0 = v; z1 = v; }
+                z0 = x * sv; z1 = sv > 0.0 ? x / sv : 0.0;
+            } else { z0 = x; z1 = x; }
         }
-        Z[e0] = z0; Z[(size_t)L * k + e0] = z1;
+        Z[e0] = z0; Z[(size_t)Lw * k + e0] = z1;
     }
     EIG_STAMP(4)
     if (Vout)
-        for (int e0 = lane; e0 < n * n; e0 += 64) { const int r = e0 / n, c = e0 - r * n; Vout[e0] = V[r * P + order[c]]; }
+        for (int e0 = tid; e0 < n * n; e0 += NT) { const int r = e0 / n, c = e0 - r * n; Vout[e0] = bufV[r * LP + order[c]]; }
 }
 
-static size_t small_eigh_lds(int n) { return sizeof(double) * ((size_t)n * (n | 1) + 128) + sizeof(int) * 128; }
+template <int L> static size_t small_eigh_lds() { return sizeof(double) * (size_t)L * JacCfg<L>::LP * JacCfg<L>::NBUF; }
 int init_device_kernels_eig() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds(128));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds(64));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds<128>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds<64>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds<32>());
     return (int)e;
 }
 void launch_small_eigh(hipStream_t st, const double* src, int nslices, int n, int L, int k, int zmode, double denom, const int* cholflag,
                        double* Z, double* res, double* Vout) {
-    const size_t lds = small_eigh_lds(n);
-    if (n <= 64) hipLaunchKernelGGL(k_small_eigh<1>, dim3(1), dim3(256), lds, st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
-    else hipLaunchKernelGGL(k_small_eigh<2>, dim3(1), dim3(256), lds, st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
+    if (n <= 32) hipLaunchKernelGGL(k_small_eigh<32>, dim3(1), dim3(JacCfg<32>::NT), small_eigh_lds<32>(), st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
+    else if (n <= 64) hipLaunchKernelGGL(k_small_eigh<64>, dim3(1), dim3(JacCfg<64>::NT), small_eigh_lds<64>(), st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
+    else hipLaunchKernelGGL(k_small_eigh<128>, dim3(1), dim3(JacCfg<128>::NT), small_eigh_lds<128>(), st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
 }
 
 }  // namespace gpca

@@ -410,7 +410,9 @@ class GpcaEngine:
     def reset_timings(self):
         self._chk(self._lib.gpca_reset_timings(self._h))
 
-    def enable_timings(self, on: bool):
+    def enable_timings(self, on):
+        """True / 1: HIP events around every timed kernel; n > 1: only every n-th rsvd call records them (the others run without the
+        ~5 us of idle stream an event pair costs); False / 0: off."""
         self._chk(self._lib.gpca_enable_timings(self._h, int(on)))
 
     def timings(self) -> dict:

@@ -322,7 +322,9 @@ typedef struct gpca_kernel_timing {
     double flops;      /* algorithmic (un-padded) flops summed over those launches */
     double bytes;      /* algorithmic HBM bytes summed over those launches */
 } gpca_kernel_timing;
-/* Timings are OFF by default (gpca_enable_timings(h, 1) turns them on); records are folded into per-name totals
+/* Timings are OFF by default (gpca_enable_timings(h, 1) turns them on; n > 1: only every n-th gpca_rsvd call records its events -- a
+ * recorded event pair costs the stream about 5 us of idle time, which a caller who wants per-kernel figures of a long run need not
+ * pay on every call: launches / total_ms then cover the sampled calls only); records are folded into per-name totals
  * once 32768 are pending, so a long-running host never accumulates events.
  * Timings accumulated since the last gpca_reset_timings (events resolved lazily here). */
 GPCA_API int gpca_get_timings(gpca_handle* h, gpca_kernel_timing* out, int32_t cap, int32_t* n);

@@ -1,5 +1,5 @@
 // The device eigen step of gpca_rsvd (csrc/small_eig.hip) alone: per-launch time back to back, the phases of one launch from
-// s_memrealtime stamps (fold + prescale | tred2 | tql2 | sort + outputs), and the residual of what it returns.
+// s_memrealtime stamps (fold + prescale | Jacobi sweeps | sort + outputs), and the residual of what it returns.
 //   hipcc --offload-arch=gfx950 -O3 -DGPCA_EIG_STAMP=1 -o kbench_eig kbench_eig.hip && ./kbench_eig
 #include "../../genomic_pca_amd/csrc/small_eig.hip"
 #include <cmath>
@@ -41,9 +41,9 @@ static int run(int n, int k, int slices) {
     CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_eig_stamp), sizeof sp));
     auto us = [&](int a, int b) { return (double)(sp[2 * b] - sp[2 * a]) * 0.01; };
     const double ghz = (double)(sp[2 * 4 + 1] - sp[1]) / ((double)(sp[2 * 4] - sp[0]) * 10.0);
-    printf("k_small_eigh n = %3d (L = %3d, %2d slices): %.1f us per launch back to back | stamps: fold %.1f, tred2 %.1f, tql2 %.1f, sort+out %.1f us, shader clock %.2f GHz, %llu QL sweeps, %llu rotations = %.0f cycles each | "
+    printf("k_small_eigh n = %3d (L = %3d, %2d slices): %.1f us per launch back to back | stamps: fold %.1f, sweeps %.1f, sort+out %.1f us, shader clock %.2f GHz, %llu Jacobi sweeps, %llu steps = %.0f cycles each | "
            "w0 = %.6e, residual / w0 = %.1e, |V^T V - I| = %.1e, cap flag %.0f\n", n, L, slices, ms / 50 * 1e3,
-           us(0, 1), us(1, 2), us(2, 3), us(3, 4), ghz, sp[10], sp[11], (double)(sp[2 * 3 + 1] - sp[2 * 2 + 1]) / (double)(sp[11] ? sp[11] : 1), R[gpca::kEigResW], resid / R[gpca::kEigResW], orth, R[gpca::kEigResFlag + 1]);
+           us(0, 1), us(1, 3), us(3, 4), ghz, sp[10], sp[11], (double)(sp[2 * 3 + 1] - sp[2 * 1 + 1]) / (double)(sp[11] ? sp[11] : 1), R[gpca::kEigResW], resid / R[gpca::kEigResW], orth, R[gpca::kEigResFlag + 1]);
     hipFree(dW); hipFree(dZ); hipFree(dR); hipFree(dV);
     return 0;
 }

@@ -298,3 +298,22 @@ def test_bed_fixture_against_the_references_own_decoder():
     other = other[:, :n]
     assert np.array_equal(np.where(a1 == -127, 255, 2 - a1.astype(np.int16)), other)
     assert (a1 == -127).sum() == (other == 255).sum() and set(np.unique(a1)) <= {-127, 0, 1, 2}
+
+
+def test_box_muller_math_of_the_sketch_against_long_double_libm(tmp_path):
+    """genomic_pca_amd/csrc/omega_math.h -- the transcendentals k_omega uses for the sketch's Box-Muller draw, written for a 33-bit integer
+    argument -- compiled for the HOST (the same source the device compiles) and held to long-double libm over every binade edge, the
+    ln table's interval edges and 2M random arguments: -2 ln u within 5e-16 relative, sin / cos(2 pi u) within 3e-16 absolute, the draw
+    within 2.5e-15 absolute (|z| <= 6.67) -- as close to the oracle's libm (gpca_oracle.c:omega4) as libm is to itself.  The committed
+    table (csrc/omega_table.inc) is the one the check program prints."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "omega_math_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "genomic_pca_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "omega_math_check.cpp"), "-o", exe])
+    out = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    tab = subprocess.run([exe, "table"], capture_output=True, text=True, timeout=60).stdout
+    inc = open(os.path.join(root, "genomic_pca_amd", "csrc", "omega_table.inc")).read()
+    assert tab.strip() == "\n".join(inc.strip().split("\n")[1:]).strip()
