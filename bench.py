@@ -368,7 +368,7 @@ def extra_config2_line(g, a, device):
                 "top_eigenvalues": [float(x) for x in e.eigenvalues()[:3]]}
 
 
-def streamed_run(g, a, M, N, k, storage, device, snp_offset, rdzv, uid_fn=None, steps=None, warmup=None, cache_gb=0.0):
+def streamed_run(g, a, M, N, k, storage, device, snp_offset, rdzv, uid_fn=None, steps=None, warmup=None, cache_gb=0.0, bench_hold=False):
     """One out-of-core job: stats sweep + `steps` timed gpca_rsvd calls over panels that are regenerated on every sweep."""
     steps = a.steps if steps is None else steps
     warmup = a.warmup if warmup is None else warmup
@@ -378,7 +378,7 @@ def streamed_run(g, a, M, N, k, storage, device, snp_offset, rdzv, uid_fn=None, 
     rank = rdzv.rank if rdzv is not None else 0
     mem = memory_preflight(eng, f"the panel ring of {M} SNPs x {N} samples ({storage}, streamed)",
                            shard_bytes_needed(M, N, storage, k, a.oversample, streamed=True, panel_rows=a.panel_rows, ring=a.ring), rank)
-    eng.stream_open(g.PanelSource.synth16(th16, a.rfit_seed, snp_offset=snp_offset), M, N, panel_rows=a.panel_rows, ring_slots=a.ring,
+    eng.stream_open(g.PanelSource.synth16(th16, a.rfit_seed, snp_offset=snp_offset, bench_hold=bench_hold), M, N, panel_rows=a.panel_rows, ring_slots=a.ring,
                     fused=not a.unfused)
     del th16
     solo = None
@@ -769,11 +769,25 @@ def main():
               M5, N5, k5 = 6_250_000, 500_000, 40
               dt5, tim5, ev5, t_stats5 = streamed_run(g, a5, M5, N5, k5, "2bit", local_rank, 0, None, steps=1, warmup=0, cache_gb=-1.0)
               n_cached5 = tim5.pop("_panels_cached"); tim5.pop("_memory", None)
+              # the same call with the generator out of the way (GPCA_SOURCE_BENCH_HOLD: the ring's buffers keep the panels they were given
+              # first, nothing is regenerated): what the ENGINE does with streamed panels of this shape.  Its eigenvalues mean nothing.
+              dt5h, tim5h, _, _ = streamed_run(g, a5, M5, N5, k5, "2bit", local_rank, 0, None, steps=1, warmup=1, cache_gb=-1.0, bench_hold=True)
+              tim5h.pop("_panels_cached"); tim5h.pop("_memory", None)
+              hidden = streamed_summary(tim5h, 1, M5, N5, k5 + a.oversample, "2bit")
               return {
+                "engine_rate_with_fills_hidden": {
+                    "definition": "the same call, same ring and HBM panel cache, with GPCA_SOURCE_BENCH_HOLD: no panel is generated in the timed call "
+                                  "(every buffer keeps the panel it was given first; the eigenvalues mean nothing): the engine's own rate on streamed "
+                                  "panels of this shape.  Beside it, `gemm_share_of_step` of the real line: the part of the real step that is GEMM "
+                                  "kernel time -- near 1, the fills are hidden behind the sweeps and the generator is not what bounds the line",
+                    "ms_per_step": dt5h * 1e3, "value": M5 * N5 / dt5h, "unit": "SNPs*samples/s",
+                    "gemm_sweeps_ms_per_step": hidden["gemm_sweeps_ms_per_step"], "generator_ms_per_step": hidden["generator_ms_per_step"],
+                    "hbm_GBs_per_sweep_algorithmic": hidden["hbm_GBs_per_sweep_algorithmic"]},
                 "workload": "BASELINE.json configs[4] per-GPU shard, out of core: 6.25M SNPs x 500k samples (781 GB of 2-bit codes per pass, never "
                             "resident), k = 40, l = 50, panels of 131 072 rows from the device generator (GPCA_PANEL_SYNTH16) through a ring of 3",
                 "snps": M5, "samples": N5, "k": k5, "steps": 1, "warmup": 0, "ms_per_step": dt5 * 1e3, "value": M5 * N5 / dt5,
                 "unit": "SNPs*samples/s", "snp_stats_s": t_stats5, "panels_cached_in_hbm": n_cached5,
+                "gemm_share_of_step": streamed_summary(tim5, 1, M5, N5, k5 + a.oversample, "2bit")["gemm_sweeps_ms_per_step"] / (dt5 * 1e3),
                 "streaming": streamed_summary(tim5, 1, M5, N5, k5 + a.oversample, "2bit"),
                 "top_eigenvalues": [float(x) for x in ev5[:3]],
                 "properties": {"eigenvalues_descending": bool(np.all(np.diff(ev5) <= 0)), "structured_eigenvalues_found": int(np.sum(ev5 > 20 * ev5[-1])),

@@ -67,6 +67,7 @@ PANEL_SYNTH16 = 3
 PANEL_MAPPED_I8 = 4
 PANEL_MAPPED_BED = 5
 SOURCE_REGISTER = 1
+SOURCE_BENCH_HOLD = 2     # SYNTH16, measurement only: generated panels stay in their buffers (gpca.h)
 
 
 class gpca_panel_source(C.Structure):

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, 1) void k_gq_n(const int8_t* __restrict__ G, i
             }
         }
     }
-    const float am = fmaxf(amax, __shfl_xor(amax, 32));
+    float am_lo, am_hi; halves_pair(amax, am_lo, am_hi);
+    const float am = fmaxf(am_lo, am_hi);
     if (h == 0) apart[wave * 32 + c] = (double)am;
 }
 // Npad = padded sample count of Qd's planes (multiple of 256); N = samples (<= 256)
@@ -256,9 +257,16 @@ __device__ __forceinline__ void gq2_mfma_decode(const i32x4 (&op)[R], const Gq8Q
 
 template <int R, int ND = kDigits>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
-                                          const int8_t* __restrict__ Qd, double qs, const float* __restrict__ rv,
-                                          const float* __restrict__ bv, float sj, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float* __restrict__ cunit, float& amax, int64_t row0, int c, int h, int lane, const unsigned* lut) {
+                                          const int8_t* __restrict__ Qd, const double* __restrict__ qscale, const float* __restrict__ rv,
+                                          const float* __restrict__ bv, const float* __restrict__ sv, float* __restrict__ Tout, int scale_out, int64_t ldt,
+                                          float* __restrict__ cunit, float& amax, int64_t row0, int c_in, int h_in, int lane_in, const unsigned* lut) {
+    // (the lane's place is made opaque per group and the column's scales are fetched in the epilogue: less is carried through the decode
+    //  loop, where the four-plane kernel has no register to spare.  It parked 9 VGPRs in scratch; now 5, all written before the loop and
+    //  read back in the epilogues -- the loop itself never touched scratch, before or after)
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    (void)c_in; (void)h_in;
+    const int c = lane & 31, h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
     uint32_t gvo[R];
 #pragma unroll
@@ -325,6 +333,8 @@ __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_
 #undef GQ2_BLOCK
 #undef GQ2_PHASE
 #undef GQ2_ABL_SHARED
+    const float sj = sv[c];           // the column's sum of Q and digit scale, fetched here (two registers less through the loop above)
+    const double qs = qscale[c];
 #pragma unroll
     for (int t = 0; t < R; ++t) {
         float ct = 0.f;     // this tile's share of c = b^T T: one partial per 32-row unit, so c does not depend on the grid partition
@@ -349,16 +359,17 @@ __global__ __launch_bounds__(256, RMAX == 4 ? 1 : 2) void k_gq_2bit(const uint8_
                                                      const float* __restrict__ rv, const float* __restrict__ bv,
                                                      const float* __restrict__ sv, float* __restrict__ Tout,
                                                      float* __restrict__ cpart, double* __restrict__ apart, int scale_out, int64_t ldt) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));          // ONE register carries the thread's place through the kernel; what the epilogues and the last store need is derived there
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
     const int64_t waves = (int64_t)gridDim.x * 4;
-    int64_t u = (units * wave) / waves;
-    const int64_t u_end = (units * (wave + 1)) / waves;
+    // (32-bit unit counters, scalars by construction: the 64-bit `u + 4 <= u_end` is a VALU compare -- there is no scalar signed 64-bit
+    //  less-than -- whose operands lived in VGPR pairs through the whole kernel and were spilled to scratch by the four-plane form)
+    int u = __builtin_amdgcn_readfirstlane((int)((units * wave) / waves));
+    const int u_end = __builtin_amdgcn_readfirstlane((int)((units * (wave + 1)) / waves));
     float amax = 0.f;
-    const float sj = sv[c];
-    const double qs = qscale[c];
     // byte (4 two-bit codes) -> 4 int8 bytes: 256-entry table in LDS; the spread then costs 2 VALU + 1 ds_read per dword
     // 32 interleaved copies (entry v of copy j at word 32 v + j): lane l reads copy l % 32, i.e. always bank l % 32 -- a single
     // 1-KiB table made 69 % of this kernel's LDS cycles bank conflicts (random bytes of 32 lanes over 32 banks)
@@ -370,16 +381,21 @@ __global__ __launch_bounds__(256, RMAX == 4 ? 1 : 2) void k_gq_2bit(const uint8_
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (RMAX == 4)
-        for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut);
+        for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut);
     else        // (kbench experiment: two tiles per sweep, two waves per SIMD)
-        for (; u + 2 <= u_end; u += 2) gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut);
+        for (; u + 2 <= u_end; u += 2) gq2_group<2, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut);
     // the 1-3 units left over go in ONE more sweep over the samples (a wave with 31 units used to make two, of 2 and of 1 tile:
     // every sweep re-reads all of Q's planes and pays its prologue)
-    if (RMAX == 4 && u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 3; }
-    else if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 2; }
-    else if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax, u * 32, c, h, lane, lut); u += 1; }
-    const float am = fmaxf(amax, __shfl_xor(amax, 32));
-    if (h == 0) apart[wave * 32 + c] = (double)am;
+    if (RMAX == 4 && u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut); u += 3; }
+    else if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut); u += 2; }
+    else if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut); u += 1; }
+    float am_lo, am_hi; halves_pair(amax, am_lo, am_hi);
+    const float am = fmaxf(am_lo, am_hi);
+    {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        if ((t2 & 32) == 0) apart[wave * 32 + (t2 & 31)] = (double)am;
+    }
 #if GPCA_ABLATE & 16
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         g_kbench_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
@@ -513,7 +529,10 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
 #ifndef GPCA_T_NT_MODE
 #define GPCA_T_NT_MODE 2      // (harness: 0 never, 1 every round, 2 every round but a workgroup's last)
 #endif
-template <int BITS, bool RB_LDS>
+#ifndef GPCA_GQD_DIRECT
+#define GPCA_GQD_DIRECT 0     // (harness: 1 = sixteen dword buffer stores per lane instead of the pass through LDS; measured slower)
+#endif
+template <int BITS, bool RB_LDS, bool ACC_ASM = false>
 __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rrow, float brow, const float* rl, const float* bl,
                                             double qs, float sj, int scale_out,
                                             float* __restrict__ tile, float* __restrict__ Tout, int64_t ldt, int64_t unit,
@@ -526,13 +545,59 @@ __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rr
     asm volatile("" : "+v"(lane));
     const int c = lane & 31, h = lane >> 5;
     float ct = 0.f;
+#if GPCA_GQD_DIRECT
+    // DIRECT form.  Element e of a lane is row (e & 3) + 8 (e >> 2) + 4 h, column c of the tile: one dword store per element writes two
+    // whole rows of the tile (lanes 0-31 one 128-byte row, lanes 32-63 the row four below) -- full lines, nothing to transpose.  As
+    // BUFFER stores they need one address register for all 16: the lane's place (column, half) is the vector offset, the row of the
+    // element an immediate ((e & 3) rows) plus a scalar offset (8 (e >> 2) rows).  No pass through LDS, no wave fences, no wait for an
+    // LDS round trip between the arithmetic and the stores: 3.84 -> X us per round of four tiles (scripts/kbench/kbench_gqd.hip).
+    {
+        (void)tile;
+        const uint32_t pitch = (uint32_t)ldt * 4u;
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(Tout + unit * 32 * ldt, 0, 32 * (int)pitch, GPCA_RSRC_FLAGS);
+        const uint32_t vo = (uint32_t)c * 4u + (uint32_t)h * 4u * pitch;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float ri = RB_LDS ? rl[rin] : __shfl(rrow, rin), bi = RB_LDS ? bl[rin] : __shfl(brow, rin);
+            const float gq = (float)(combine_digits<BITS>(a, e) * qs);
+            const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
+            ct = __fmaf_rn(bi, tv, ct);
+            const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
+            amax = fmaxf(amax, fabsf(ov));
+            const uint32_t so = (uint32_t)(8 * (e >> 2)) * pitch;
+            // streaming store when another round follows (see the LDS form below for why); a workgroup's last round stores plainly
+            if (GPCA_T_NT_MODE == 1 || (GPCA_T_NT_MODE == 2 && stream_store)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ov), rt, vo + (uint32_t)(e & 3) * pitch, so, 2);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ov), rt, vo + (uint32_t)(e & 3) * pitch, so, 0);
+        }
+        GPCA_STORE_CUNIT(unit)
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
         // r and b of that row: from the wave's LDS staging (k_gq_d: DMA-ed at the start of the round, no compiler-visible load whose
         // wait would drain the DMA queue), or from lane `rin` of registers loaded one row per lane
         const float ri = RB_LDS ? rl[rin] : __shfl(rrow, rin), bi = RB_LDS ? bl[rin] : __shfl(brow, rin);
-        const float gq = (float)(combine_digits<BITS>(a, e) * qs);
+        double comb;
+        if (ACC_ASM) {
+            // (harness kernel k_gq_s, scripts/kbench/gqs_skew.inc) the four digit sums of element e, read from the accumulation registers
+            // HERE: left to the register allocator, the 64 reads of a tile that leaves in the middle of the stage loop became copies it
+            // made every stage -- through scratch
+            static_assert(!ACC_ASM || BITS == 7, "four base-128 digits");
+            int d0, d1, d2, d3;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d0) : "a"(a[0][e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d1) : "a"(a[1][e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d2) : "a"(a[2][e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d3) : "a"(a[kDigits - 1][e]));
+            comb = (double)d0 + 128.0 * (double)d1 + 16384.0 * (double)d2 + 2097152.0 * (double)d3;      // (= combine_digits<7>)
+            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        } else {
+            comb = combine_digits<BITS>(a, e);
+        }
+        const float gq = (float)(comb * qs);
         const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
         ct = __fmaf_rn(bi, tv, ct);
         const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
@@ -740,7 +805,7 @@ __device__ __forceinline__ void gqd_round(const int8_t* __restrict__ G, int64_t 
     float* tile = sm->tile[wv];
 #pragma unroll
     for (int t = 0; t < R; ++t)
-        if (t < nvalid) gq_tile_out<7, true>(acc[t], 0.f, 0.f, &sm->rb[wv][0][32 * t], &sm->rb[wv][1][32 * t], qs, sj, scale_out, tile, Tout, ldt, unit0 + t, cunit, amax, lane, chain);
+        if (t < nvalid) gq_tile_out<7, true>(acc[t], 0.f, 0.f, &sm->rb[wv][0][32 * t], &sm->rb[wv][1][32 * t], qs, sj, scale_out, tile, Tout, ldt, unit0 + t, cunit, amax, lane, nx.unit0 != unit0);      // (= chain, from scalars that are live anyway: `chain` itself, needed this late, was kept as 0 / 1 in a VGPR, spilled to scratch, and read back behind a vmcnt(0))
     GQD_STAMP(2 + 2 * round_ix)
 }
 
@@ -753,6 +818,10 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
                                                   int chain_ok, int phase_mul) {
     extern __shared__ __attribute__((aligned(16))) char gqd_smem[];
     GqdSmem* sm = reinterpret_cast<GqdSmem*>(gqd_smem);
+    // (launch_gq_d refuses anything else.  Told to the compiler because it hoisted the test `nstage != 1` of the fill bookkeeping out of
+    //  the round loop as a 0 / 1 VGPR, spilled that register to scratch, read it back in every epilogue and put vmcnt(0) -- a drain of
+    //  the chained prefetches AND of the epilogue's stores, whose acknowledgements take microseconds -- at the head of every round.)
+    __builtin_assume(nstage >= 2 && (nstage & 1) == 0);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -775,7 +844,6 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
         return r;
     };
     const bool chain_all = chain_ok && nstage > kGqdSlots;    // (more than 6 units in every round, whatever its R: a round's own refills start inside it)
-    bool prologue = true;
     uint32_t rslot = 0;
     int round_ix = 0;
     GQD_STAMP(0)
@@ -784,6 +852,11 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
         const int64_t un = u + (u1 - u < 16 ? u1 - u : 16);
         const GqdRound cur = round_at(u);
         const bool chain = chain_all && un < u1;
+        // a round starts cold unless the round before it was chained to it -- every round but a workgroup's first, when rounds chain at
+        // all.  (Recomputed from scalars every round: carried through the loop as a flag, the compiler kept it in a VGPR, spilled that
+        // to scratch and drained the whole memory queue -- vmcnt(0): the chain's prefetches and the epilogue's stores -- before every
+        // round to read it back.)
+        const bool prologue = !chain_all || u == u0;
         GqdRound nx = cur;
         if (chain) nx = round_at(un);
 #define GPCA_GQD_ROUND(RR) gqd_round<NT, RR>(G, ldg, nstage, Qd, sm, wv, lane, c, h, cur.unit0, cur.nv, prologue, chain, nx, rslot, round_ix, ph, units * 32, qs, rv, bv, sj, Tout, scale_out, ldt, cpart, amax)
@@ -792,14 +865,14 @@ __global__ __launch_bounds__(256, 1) void k_gq_d(const int8_t* __restrict__ G, i
         else if (cur.R == 2) GPCA_GQD_ROUND(2);
         else GPCA_GQD_ROUND(1);
 #undef GPCA_GQD_ROUND
-        prologue = !chain;
         u = un;
         ++round_ix;
     }
 #if GPCA_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 0) g_gqd_stamp_n = round_ix;
 #endif
-    const float am = fmaxf(amax, __shfl_xor(amax, 32));
+    float am_lo, am_hi; halves_pair(amax, am_lo, am_hi);
+    const float am = fmaxf(am_lo, am_hi);
     if (h == 0) apart[((int64_t)blockIdx.x * 4 + wv) * 32 + c] = (double)am;
 }
 

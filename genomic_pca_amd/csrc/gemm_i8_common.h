@@ -21,7 +21,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc8(const void* p) {
 // c = b^T T is summed per 32-row unit (fixed order: 16 rows per lane half, then the two halves), one partial per unit at
 // cunit[unit][32]: whichever wave of whichever launch computes a unit writes the same bits, so resident, sharded and
 // streamed-panel runs agree on c exactly
-#define GPCA_STORE_CUNIT(UNIT) { const float co_ = ct + __shfl_xor(ct, 32); if (h == 0) cunit[(int64_t)(UNIT) * 32 + c] = co_; }
+// (the two halves of the wave meet through v_permlane32_swap: lanes 0-31 end up with (own, partner), lanes 32-63 with (partner, own) --
+//  no lane id, which a __shfl_xor keeps in a register for the whole kernel)
+__device__ __forceinline__ void halves_pair(float x, float& lo, float& hi) {
+    const unsigned v = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+}
+#define GPCA_STORE_CUNIT(UNIT) { float lo_, hi_; halves_pair(ct, lo_, hi_); const float co_ = lo_ + hi_; if (h == 0) cunit[(int64_t)(UNIT) * 32 + c] = co_; }
 
 // Shapes the hand-counted DMA pipelines were derived for: sample pitch a multiple of `npad_mult`, row count a multiple of `rows_mult`.
 // The launchers refuse anything else (hipErrorInvalidValue -> GPCA_ERR_HIP with the kernel's name) rather than compute garbage.

@@ -98,6 +98,7 @@ struct Filler {
     std::mutex m; std::condition_variable cv; std::thread worker;
     // host-side accounting (gpca_stream_get_info)
     int64_t fills = 0; double fill_host_ms = 0.0, fill_wait_ms = 0.0, register_ms = 0.0;
+    std::map<void*, int64_t> held;   // GPCA_SOURCE_BENCH_HOLD: device buffers that hold a generated panel (rows)
 };
 
 struct StreamState {

@@ -104,7 +104,7 @@ static void filler_close(Filler& f) {
         f.cv.notify_all();
         f.worker.join();
     }
-    f.quit = false; f.busy = false; f.jobs.clear(); f.posted = f.produced = f.consumed = 0;
+    f.quit = false; f.busy = false; f.jobs.clear(); f.posted = f.produced = f.consumed = 0; f.held.clear();
     dfree(f.d_thresh); dfree(f.d_scratch8); dfree(f.d_raw); dfree(f.d_flags);
     for (size_t i = 0; i < f.h_stage.size(); ++i) {
         if (f.ev_stage[i]) { (void)hipEventSynchronize(f.ev_stage[i]); (void)hipEventDestroy(f.ev_stage[i]); }
@@ -360,6 +360,11 @@ int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst
             HIPCHK(hipGetLastError());
             return GPCA_OK;
         case GPCA_PANEL_SYNTH16:
+            if (s.flags & GPCA_SOURCE_BENCH_HOLD) {      // measurement only: a buffer that already holds a generated panel of this height keeps it
+                auto it = f.held.find(dst);
+                if (it != f.held.end() && it->second == rows) return GPCA_OK;
+                f.held[dst] = rows;
+            }
             launch_synth16(st, dst, packed ? 1 : 0, rows, h->N, packed ? h->ld2 : h->ld8, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
             HIPCHK(hipGetLastError());
             return GPCA_OK;

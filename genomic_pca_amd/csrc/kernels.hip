@@ -367,7 +367,7 @@ int64_t omega_num_parts(int64_t Mpad) { return (Mpad + 63) / 64; }
 // sketches wider than 64 columns: the plain any-L kernels of wide_sketch.hip
 void launch_gram_any_f64(hipStream_t st, const double* X, int64_t rows, int64_t rpb, int64_t parts, int L, double* part);
 void launch_gram_any_f32(hipStream_t st, const float* X, int64_t rows, int64_t rpb, int64_t parts, int L, double* part);
-void launch_chol_inv_any(hipStream_t st, const double* W, int n, int L, double* Z, double* work, int* flag);
+int launch_chol_inv_any(hipStream_t st, const double* W, int n, int L, double* Z, int* flag);
 void launch_apply_right_any(hipStream_t st, double* X, int64_t rows, int64_t parts, int L, const double* Z, double* csum_part, double* amax_part);
 void launch_rightmul_any_f64(hipStream_t st, const double* X, int64_t rows, int L, const double* Z, int K, double* out64, float* out32);
 void launch_rightmul_any_gather_f32(hipStream_t st, const float* X, const int64_t* row_ids, int64_t nrows, int L, const double* Z, int K, float* out32);
@@ -948,7 +948,7 @@ void launch_chol_inv_fold(hipStream_t st, const double* part, int P, int n, int 
 void launch_chol_inv(hipStream_t st, const double* W, int n, int ld, double* Z, int* flag) {
     if (ld == 32) hipLaunchKernelGGL(k_chol_inv<32>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
     else if (ld == 64) hipLaunchKernelGGL(k_chol_inv<64>, dim3(1), dim3(64), 0, st, W, n, Z, flag);
-    else launch_chol_inv_any(st, W, n, ld, Z, Z + (size_t)ld * ld, flag);       // (Z's allocation holds 2 x L x L doubles: the second half is the factor's scratch)
+    else (void)launch_chol_inv_any(st, W, n, ld, Z, flag);       // (ld = 128 = kMaxSketchCols: the factor lives in LDS)
 }
 
 void launch_apply_right_inplace(hipStream_t st, double* X, int64_t rows, int L, const double* Z, float* Qout,

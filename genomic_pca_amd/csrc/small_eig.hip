@@ -61,8 +61,8 @@ EIGDEV double eig_rcp(double x) {
     return fma(r, fma(-x, r, 1.0), r);
 }
 
-// Off-diagonal entries of the prescaled matrix (largest entry in [0.5, 1)): at or below kJacSkip a pair is left alone; a sweep whose pairs
-// were all at or below kJacDone before their rotations was the last one.
+// Off-diagonal entries of the prescaled matrix (largest entry in [0.5, 1)): at or below kJacSkip a pair is left alone; the iteration ends
+// after the sweep that leaves nothing above kJacDone off the diagonal.
 constexpr double kJacSkip = 1e-17, kJacDone = 2e-15;
 template <int L> struct JacCfg {
     static constexpr int H = L / 2;                            // index pairs = 2 x 2 blocks per side
@@ -73,31 +73,29 @@ template <int L> struct JacCfg {
     static constexpr int NBUF = DB ? 4 : 1;
 };
 // round-robin with index 0 fixed: the slot the index at slot s moves to after a step (pairs are slots (2i, 2i + 1))
-template <int L> EIGDEV int jac_dest(int s) { return s == 0 ? 0 : (s == 1 ? 2 : ((s & 1) ? s - 2 : (s == L - 2 ? L - 1 : s + 2))); }
+// Le = the even number of slots that take part (n rounded up to even: the padded pairs beyond it never move and never meet anybody)
+EIGDEV int jac_dest(int s, int Le) { return s >= Le ? s : (s == 0 ? 0 : (s == 1 ? (Le > 2 ? 2 : 1) : ((s & 1) ? s - 2 : (s == Le - 2 ? Le - 1 : s + 2)))); }
 // LDS offset (doubles) of element (r, c): every other pair of rows starts one double later, so that the scattered 8-byte stores of a
 // step (64 lanes: 4 block rows x 16 block columns, column stride 2) fill all sixteen 8-byte bank slots instead of eight
 template <int L> EIGDEV int jac_at(int r, int c) { return r * JacCfg<L>::LP + ((r >> 1) & 1) + c; }
 
-// The rotation that annihilates a_pq of [[app, apq], [apq, aqq]]: J = [[c, s], [-s, c]], t = tan = sign(z) / (|z| + sqrt(1 + z^2)), z = (aqq - app) / (2 apq),
-// written as 2 apq / (d + sign(d) sqrt(d^2 + 4 apq^2)).  c is refined to full precision (it keeps V orthonormal); t is not exact to the last
-// bits and need not be: whatever it leaves of a_pq is rotated again.  big: |apq| was above kJacDone.
-EIGDEV void jac_rot(double app, double a01, double a10, double aqq, double& c, double& s, bool& big) {
+// The rotation that annihilates a_pq of [[app, apq], [apq, aqq]]: J = [[c, s], [-s, c]] with tan 2t = 2 apq / (aqq - app), |t| <= pi / 4.
+EIGDEV void jac_rot(double app, double a01, double a10, double aqq, double& c, double& s) {
     const double b2 = a01 + a10, dd = aqq - app;               // 2 apq of the symmetrised pair
 #if GPCA_EIG_ABL & 1
-    c = 0.8; s = 0.6; big = false; return;
+    c = 0.8; s = 0.6; return;
 #endif
-    // no branch: a thread runs two of these chains (its row pair's and its column pair's) and the scheduler interleaves them only inside
-    // one basic block; a pair at or below kJacSkip computes with sq = 1 and is deselected at the end (NaN input: deselected too)
+    // By the double angle -- cos 2t = |d| / r, sin 2t = +-2 apq / r, r = sqrt(d^2 + 4 apq^2); c = sqrt((1 + cos 2t) / 2), s = sin 2t / (2 c) -- the
+    // chain is two reciprocal square roots and six other operations deep (the tangent form t = 2 apq / (d + sign(d) r), c = 1 / sqrt(1 + t^2)
+    // needs a reciprocal between them: twice as deep).  c^2 + s^2 = 1 to the accuracy of the second root, whatever the first one's.
+    // No branch; a pair at or below kJacSkip computes with sq = 1 and is deselected at the end (NaN input: deselected too).
     const bool live = fabs(b2) > 2.0 * kJacSkip;
     const double sq = live ? fma(dd, dd, b2 * b2) : 1.0;
-    const double r = sq * eig_rsqrt(sq);
-    const double den = live ? dd + (dd >= 0.0 ? r : -r) : 1.0;
-    double rc = __builtin_amdgcn_rcp(den);
-    rc = fma(rc, fma(-den, rc, 1.0), rc);                      // one Newton step: 2e-15
-    const double t = b2 * rc;                                  // |t| <= 1
-    const double ci = eig_rsqrt(fma(t, t, 1.0));
-    c = live ? ci : 1.0; s = live ? t * ci : 0.0;
-    big = fabs(b2) > 2.0 * kJacDone;                           // (NaN: false)
+    const double rinv = eig_rsqrt(sq);
+    const double c2 = fabs(dd) * rinv, s2 = (dd >= 0.0 ? b2 : -b2) * rinv;
+    const double h = fma(0.5, c2, 0.5);                        // cos^2 t, in [0.5, 1]
+    const double ci = eig_rsqrt(h);
+    c = live ? h * ci : 1.0; s = live ? 0.5 * s2 * ci : 0.0;
 }
 
 // src: the Gram W [Lw][Lw] (nslices == 0) or `nslices` partial sums of it [nslices][Lw * Lw] (summed here in slice order); only the
@@ -116,7 +114,6 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
     __shared__ double wsl[128];                                // eigenvalue by slot, then sorted
     __shared__ int order[128], genuine[128];
     __shared__ double redmax[NT];
-    __shared__ int big[2];                                     // a pair above kJacDone was rotated in the sweep (two flags, alternating)
     const int tid = threadIdx.x;
 #if GPCA_EIG_STAMP
     if (tid == 0) { g_eig_stamp[10] = 0; g_eig_stamp[11] = 0; }
@@ -162,7 +159,6 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
         }
     }
     redmax[tid] = amax;
-    if (tid < 2) big[tid] = 0;
     __syncthreads();
     for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) redmax[tid] = fmax(redmax[tid], redmax[tid + st]); __syncthreads(); }
     amax = redmax[0];
@@ -170,41 +166,41 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
     if (amax > 0.0) (void)frexp(amax, &ex);
     const double sc = ldexp(1.0, -ex), unsc = ldexp(1.0, ex);
     // the thread's blocks and where their elements go / come from in an exchange (the same every step)
-    double a[NBK][4], v[NBK][4], dI[NBK][4], dJ[NBK][4];        // dI / dJ: the 2 x 2 diagonal blocks of the thread's row pair and column pair
-    int wA[NBK][4], wV[NBK][4], rB[NBK][2], rI[NBK][2], rJ[NBK][2];
+    const int Le = (n + 1) & ~1;                               // slots in the round-robin: Le - 1 steps per sweep
+    double a[NBK][4], v[NBK][4], dJ[NBK][4];                   // dJ: the 2 x 2 diagonal block of the thread's column pair
+    int wA[NBK][4], wV[NBK][4], rB[NBK][2], rJ[NBK][2], srcI[NBK];     // srcI: byte address (ds_bpermute) of the lane of this wave whose column pair is the thread's row pair
 #pragma unroll
     for (int q = 0; q < NBK; ++q) {
         const int bk = tid + NT * q, I = bk / H, J = bk - I * H;
 #pragma unroll
         for (int e1 = 0; e1 < 4; ++e1) {
             const int r = 2 * I + (e1 >> 1), c = 2 * J + (e1 & 1);
-            wA[q][e1] = jac_at<L>(jac_dest<L>(r), jac_dest<L>(c)); wV[q][e1] = jac_at<L>(r, jac_dest<L>(c));
+            wA[q][e1] = jac_at<L>(jac_dest(r, Le), jac_dest(c, Le)); wV[q][e1] = jac_at<L>(r, jac_dest(c, Le));
             v[q][e1] = r == c ? 1.0 : 0.0;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { rB[q][h] = jac_at<L>(2 * I + h, 2 * J); rI[q][h] = jac_at<L>(2 * I + h, 2 * I); rJ[q][h] = jac_at<L>(2 * J + h, 2 * J); }
+        for (int h = 0; h < 2; ++h) { rB[q][h] = jac_at<L>(2 * I + h, 2 * J); rJ[q][h] = jac_at<L>(2 * J + h, 2 * J); }
+        srcI[q] = 4 * I;                                       // (a wave holds every column pair: lanes 0 .. H - 1 have J = lane)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                a[q][2 * h + g] = buf0[rB[q][h] + g] * sc; dI[q][2 * h + g] = buf0[rI[q][h] + g] * sc; dJ[q][2 * h + g] = buf0[rJ[q][h] + g] * sc;
-            }
+            for (int g = 0; g < 2; ++g) { a[q][2 * h + g] = buf0[rB[q][h] + g] * sc; dJ[q][2 * h + g] = buf0[rJ[q][h] + g] * sc; }
     }
     __syncthreads();                                           // (everybody has read buf0: it is the first exchange buffer)
     EIG_STAMP(1)
     // ---- sweeps ----
     int capped = 1, sweeps = 0, cur = 0;
     for (int sweep = 0; sweep < 40; ++sweep) {
-        for (int step = 0; step < L - 1; ++step) {
-            // (1) the rotations of the thread's row pair and column pair, each from that pair's diagonal block (every thread of a block row /
-            //     column computes the same numbers: no exchange of (c, s), no barrier for them); A <- R_I^T A R_J, V <- V R_J
-            bool anybig = false;
+        for (int step = 0; step < Le - 1; ++step) {
+            // (1) the rotation of the thread's COLUMN pair from that pair's diagonal block (every thread of a block column computes the same
+            //     numbers); the rotation of its ROW pair I is the one the lane with column pair I of this wave has just computed: an
+            //     LDS-crossbar read (ds_bpermute), no memory, no barrier.  A <- R_I^T A R_J, V <- V R_J
 #pragma unroll
             for (int q = 0; q < NBK; ++q) {
-                double cI, sI, cJ, sJ; bool b1, b2;
-                jac_rot(dI[q][0], dI[q][1], dI[q][2], dI[q][3], cI, sI, b1);
-                jac_rot(dJ[q][0], dJ[q][1], dJ[q][2], dJ[q][3], cJ, sJ, b2);
-                anybig = anybig || b1 || b2;
+                double cJ, sJ;
+                jac_rot(dJ[q][0], dJ[q][1], dJ[q][2], dJ[q][3], cJ, sJ);
+                const double cI = __hiloint2double(__builtin_amdgcn_ds_bpermute(srcI[q], __double2hiint(cJ)), __builtin_amdgcn_ds_bpermute(srcI[q], __double2loint(cJ)));
+                const double sI = __hiloint2double(__builtin_amdgcn_ds_bpermute(srcI[q], __double2hiint(sJ)), __builtin_amdgcn_ds_bpermute(srcI[q], __double2loint(sJ)));
                 const double b00 = fma(cI, a[q][0], -(sI * a[q][2])), b01 = fma(cI, a[q][1], -(sI * a[q][3]));
                 const double b10 = fma(sI, a[q][0], cI * a[q][2]), b11 = fma(sI, a[q][1], cI * a[q][3]);
                 a[q][0] = fma(cJ, b00, -(sJ * b01)); a[q][1] = fma(sJ, b00, cJ * b01);
@@ -215,7 +211,6 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
                 v[q][2] = fma(cJ, v10, -(sJ * v11)); v[q][3] = fma(sJ, v10, cJ * v11);
 #endif
             }
-            if (anybig) big[sweep & 1] = 1;
             // (2) the next pairing: every element to its new place through LDS, then the thread's new blocks (and its pairs' diagonal blocks) back
             double* bA = eig_sm + (C::DB ? 2 * cur * BUF : 0);
             double* bV = C::DB ? bA + BUF : bA;
@@ -233,7 +228,7 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        if (!(GPCA_EIG_ABL & 4)) { dI[q][2 * h + g] = bA[rI[q][h] + g]; dJ[q][2 * h + g] = bA[rJ[q][h] + g]; a[q][2 * h + g] = bA[rB[q][h] + g]; }
+                        if (!(GPCA_EIG_ABL & 4)) { dJ[q][2 * h + g] = bA[rJ[q][h] + g]; a[q][2 * h + g] = bA[rB[q][h] + g]; }
                         if (C::DB && !(GPCA_EIG_ABL & 2)) v[q][2 * h + g] = bV[rB[q][h] + g];
                     }
             if (C::DB) cur ^= 1;                               // (the next step writes the other pair of buffers: a wave one barrier ahead cannot overwrite what a slower one still reads)
@@ -254,16 +249,25 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
             }
         }
         ++sweeps;
-        // Every thread has passed the barrier of this sweep's last step: the flag is complete; the other one is reset for the next sweep.
-        // Done when no pair of the sweep was above kJacDone BEFORE its rotation: what those rotations leave behind is below rounding
-        // (no confirming sweep: it would rotate nothing).
-        const int any = big[sweep & 1];
+        // Done when nothing off the diagonal is above kJacDone any more: every thread looks at its own elements (a diagonal block's own
+        // diagonal excepted), one maximum over the workgroup.  (A flag "some pair of this sweep was large before its rotation" needs one more
+        // sweep to come back empty: 31 steps that rotate nothing.)
+        double om = 0.0;
+#pragma unroll
+        for (int q = 0; q < NBK; ++q) {
+            const int bk = tid + NT * q; const bool dg = (bk / H) == (bk % H);
+            om = fmax(om, fmax(fabs(a[q][1]), fabs(a[q][2])));
+            if (!dg) om = fmax(om, fmax(fabs(a[q][0]), fabs(a[q][3])));
+        }
+        redmax[tid] = om;                                      // (NaN: fmax drops it -- NaN input ends after the first sweep)
         __syncthreads();
-        if (tid == 0) big[sweep & 1] = 0;                      // (used again two sweeps on; everybody has read it)
-        if (GPCA_EIG_ABL ? sweep == 7 : !any) { capped = 0; break; }
+        for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) redmax[tid] = fmax(redmax[tid], redmax[tid + st]); __syncthreads(); }
+        const double offmax = redmax[0];
+        __syncthreads();
+        if (GPCA_EIG_ABL ? sweep == 7 : !(offmax > kJacDone)) { capped = 0; break; }
     }
 #if GPCA_EIG_STAMP
-    if (tid == 0) { g_eig_stamp[10] = sweeps; g_eig_stamp[11] = (unsigned long long)sweeps * (L - 1); }
+    if (tid == 0) { g_eig_stamp[10] = sweeps; g_eig_stamp[11] = (unsigned long long)sweeps * (Le > 1 ? Le - 1 : 0); }
 #endif
     (void)sweeps;
     EIG_STAMP(3)

@@ -1,4 +1,5 @@
-// Tall-skinny helpers for sketches wider than 64 columns (L = 128 or 256 padded columns; k + oversample up to 256).
+// Tall-skinny helpers for sketches wider than 64 columns (L = 128 padded columns = kMaxSketchCols; k + oversample up to 128, i.e. 118
+// components with the reference's fixed oversampling of 10).
 //
 // The reference clamps k only to min(samples, variants) and always adds 10 (main.rs:621-628, 636), and its authors sweep
 // components_per_block to 50 (tests/sweep_run.py:61): --components 60 is an ordinary call there.  The two GEMMs of the exact-integer
@@ -12,7 +13,7 @@
 namespace gpca {
 
 // part[blk][a][c] = sum over the block's rows of X[n][a] X[n][c] (f64).  256 threads; the L x L outputs are dealt out 64 per thread
-// in (a, c) order (L <= 128: one pass; L = 256: four passes over the tile); rows staged 16 at a time.
+// in (a, c) order (L <= 128: one pass); rows staged 16 at a time.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gram_any(const T* __restrict__ X, int64_t rows, int64_t rpb, int L, double* __restrict__ part) {
     extern __shared__ double tile_any[];                 // [16][L]
@@ -56,55 +57,81 @@ void launch_gram_any_f32(hipStream_t st, const float* X, int64_t rows, int64_t r
     hipLaunchKernelGGL((k_gram_any<float>), dim3((unsigned)parts), dim3(256), sizeof(double) * 16 * L, st, X, rows, rpb, L, part);
 }
 
-// W (n x n used, pitch L, upper triangle) = R^T R; Z (L x L) = R^-1 (upper, zero elsewhere).  One workgroup, the matrices in global
-// memory (L2-resident: 128 KiB at L = 128), a barrier per elimination step.  Same contracts as k_chol_inv (kernels.hip): a pivot that
-// is not finite records (j + 1) in *flag and carries on with pivot 1; a pivot that is zero to rounding against the column's own
-// squared norm (1e-13) drops its column from the basis (zero row in R and R^-1).  `work` = L x L doubles of scratch (R).
-__global__ __launch_bounds__(256) void k_chol_inv_any(const double* __restrict__ Wg, int n, int L, double* __restrict__ Zg, double* __restrict__ work,
-                                                      int* __restrict__ flag) {
-    __shared__ double rowj[256];
-    __shared__ double sh_dinv;
+// W (n x n used, pitch L, upper triangle) = R^T R; Z (L x L) = R^-1 (upper, zero elsewhere).  One workgroup, L <= 128, everything in
+// LDS: one (L x (L + 1)) square of doubles (129 KiB at L = 128, opted in) holds R in its upper triangle and, once the factor is
+// complete, the transpose of R^-1 in its strictly lower one (the inverse is upper triangular too: its column c, above the diagonal,
+// is row c of the lower triangle -- the thread that owns the column walks its own row) with the inverse's diagonal beside it.
+// Same contracts as k_chol_inv (kernels.hip): a pivot that is not finite records (j + 1) in *flag and carries on with pivot 1; a pivot
+// that is zero to rounding against the column's own squared norm (1e-13) drops its column from the basis (zero row in R and R^-1).
+// Every element sees the arithmetic of the first form of this kernel (one workgroup reading and writing global memory, a serial loop
+// over the rows of every elimination step, milliseconds at n = 100) in the same order: R[r][c] -= R[j][r] R[j][c] for j ascending,
+// the substitution sums for k ascending.
+//   * elimination step j: thread (c = tid mod 128, half = tid / 128) updates column c of the rows j + 1 + half, j + 3 + half, ...
+//     (R[j][r] is a broadcast read, column c of consecutive rows is conflict-free at the odd pitch); two barriers per step.
+//   * back substitution with the row index i as the uniform outer loop: thread c (c >= i) forms x_c[i] from R[i][k] (broadcast) and its
+//     own x_c[k] (row c of the lower triangle).
+// scripts/kbench/kbench_chol.hip `wide` times both forms.
+constexpr int kCholAnyMaxL = 128;
+__global__ __launch_bounds__(256) void k_chol_inv_any(const double* __restrict__ Wg, int n, int L, double* __restrict__ Zg, int* __restrict__ flag) {
+    extern __shared__ double chol_any_lds[];              // [L][L + 1] + [L] (diagonal of the inverse) + [1]
+    const int P = L + 1;
+    double* R = chol_any_lds;
+    double* zdiag = R + (size_t)L * P;
+    double* sh_dinv = zdiag + L;
     const int tid = threadIdx.x;
-    double* R = work;
     // R := upper triangle of W on the n x n block, identity outside
     for (int e = tid; e < L * L; e += 256) {
         const int r = e / L, c = e - r * L;
-        R[e] = (r < n && c < n) ? ((c >= r) ? Wg[r * L + c] : 0.0) : ((r == c) ? 1.0 : 0.0);
-        Zg[e] = 0.0;
+        R[r * P + c] = (r < n && c < n) ? ((c >= r) ? Wg[r * L + c] : 0.0) : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
+    const int cc = tid & (kCholAnyMaxL - 1), half = tid >> 7;
     for (int j = 0; j < n; ++j) {
         if (tid == 0) {
-            double piv = R[j * L + j];
+            double piv = R[j * P + j];
             const double d0 = Wg[j * L + j];
-            if (!isfinite(piv) || !isfinite(d0)) { atomicCAS(flag, 0, j + 1); piv = 1.0; R[j * L + j] = 1.0; }
+            if (!isfinite(piv) || !isfinite(d0)) { atomicCAS(flag, 0, j + 1); piv = 1.0; R[j * P + j] = 1.0; }
             const bool dependent = !(piv > 1e-13 * d0);
-            sh_dinv = dependent ? 0.0 : 1.0 / sqrt(piv);
+            *sh_dinv = dependent ? 0.0 : 1.0 / sqrt(piv);
         }
         __syncthreads();
-        const double dinv = sh_dinv;
-        // row j of R: R[j][c] = (c == j ? piv : R[j][c]) * dinv
-        for (int c = j + tid; c < n; c += 256) { const double v = R[j * L + c] * dinv; R[j * L + c] = v; rowj[c & 255] = v; }
+        const double dinv = *sh_dinv;
+        if (half == 0 && cc >= j && cc < n) R[j * P + cc] *= dinv;          // row j of the factor
         __syncthreads();
-        // trailing update: R[r][c] -= R[j][r] R[j][c] for j < r <= c < n   (L <= 256: rowj holds row j's entries by column)
-        for (int r = j + 1; r < n; ++r) {
-            const double a = rowj[r & 255];
-            for (int c = r + tid; c < n; c += 256) R[r * L + c] -= a * rowj[c & 255];
+        if (cc > j && cc < n) {
+            const double rc = R[j * P + cc];
+            for (int r = j + 1 + half; r <= cc; r += 2) R[r * P + cc] -= R[j * P + r] * rc;
         }
+        // (the next step's pivot R[j+1][j+1] and row j + 1 were written by this step: the barrier at the top of the loop body orders them)
         __syncthreads();
     }
-    // Z = R^-1 by back substitution, one column per thread: R x = e_c, x[k] = 0 for k > c; a dropped row (R[i][i] = 0) gives x[i] = 0
-    for (int c = tid; c < n; c += 256) {
-        for (int i = c; i >= 0; --i) {
-            double acc = (i == c) ? 1.0 : 0.0;
-            for (int k = i + 1; k <= c; ++k) acc -= R[i * L + k] * Zg[k * L + c];
-            const double d = R[i * L + i];
-            Zg[i * L + c] = d != 0.0 ? acc / d : 0.0;
+    // Z = R^-1 by back substitution: R x = e_c, x[k] = 0 for k > c; a dropped row (R[i][i] = 0) gives x[i] = 0
+    if (tid < n) zdiag[tid] = R[tid * P + tid] != 0.0 ? 1.0 / R[tid * P + tid] : 0.0;
+    __syncthreads();
+    if (half == 0 && cc < n) {
+        double* xrow = R + (size_t)cc * P;                // x_c[k] for k < c lives at [c][k]
+        for (int i = cc - 1; i >= 0; --i) {
+            // k ascends from i + 1 to c; the last term is the column's own diagonal entry x_c[c]
+            double acc = 0.0;
+            for (int k = i + 1; k < cc; ++k) acc -= R[i * P + k] * xrow[k];
+            acc -= R[i * P + cc] * zdiag[cc];
+            const double d = R[i * P + i];
+            xrow[i] = d != 0.0 ? acc / d : 0.0;
         }
+    }
+    __syncthreads();
+    for (int e = tid; e < L * L; e += 256) {
+        const int r = e / L, c = e - r * L;
+        Zg[e] = (r < n && c < n) ? (r < c ? R[c * P + r] : (r == c ? zdiag[r] : 0.0)) : 0.0;
     }
 }
-void launch_chol_inv_any(hipStream_t st, const double* W, int n, int L, double* Z, double* work, int* flag) {
-    hipLaunchKernelGGL(k_chol_inv_any, dim3(1), dim3(256), 0, st, W, n, L, Z, work, flag);
+int launch_chol_inv_any(hipStream_t st, const double* W, int n, int L, double* Z, int* flag) {
+    if (L > kCholAnyMaxL || n > L) return (int)hipErrorInvalidValue;
+    const size_t lds = sizeof(double) * ((size_t)L * (L + 1) + L + 1);
+    static bool opted = false;
+    if (!opted) { if (hipFuncSetAttribute((const void*)k_chol_inv_any, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * ((size_t)kCholAnyMaxL * (kCholAnyMaxL + 1) + kCholAnyMaxL + 1))) != hipSuccess) return (int)hipErrorInvalidValue; opted = true; }
+    hipLaunchKernelGGL(k_chol_inv_any, dim3(1), dim3(256), lds, st, W, n, L, Z, flag);
+    return 0;
 }
 
 // X[n][:] <- X[n][:] Z in place (f64): a workgroup takes kTailRows = 64 rows (the partial-array granularity of k_apply_right_tail,
@@ -113,7 +140,7 @@ void launch_chol_inv_any(hipStream_t st, const double* W, int n, int L, double* 
 __global__ __launch_bounds__(256) void k_apply_right_any(double* __restrict__ X, int64_t rows, const double* __restrict__ Z, int L,
                                                          double* __restrict__ csum_part, double* __restrict__ amax_part) {
     extern __shared__ double xs_any[];                    // [32][L]
-    const int cc = threadIdx.x;                           // (L <= 256: one output column per thread)
+    const int cc = threadIdx.x;                           // (L <= 128 < 256: one output column per thread)
     double cs = 0.0, am = 0.0;
     for (int sub = 0; sub < 64; sub += 32) {
         const int64_t n0 = (int64_t)blockIdx.x * 64 + sub;

@@ -123,8 +123,9 @@ class PanelSource:
         return PanelSource(_lib.PANEL_SYNTH, thresh=thresh, seed=seed, snp_offset=snp_offset)
 
     @staticmethod
-    def synth16(thresh16, seed, snp_offset=0):
-        return PanelSource(_lib.PANEL_SYNTH16, thresh=thresh16, seed=seed, snp_offset=snp_offset)
+    def synth16(thresh16, seed, snp_offset=0, bench_hold=False):
+        """bench_hold: MEASUREMENT ONLY (gpca.h GPCA_SOURCE_BENCH_HOLD): buffers that hold a generated panel are not generated again."""
+        return PanelSource(_lib.PANEL_SYNTH16, thresh=thresh16, seed=seed, snp_offset=snp_offset, flags=_lib.SOURCE_BENCH_HOLD if bench_hold else 0)
 
 
 # Defaults added to every GpcaEngine's gpca_config.reserved (flags OR-ed in, wave targets used when the caller passes 0).  The library

@@ -168,6 +168,10 @@ typedef enum gpca_panel_kind {
  * gpca_load_from_source) is in progress on another thread, which holds the handle's lock: it may block on I/O, it must not
  * call into the same handle.  Every panel is asked exactly once per pass (cached panels once in all); after a failure no
  * further panel is asked in that pass. */
+#define GPCA_SOURCE_BENCH_HOLD 2 /* SYNTH16, MEASUREMENT ONLY: a ring / cache buffer that already holds a generated panel of the same height is not
+                                   generated again -- every pass then multiplies whatever panels the buffers held first.  The numbers a call
+                                   returns are NOT a PCA of the source; what it measures is the engine's rate over streamed panels with the
+                                   generator out of the way (bench.py: config5_per_gpu_shard_streamed.engine_rate_with_fills_hidden). */
 typedef int (*gpca_panel_fn)(void* user, int64_t row0, int64_t rows, void* dst, int64_t ld);
 typedef struct gpca_panel_source {
     int32_t kind;           /* gpca_panel_kind */

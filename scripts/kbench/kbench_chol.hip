@@ -91,6 +91,50 @@ __global__ __launch_bounds__(64) void k_chol_inv_old(const double* __restrict__ 
     }
 }
 }  // namespace gpca
+
+// The wide-sketch (L = 128) factorisation in its first form -- one workgroup on global memory, a serial loop over the rows of every
+// elimination step -- kept here for the comparison with the LDS-resident kernel of csrc/wide_sketch.hip.
+namespace gpca {
+__global__ __launch_bounds__(256) void k_chol_inv_any_old(const double* __restrict__ Wg, int n, int L, double* __restrict__ Zg, double* __restrict__ work,
+                                                          int* __restrict__ flag) {
+    __shared__ double rowj[256];
+    __shared__ double sh_dinv;
+    const int tid = threadIdx.x;
+    double* R = work;
+    for (int e = tid; e < L * L; e += 256) {
+        const int r = e / L, c = e - r * L;
+        R[e] = (r < n && c < n) ? ((c >= r) ? Wg[r * L + c] : 0.0) : ((r == c) ? 1.0 : 0.0);
+        Zg[e] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            double piv = R[j * L + j];
+            const double d0 = Wg[j * L + j];
+            if (!isfinite(piv) || !isfinite(d0)) { atomicCAS(flag, 0, j + 1); piv = 1.0; R[j * L + j] = 1.0; }
+            const bool dependent = !(piv > 1e-13 * d0);
+            sh_dinv = dependent ? 0.0 : 1.0 / sqrt(piv);
+        }
+        __syncthreads();
+        const double dinv = sh_dinv;
+        for (int c = j + tid; c < n; c += 256) { const double v = R[j * L + c] * dinv; R[j * L + c] = v; rowj[c & 255] = v; }
+        __syncthreads();
+        for (int r = j + 1; r < n; ++r) {
+            const double a = rowj[r & 255];
+            for (int c = r + tid; c < n; c += 256) R[r * L + c] -= a * rowj[c & 255];
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < n; c += 256) {
+        for (int i = c; i >= 0; --i) {
+            double acc = (i == c) ? 1.0 : 0.0;
+            for (int k = i + 1; k <= c; ++k) acc -= R[i * L + k] * Zg[k * L + c];
+            const double d = R[i * L + i];
+            Zg[i * L + c] = d != 0.0 ? acc / d : 0.0;
+        }
+    }
+}
+}  // namespace gpca
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 template <int NN>
 static int run() {
@@ -122,4 +166,38 @@ static int run() {
            NN, n, t[0] / 6, t[1] / 6, memcmp(Z0.data(), Z1.data(), NN * NN * 8) == 0 ? "bit-identical" : "DIFFER");
     return 0;
 }
-int main() { return run<32>() || run<64>(); }
+
+static int run_wide(int n) {
+    const int L = 128;
+    std::vector<double> A(L * L), W(L * L, 0.0);
+    unsigned x = 777u + n;
+    for (auto& a : A) { x = x * 1664525u + 1013904223u; a = ((x >> 8) & 0xffff) / 65536.0 - 0.5; }
+    // (column n - 3 = column 1 + column 2: one dependent pivot, the case the rank contract is for)
+    for (int k = 0; k < L; ++k) A[k * L + n - 3] = A[k * L + 1] + A[k * L + 2];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0.0; for (int k = 0; k < L; ++k) s += A[k * L + i] * A[k * L + j]; W[i * L + j] = s; }
+    double *dW, *dZ0, *dZ1, *dwork; int* flag;
+    CK(hipMalloc(&dW, L * L * 8)); CK(hipMalloc(&dZ0, L * L * 8)); CK(hipMalloc(&dZ1, L * L * 8)); CK(hipMalloc(&dwork, L * L * 8)); CK(hipMalloc(&flag, 4)); CK(hipMemset(flag, 0, 4));
+    CK(hipMemcpy(dW, W.data(), L * L * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double t[2] = {0, 0};
+    for (int rep = 0; rep < 3; ++rep)
+        for (int v = 0; v < 2; ++v) {
+            auto go = [&]() {
+                if (v == 0) hipLaunchKernelGGL(gpca::k_chol_inv_any_old, dim3(1), dim3(256), 0, 0, dW, n, L, dZ0, dwork, flag);
+                else (void)gpca::launch_chol_inv_any(0, dW, n, L, dZ1, flag);
+            };
+            go();
+            hipEventRecord(e0);
+            for (int it = 0; it < 10; ++it) go();
+            hipEventRecord(e1); CK(hipEventSynchronize(e1));
+            float ms; hipEventElapsedTime(&ms, e0, e1); t[v] += ms / 10 * 1e3;
+        }
+    std::vector<double> Z0(L * L), Z1(L * L);
+    CK(hipMemcpy(Z0.data(), dZ0, L * L * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Z1.data(), dZ1, L * L * 8, hipMemcpyDeviceToHost));
+    int zero_rows = 0;
+    for (int i = 0; i < n; ++i) { bool z = true; for (int c = 0; c < n; ++c) z = z && Z1[i * L + c] == 0.0; zero_rows += z; }
+    printf("k_chol_inv_any (L = 128, n = %d): global-memory form %.1f us, LDS-resident %.1f us per launch; results %s; dropped columns %d\n",
+           n, t[0] / 3, t[1] / 3, memcmp(Z0.data(), Z1.data(), L * L * 8) == 0 ? "bit-identical" : "DIFFER", zero_rows);
+    return 0;
+}
+int main() { return run<32>() || run<64>() || run_wide(70) || run_wide(100) || run_wide(128); }

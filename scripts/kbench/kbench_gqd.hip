@@ -5,10 +5,13 @@
 #define GPCA_STAMP 1
 #endif
 #include "../../genomic_pca_amd/csrc/gemm_i8.hip"
+#include "gqs_skew.inc"
 #include <algorithm>
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <cstring>
+#define CK_V(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); } } while (0)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void k_fill(uint32_t* p, int64_t n, uint32_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -27,33 +30,60 @@ static int ab_main(int argc, char** argv) {
     CK(hipMalloc(&G, M * ld8)); CK(hipMalloc(&Qd, Npad * 32 * 4));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)G, M * ld8 / 4, 1u);
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, (uint32_t*)Qd, Npad * 32, 2u);
-    CK(hipMalloc(&qs, 32 * 8)); CK(hipMemset(qs, 0, 32 * 8));
+    CK(hipMalloc(&qs, 32 * 8));
     CK(hipMalloc(&r, M * 4)); CK(hipMalloc(&b, M * 4)); CK(hipMalloc(&s, 32 * 4)); CK(hipMalloc(&T, M * 32 * 4));
-    CK(hipMemset(r, 0, M * 4)); CK(hipMemset(b, 0, M * 4)); CK(hipMemset(s, 0, 32 * 4));
+    {   // operands that make every output element distinct: the settings' outputs are compared bit by bit at the end
+        std::vector<double> hq(32); std::vector<float> hs(32), hr(M), hb(M);
+        for (int i = 0; i < 32; ++i) { hq[i] = 1e-3 * (1 + i); hs[i] = 0.25f + 0.01f * i; }
+        for (int64_t i = 0; i < M; ++i) { hr[i] = 1.f + (float)(i % 977) * 1e-3f; hb[i] = -0.5f + (float)(i % 331) * 3e-3f; }
+        CK(hipMemcpy(qs, hq.data(), 32 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(s, hs.data(), 32 * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(r, hr.data(), M * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b, hb.data(), M * 4, hipMemcpyHostToDevice));
+    }
     CK(hipMalloc(&cp, (M / 32) * 32 * 4)); CK(hipMalloc(&ap, waves * 32 * 8));
     if (gpca::init_device_kernels_i8() != 0) { printf("LDS opt-in failed\n"); return 1; }
     gpca::GqPlan plan{M / 32, waves};
     std::vector<gpca::KernelOpts> kos;
+    std::vector<int> skews;
+    auto go = [&](size_t c_) -> int {
+        if (skews[c_]) return gpca::launch_gq_s(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[c_].gq_phase, skews[c_] - 1);
+        return gpca::launch_gq_d(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[c_]);
+    };
     std::vector<std::string> names;
     for (int i = 5; i < argc; ++i) {
-        int a = 0, bb = 0, ch = 1;
-        sscanf(argv[i], "%d:%d:%d", &a, &bb, &ch);
+        int a = 0, bb = 0, ch = 1, sk = 0;
+        sscanf(argv[i], "%d:%d:%d:%d", &a, &bb, &ch, &sk);
         gpca::KernelOpts ko; ko.gq_chain = ch; ko.gq_phase = a | (bb << 16);
-        kos.push_back(ko); names.push_back(argv[i]);
+        kos.push_back(ko); skews.push_back(sk); names.push_back(argv[i]);
     }
     std::vector<std::vector<double>> ms(kos.size());
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int it = 0; it < 10; ++it) if (gpca::launch_gq_d(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[0]) != 0) { printf("launch refused\n"); return 1; }
+    for (int it = 0; it < 10; ++it) if (go(0) != 0) { printf("launch refused\n"); return 1; }
     for (int rep = 0; rep < reps; ++rep)
         for (size_t c = 0; c < kos.size(); ++c) {
-            gpca::launch_gq_d(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[c]);
+            go(c);
             (void)hipEventRecord(e0);
-            for (int it = 0; it < 10; ++it) gpca::launch_gq_d(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[c]);
+            for (int it = 0; it < 10; ++it) go(c);
             (void)hipEventRecord(e1); CK(hipEventSynchronize(e1));
             float t; (void)hipEventElapsedTime(&t, e0, e1);
             ms[c].push_back(t / 10);
         }
-    printf("k_gq_d %lld x %lld, %d x 10 launches per setting, round-robin (A:B[:chain] -> workgroup b starts at stage ((b %% 8) A + (b / 8) B) mod stages)\n", (long long)M, (long long)N, reps);
+    {   // every setting's T, c partials and column maxima against the first setting's, bit by bit
+        const size_t nt = (size_t)M * 32, nc = (size_t)(M / 32) * 32, na = (size_t)waves * 32;
+        std::vector<float> T0(nt), T1(nt), c0(nc), c1(nc); std::vector<double> a0(32, 0.0), a1(32), ah(na);
+        auto colmax = [&](std::vector<double>& out) { CK_V(hipMemcpy(ah.data(), ap, na * 8, hipMemcpyDeviceToHost)); out.assign(32, 0.0); for (size_t i = 0; i < na; ++i) out[i % 32] = std::max(out[i % 32], ah[i]); };
+        for (size_t c = 0; c < kos.size(); ++c) {
+            CK(hipMemset(T, 0xff, nt * 4)); CK(hipMemset(cp, 0xff, nc * 4)); CK(hipMemset(ap, 0, na * 8));
+            go(c);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(c ? T1.data() : T0.data(), T, nt * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c ? c1.data() : c0.data(), cp, nc * 4, hipMemcpyDeviceToHost));
+            colmax(c ? a1 : a0);
+            if (c) printf("  %-10s vs %s: T %s, c partials %s, column maxima %s\n", names[c].c_str(), names[0].c_str(), memcmp(T0.data(), T1.data(), nt * 4) ? "DIFFER" : "bit-identical",
+                          memcmp(c0.data(), c1.data(), nc * 4) ? "DIFFER" : "bit-identical", memcmp(a0.data(), a1.data(), 32 * 8) ? "DIFFER" : "bit-identical");
+        }
+        double sum = 0; for (size_t i = 0; i < nt; i += 9973) sum += T0[i];
+        printf("  (sample sum of T: %.6g)\n", sum);
+    }
+    printf("k_gq_d %lld x %lld, %d x 10 launches per setting, round-robin (A:B[:chain[:skew]] -> workgroup b starts at stage ((b %% 8) A + (b / 8) B) mod stages; skew 1 = k_gq_s)\n", (long long)M, (long long)N, reps);
     for (size_t c = 0; c < kos.size(); ++c) {
         std::vector<double> v = ms[c]; std::sort(v.begin(), v.end());
         double m = 0; for (double x : v) m += x; m /= v.size();

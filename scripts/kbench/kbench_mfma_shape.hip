@@ -51,6 +51,63 @@ __global__ __launch_bounds__(256) void k16(const i32x4* __restrict__ in, int* __
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// Round 5 (VERDICT r4 #4b): the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 (e2m1) genotype codes x fp6 (e2m3) digits.  The dosage
+// codes 0 / 1 / 2 are exact in e2m1 and e2m3 carries the integers k / 8, |k| <= 15, so a signed base-31 digit of the skinny operand fits; the
+// instruction does 32 x 32 x 64 MACs in the cycles of the int8 32 x 32 x 32 -- twice the MACs per clock (MI355X_MICROARCH.md), f32
+// accumulation (exact while |sum| < 2^24).  A 28-bit value needs 6 such digits against 4 int8 planes, so the packed kernels would gain
+// (4 / 6) x (rate ratio): the question is what rate the part SUSTAINS on high-entropy operands next to the int8 loop above, same run.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k46(const i32x4* __restrict__ in, float* __restrict__ out, int iters, unsigned long long* clk) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const i32x4 a4 = in[t];                                  // 32 e2m1 nibbles: genotype codes as fp4 (masked below to {0, 1, 2} = 0x0, 0x2, 0x4)
+    i32x8 a = {a4.x & 0x66666666 & ~((a4.x & 0x44444444) >> 1), a4.y & 0x66666666 & ~((a4.y & 0x44444444) >> 1),
+               a4.z & 0x66666666 & ~((a4.z & 0x44444444) >> 1), a4.w & 0x66666666 & ~((a4.w & 0x44444444) >> 1), 0, 0, 0, 0};
+    i32x8 b[4];
+    for (int j = 0; j < 4; ++j) {                            // 32 e2m3 values in 6 dwords: random 6-bit patterns with the exponent kept <= 1 (|x| < 2: the uniform part of the grid)
+        const i32x4 lo = in[t + (1 + j) * 65536], hi = in[t + 5 * 65536];
+        b[j] = i32x8{lo.x & ~0x10410410, lo.y & ~0x41041041, lo.z & ~0x04104104, lo.w & ~0x10410410, hi.x & ~0x41041041, (hi.y + j) & ~0x04104104, 0, 0};
+    }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[0], c0, 4, 2, 0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[1], c1, 4, 2, 0, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[2], c2, 4, 2, 0, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[3], c3, 4, 2, 0, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+    out[t] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+// the same with fp8 e4m3 digits (integers to 15 exact: base 31 as well) -- the 8-bit formats run the scaled instruction at half the rate
+__global__ __launch_bounds__(256) void k48(const i32x4* __restrict__ in, float* __restrict__ out, int iters, unsigned long long* clk) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const i32x4 a4 = in[t];
+    i32x8 a = {a4.x & 0x66666666 & ~((a4.x & 0x44444444) >> 1), a4.y & 0x66666666 & ~((a4.y & 0x44444444) >> 1),
+               a4.z & 0x66666666 & ~((a4.z & 0x44444444) >> 1), a4.w & 0x66666666 & ~((a4.w & 0x44444444) >> 1), 0, 0, 0, 0};
+    i32x8 b[4];
+    for (int j = 0; j < 4; ++j) {
+        const i32x4 lo = in[t + (1 + j) * 65536], hi = in[t + 5 * 65536];
+        b[j] = i32x8{lo.x & (int)0xbfbfbfbf, lo.y & (int)0xbfbfbfbf, lo.z & (int)0xbfbfbfbf, lo.w & (int)0xbfbfbfbf, hi.x & (int)0xbfbfbfbf, (hi.y + j) & (int)0xbfbfbfbf, hi.z & (int)0xbfbfbfbf, hi.w & (int)0xbfbfbfbf};
+    }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[0], c0, 4, 0, 0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[1], c1, 4, 0, 0, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[2], c2, 4, 0, 0, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[3], c3, 4, 0, 0, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+    out[t] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 int main(int argc, char** argv) {
     const int zero = argc > 1 && atoi(argv[1]) == 0;       // "0": all-zero operands (the clock without data toggling)
     const int blocks = 256 * 2, iters = 20000;
@@ -61,17 +118,21 @@ int main(int argc, char** argv) {
     hipMalloc(&din, h.size() * 4); hipMalloc(&dout, blocks * 256 * 4); hipMalloc(&dclk, blocks * 16);
     hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int which = 0; which < 2; ++which) {
+    auto go = [&](int which) {
+        if (which == 0) hipLaunchKernelGGL(k32, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+        else if (which == 1) hipLaunchKernelGGL(k16, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+        else if (which == 2) hipLaunchKernelGGL(k46, dim3(blocks), dim3(256), 0, 0, din, (float*)dout, iters, dclk);
+        else hipLaunchKernelGGL(k48, dim3(blocks), dim3(256), 0, 0, din, (float*)dout, iters, dclk);
+    };
+    for (int which = 0; which < 4; ++which) {
         for (int rep = 0; rep < 3; ++rep) {
             // ~2 s of back-to-back launches before the timed one (DVFS settles)
             const int warm = rep == 0 ? 300 : 2;
             for (int w = 0; w < warm; ++w) {
-                if (which == 0) hipLaunchKernelGGL(k32, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
-                else hipLaunchKernelGGL(k16, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+                go(which);
             }
             hipEventRecord(e0);
-            if (which == 0) hipLaunchKernelGGL(k32, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
-            else hipLaunchKernelGGL(k16, dim3(blocks), dim3(256), 0, 0, din, dout, iters, dclk);
+            go(which);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
             std::vector<unsigned long long> c(blocks * 2);
@@ -79,9 +140,10 @@ int main(int argc, char** argv) {
             std::vector<double> ghz;
             for (int b = 0; b < blocks; ++b) ghz.push_back((double)c[2 * b] / (double)c[2 * b + 1] * 0.1);
             std::sort(ghz.begin(), ghz.end());
-            const double macs = (double)blocks * 4 /*waves*/ * iters * 4.0 * 32768.0;
+            const double macs = (double)blocks * 4 /*waves*/ * iters * 4.0 * 32768.0 * (which >= 2 ? 2.0 : 1.0);
+            const char* nm[] = {"i8 32x32x32", "i8 16x16x64", "scaled 32x32x64 fp4 (e2m1) x fp6 (e2m3)", "scaled 32x32x64 fp4 (e2m1) x fp8 (e4m3)"};
             printf("%s %s rep %d: %.3f ms  %.1f TOP/s  in-kernel clock %.3f GHz (median over workgroups)\n", zero ? "zeros " : "random",
-                   which == 0 ? "32x32x32" : "16x16x64", rep, ms, 2.0 * macs / (ms * 1e-3) / 1e12, ghz[ghz.size() / 2]);
+                   nm[which], rep, ms, 2.0 * macs / (ms * 1e-3) / 1e12, ghz[ghz.size() / 2]);
         }
     }
     return 0;

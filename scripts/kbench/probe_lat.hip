@@ -87,6 +87,55 @@ __global__ __launch_bounds__(64) void k_probe(double* out, unsigned long long* c
 #pragma unroll 16
     for (int i = 0; i < REP / 4; ++i) { lds[lane] = a; asm volatile("" ::: "memory"); a = lds[lane ^ 1] * b; }
     END
+    // 11-15: issue rate of the K1 epilogue's conversions (8 independent destinations, 256 instructions in all)
+#define INDEP8(INSTR, OUTC, INC, SRC)                                                                         \
+    BEGIN                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < REP / 8; ++i) {                                                     \
+        asm volatile(INSTR " %0, %1" : OUTC(r0) : INC(SRC)); asm volatile(INSTR " %0, %1" : OUTC(r1) : INC(SRC));  \
+        asm volatile(INSTR " %0, %1" : OUTC(r2) : INC(SRC)); asm volatile(INSTR " %0, %1" : OUTC(r3) : INC(SRC));  \
+        asm volatile(INSTR " %0, %1" : OUTC(r4) : INC(SRC)); asm volatile(INSTR " %0, %1" : OUTC(r5) : INC(SRC));  \
+        asm volatile(INSTR " %0, %1" : OUTC(r6) : INC(SRC)); asm volatile(INSTR " %0, %1" : OUTC(r7) : INC(SRC));  \
+    }                                                                                                         \
+    END
+    { int isrc = lane * 977 + 13; double r0, r1, r2, r3, r4, r5, r6, r7;
+      INDEP8("v_cvt_f64_i32", "=v", "v", isrc)
+      a += r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; }
+    { float r0, r1, r2, r3, r4, r5, r6, r7;
+      INDEP8("v_cvt_f32_f64", "=v", "v", a)
+      a += r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; }
+    { double r0 = a, r1 = a, r2 = a, r3 = a, r4 = a, r5 = a, r6 = a, r7 = a;
+      BEGIN
+#pragma unroll
+      for (int i = 0; i < REP / 8; ++i) {
+          asm volatile("v_add_f64 %0, %0, %1" : "+v"(r0) : "v"(b)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(r1) : "v"(b));
+          asm volatile("v_add_f64 %0, %0, %1" : "+v"(r2) : "v"(b)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(r3) : "v"(b));
+          asm volatile("v_add_f64 %0, %0, %1" : "+v"(r4) : "v"(b)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(r5) : "v"(b));
+          asm volatile("v_add_f64 %0, %0, %1" : "+v"(r6) : "v"(b)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(r7) : "v"(b));
+      }
+      END
+      a += r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; }
+    { double r0 = a, r1 = a, r2 = a, r3 = a, r4 = a, r5 = a, r6 = a, r7 = a;
+      BEGIN
+#pragma unroll
+      for (int i = 0; i < REP / 8; ++i) {
+          asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r0) : "v"(b)); asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r1) : "v"(b));
+          asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r2) : "v"(b)); asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r3) : "v"(b));
+          asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r4) : "v"(b)); asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r5) : "v"(b));
+          asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r6) : "v"(b)); asm volatile("v_fmac_f64 %0, 0x40600000, %1" : "+v"(r7) : "v"(b));
+      }
+      END
+      a += r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; }
+    { float r0 = (float)a, r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = r0, r7 = r0; float fb = 1.0001f;
+      BEGIN
+#pragma unroll
+      for (int i = 0; i < REP / 8; ++i) {
+          asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r0) : "v"(fb)); asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r1) : "v"(fb));
+          asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r2) : "v"(fb)); asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r3) : "v"(fb));
+          asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r4) : "v"(fb)); asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r5) : "v"(fb));
+          asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r6) : "v"(fb)); asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r7) : "v"(fb));
+      }
+      END
+      a += r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; }
     out[lane] = a;
 }
 int main() {
@@ -97,8 +146,10 @@ int main() {
     unsigned long long h[16]; hipMemcpy(h, c, sizeof h, hipMemcpyDeviceToHost);
     const char* nm[] = {"empty", "dependent v_fma_f64 x256", "4 independent v_fma_f64 chains, 256 in all", "dependent v_mul_f64 x256", "dependent v_rsq_f64 x256",
                         "dependent v_fma_f32 x256", "(2 readlane + mul + fma) x128", "LDS read -> address of the next x64", "(2 DPP mov + mul + add) x64",
-                        "(cmp + mul + 2 cndmask) x64", "(LDS write, read other lane's, mul) x64"};
-    const int reps[] = {1, 256, 256, 256, 256, 256, 128, 64, 64, 64, 64};
-    for (int i = 0; i < 11; ++i) printf("%-48s %6llu cycles  = %.1f per repetition\n", nm[i], h[i], (double)(h[i] - h[0]) / reps[i]);
+                        "(cmp + mul + 2 cndmask) x64", "(LDS write, read other lane's, mul) x64",
+                        "independent v_cvt_f64_i32 x256", "independent v_cvt_f32_f64 x256", "independent v_add_f64 x256 (8 chains)",
+                        "independent v_fmac_f64 with a literal x256", "independent v_fmac_f32 x256 (8 chains)"};
+    const int reps[] = {1, 256, 256, 256, 256, 256, 128, 64, 64, 64, 64, 256, 256, 256, 256, 256};
+    for (int i = 0; i < 16; ++i) printf("%-48s %6llu cycles  = %.1f per repetition\n", nm[i], h[i], (double)(h[i] - h[0]) / reps[i]);
     return 0;
 }

@@ -988,8 +988,8 @@ def test_alternative_kernels_same_answer(gpca, oracle, monkeypatch, env):
     assert oracle.max_abs_dpc(res["alt"][1], R["scores"]) < TOL_PC
 
 
-@pytest.mark.parametrize("N", [200, 1000, 1300])
-@pytest.mark.parametrize("M", [500, 1500, 2500, 3700])
+@pytest.mark.parametrize("M,N", [(m, n) for n in (200, 1000, 1300) for m in (500, 1500, 2500, 3700)] +
+                         [(1500, 500), (3700, 500), (1500, 700), (3700, 700), (2500, 1800), (1500, 2504), (3700, 2504)])
 def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, monkeypatch, M, N):
     """k_gq_d's rounds of fewer than four tiles per wave (R = 3, 2, 1 and waves that only ride along): grids of 1, 2 and 3 workgroups
     over 16 ... 116 row units leave every remainder class behind the full rounds -- (3,3,2,2), (2,2,1,1), (1,1,1,1), (2,1,1,1),
@@ -1001,8 +1001,10 @@ def test_short_dma_rounds_same_bits_as_the_register_staged_kernel(gpca, oracle, 
     th = gpca.synth_thresholds(M, 3, seed=5, fst=0.1)
     G = oracle.synth_genotypes(M, N, 5, th)
     res = {}
-    # (N = 1000 and 1300 are 8 and 12 stages: the rounds of a workgroup are CHAINED there -- the next round's first units and planes
-    #  are fetched behind the current round's epilogue, whatever the two rounds' tile counts; 2 stages keep the drained form)
+    # (N = 1000, 1300, 1800 and 2504 are 8, 12, 16 and 20 stages of 128 samples: the rounds of a workgroup are CHAINED there -- the next
+    #  round's first units and planes are fetched behind the current round's epilogue, whatever the two rounds' tile counts -- and from
+    #  16 stages the workgroups start their sweeps at different stages; 2, 4 and 6 stages (N = 200, 500, 700) keep the drained form:
+    #  the sample axes of 1000 Genomes (2 504) and of a few hundred to a few thousand samples that the shape sweep is about)
     for name, env in (("staged", dict(simple=1)), ("w4", dict(gq_waves=4)), ("w8", dict(gq_waves=8)), ("w12", dict(gq_waves=12)),
                       ("w4_k2w8", dict(gq_waves=4, gtt_waves=8)), ("w16", dict(gq_waves=16, gtt_waves=32)), ("default", {})):
         with monkeypatch.context() as mp:
