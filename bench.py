@@ -252,6 +252,12 @@ def roofline_of(timings, precision, steps, storage="int8", planes=4):
         return {"bound": "mfma", "achieved": tops, "peak": 5000.0, "unit": "TOP/s (int8, executed digit-plane MFMAs)",
                 "frac": tops / 5000.0, "frac_of_sustained": tops / INT8_MFMA_SUSTAINED_TOPS, "sustained_peak": INT8_MFMA_SUSTAINED_TOPS,
                 "sustained_peak_source": "bare register-resident int8 MFMA loop on random bytes, 1.70 GHz under load (profiles/r1_kbench_summary.md section 8)",
+                "bound_detail": "matrix-core issue under operand delivery, not the dense int8 peak: 256 accumulation registers hold 4 tiles x 4 planes, so a "
+                                "loaded plane operand feeds 4 MFMAs and Q's planes are re-read by every wave (18 % of the launch, ablated); the clock under "
+                                "a dense int8 MFMA stream is 1.7 GHz, not 2.4.  Measured reach of this design: 0.49 of `peak` with the plane operands "
+                                "shared through LDS and nothing synchronised (profiles/r4_kbench_summary.md section 3); fp4 x fp6 scaled MFMAs run at "
+                                "1.97 x the int8 rate but need 6 planes for 28 bits = 384 accumulators at 4 tiles (profiles/r5_kbench_summary.md section 4)",
+                "reach_of_this_design_frac": 0.49,
                 "digit_planes": planes, "traffic": traffic, "hbm_GBs_algorithmic": gbs, "algorithmic_TFLOPs_equivalent": tflops, **common}
     if precision == "i8":   # exact-integer MFMA needs ~1/10 of the matrix-core time per byte: HBM-bound
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

@@ -31,7 +31,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-t", "--threads", type=int, default=None, help="accepted for compatibility (the GPU does the work)")
     p.add_argument("--log-level", default="Info")
     p.add_argument("-d", "--vcf-dir", default=None)
-    p.add_argument("-k", "--components", type=int, default=None)
+    p.add_argument("-k", "--components", type=int, default=None,
+                   help="Number of principal components to compute (for VCF workflow); at most 118 here (the sketch holds components + 10 <= 128 "
+                        "columns, gpca.h; the reference clamps only to min(samples, variants), main.rs:621-628)")
     p.add_argument("--maf", type=float, default=None)
     p.add_argument("--rfit-seed", type=int, default=None)
     p.add_argument("--eigensnp", action="store_true")

@@ -57,7 +57,8 @@ void print_help() {
         "  -t, --threads <THREADS>              accepted for compatibility (the GPU does the work)\n"
         "      --log-level <LOG_LEVEL>          [default: Info]\n"
         "  -d, --vcf-dir <VCF_DIR>              Directory containing VCF files (required if not using --eigensnp).\n"
-        "  -k, --components <COMPONENTS>        Number of principal components to compute (for VCF workflow).\n"
+        "  -k, --components <COMPONENTS>        Number of principal components to compute (for VCF workflow); at most 118 here\n"
+        "                                       (the sketch holds components + 10 <= 128 columns; the reference has no cap).\n"
         "      --maf <MAF>                      Minimum MAF for VCF variant filtering [default: 0.01 in VCF mode]\n"
         "      --rfit-seed <RFIT_SEED>          Seed for the randomized SVD (VCF workflow).\n"
         "      --eigensnp                       Run PCA on BED + LD block files.\n"

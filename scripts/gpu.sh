@@ -1,5 +1,6 @@
 #!/bin/bash
-# The one GPU-box helper (replaces the per-experiment gpu_r3_*.sh launchers).  usage: scripts/gpu.sh <tag> <step> [<step> ...]
+# The one GPU-box helper (the per-experiment gpu_*_r2.sh / gpu_r3_*.sh launchers of earlier rounds are gone: every run they made is a
+# step list of this script -- e.g. the streaming-read ceiling probe is `kbench=kbench_stream`, a PMC pass is part of `profile`).  usage: scripts/gpu.sh <tag> <step> [<step> ...]
 # Steps run in order and the chain stops at the first failure (no GPU step is started after one that failed or timed out).
 #   tests[=<pytest -k expression>]   the -m gpu suite (or a selection)           -> gpurun_out/pytest_<tag>.log
 #   file=<tests/x.py[::test]>        one test file / node id                      -> gpurun_out/pytest_<tag>.log (appended)

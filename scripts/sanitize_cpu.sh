@@ -9,8 +9,8 @@ make -s -C oracle asan
 make -s -C genomic_pca_amd/host asan
 ASAN_LIB=$(gcc -print-file-name=libasan.so)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
-echo "== oracle under ASan + UBSan (tests/test_oracle.py, tests/test_launch.py's hub test, tests/test_dist_gloo.py)"
-GPCA_ORACLE_SANITIZE=1 LD_PRELOAD=$ASAN_LIB python -m pytest tests/test_oracle.py tests/test_dist_gloo.py -x -q -m "not gpu" -p no:cacheprovider
+echo "== oracle under ASan + UBSan (tests/test_oracle.py, tests/test_launch.py, tests/test_dist_gloo.py)"
+GPCA_ORACLE_SANITIZE=1 LD_PRELOAD=$ASAN_LIB python -m pytest tests/test_oracle.py tests/test_launch.py tests/test_dist_gloo.py -x -q -m "not gpu" -p no:cacheprovider
 echo "== host program and parsers under ASan + UBSan (tests/test_cpp_host.py, tests/test_io_cli.py: the CPU tests)"
 GPCA_HOST_SANITIZE=1 python -m pytest tests/test_cpp_host.py tests/test_io_cli.py tests/test_abi.py -x -q -m "not gpu" -p no:cacheprovider
 echo "sanitize_cpu: clean"

@@ -173,6 +173,27 @@ def test_streamed_equals_resident_bitwise(gpca, oracle, store, kind):
 
 
 @pytest.mark.parametrize("store", ["int8", "2bit"])
+def test_wide_sketch_streamed_equals_resident(gpca, oracle, store):
+    """k = 70 -> l = 80: a sketch of 128 padded columns (four 32-column GEMM blocks, the any-L helpers of wide_sketch.hip, the running
+    column maxima and integer partial sums of four blocks) out of core.  The 6-pass walk is the resident run's bits; the fused walk
+    (K1 and K2 of a power iteration per panel visit, quantised against the previous pass's maxima) holds its usual bar."""
+    M, N, P, k, seed = 9_000, 700, 6, 70, 4
+    th = gpca.synth_thresholds(M, P, seed=seed, fst=0.25)
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.synth_genotypes(M, N, seed, th)
+        res = _run(e, k, seed, gpca.QcConfig.none())
+    with gpca.GpcaEngine(**_modes(store)) as e:
+        e.stream_open(gpca.PanelSource.synth(th, seed), M, N, panel_rows=2048, ring_slots=2, fused=False)
+        stm = _run(e, k, seed, gpca.QcConfig.none())
+        _same(res, stm)
+        e.stream_open(gpca.PanelSource.synth(th, seed), M, N, panel_rows=2048, ring_slots=2)           # fused
+        fus = _run(e, k, seed, gpca.QcConfig.none())
+    assert res["ev"].shape == (k,)
+    assert np.max(np.abs(fus["ev"] - res["ev"]) / res["ev"]) < 1e-6
+    assert oracle.max_abs_dpc(fus["sc"][:, :P - 1], res["sc"][:, :P - 1]) < 1e-6
+
+
+@pytest.mark.parametrize("store", ["int8", "2bit"])
 @pytest.mark.parametrize("kind,register", [("mapped_i8", False), ("mapped_i8", True), ("mapped_bed", False), ("mapped_bed", True)])
 def test_mapped_sources_equal_resident_bitwise(gpca, oracle, store, kind, register, monkeypatch):
     """GPCA_PANEL_MAPPED_*: the whole matrix sits in host memory (here with a row pitch wider than a row, as a padded mapping has);
