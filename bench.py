@@ -802,8 +802,10 @@ def main():
         # bench lines of the other BASELINE.json configs, measured with this build by the scripts named in DESIGN.md (too large or too
         # long for the default run; each file holds one line in this same format)
         out["see_also"] = {k_: v_ for k_, v_ in {
-            "this command on one box this round: bench line, rocprofv3 --kernel-trace --stats, PMC passes, one call launch by launch": "profiles/r4a_summary.md",
-            "A/B and ablation evidence behind the round's kernel changes": "profiles/r4_kbench_summary.md",
+            "this command on one box this round: bench line, rocprofv3 --kernel-trace --stats, PMC passes": "profiles/r5a_summary.md",
+            "one call of that run launch by launch": "profiles/r5a_call_timeline.md",
+            "A/B and ablation evidence behind the round's kernel changes": "profiles/r5_kbench_summary.md",
+            "the same for round 4's kernels": "profiles/r4_kbench_summary.md",
             "10M x 100k on ONE GPU, 2-bit rows, exact path": "profiles/r2_bench_10Mx100k_2bit_one_gpu.json",
             "configs[2] end to end through the command line": "profiles/r2_cli_config3_end_to_end.json",
             "host panel sources at link rate (32 GB matrix)": "profiles/r3_stream_host_link_rates_32GB.jsonl",
