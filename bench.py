@@ -787,7 +787,7 @@ def main():
                                   "panels of this shape.  Beside it, `gemm_share_of_step` of the real line: the part of the real step that is GEMM "
                                   "kernel time -- near 1, the fills are hidden behind the sweeps and the generator is not what bounds the line",
                     "ms_per_step": dt5h * 1e3, "value": M5 * N5 / dt5h, "unit": "SNPs*samples/s",
-                    "gemm_sweeps_ms_per_step": hidden["gemm_sweeps_ms_per_step"], "generator_ms_per_step": hidden["generator_ms_per_step"],
+                    "gemm_sweeps_ms_per_step": hidden["gemm_sweeps_ms_per_step"],
                     "hbm_GBs_per_sweep_algorithmic": hidden["hbm_GBs_per_sweep_algorithmic"]},
                 "workload": "BASELINE.json configs[4] per-GPU shard, out of core: 6.25M SNPs x 500k samples (781 GB of 2-bit codes per pass, never "
                             "resident), k = 40, l = 50, panels of 131 072 rows from the device generator (GPCA_PANEL_SYNTH16) through a ring of 3",
