@@ -582,6 +582,11 @@ def main():
     local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(a.gpus, 1):
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        # (ranks started by torch.distributed.run do not pass through launch.run_ranks, which sets this for its children.  This pool's host
+        #  driver supports dmabuf IPC only; with the legacy mode RCCL's ncclCommInitRank fails in hipIpcGetMemHandle.  Before any HIP call;
+        #  a value the caller exported wins.)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # No torch anywhere in this harness: libgpca.so carries its own RCCL exchange, and what the host side of a multi-rank run needs (the
     # unique id handed round, a barrier on both sides of the timed region, the max over ranks) goes through genomic_pca_amd/launch.py's hub
     # -- also when torch.distributed.run started the ranks (rank 0 then hosts the hub).  One HIP runtime per process, whatever the launcher.

@@ -259,13 +259,12 @@ template <int R, int ND = kDigits>
 __device__ __forceinline__ void gq2_group(const uint8_t* __restrict__ G2, int64_t ld2, int64_t nsuper,
                                           const int8_t* __restrict__ Qd, const double* __restrict__ qscale, const float* __restrict__ rv,
                                           const float* __restrict__ bv, const float* __restrict__ sv, float* __restrict__ Tout, int scale_out, int64_t ldt,
-                                          float* __restrict__ cunit, float& amax, int64_t row0, int c_in, int h_in, int lane_in, const unsigned* lut) {
+                                          float* __restrict__ cunit, float& amax, int64_t row0, int lane_in, const unsigned* lut) {
     // (the lane's place is made opaque per group and the column's scales are fetched in the epilogue: less is carried through the decode
     //  loop, where the four-plane kernel has no register to spare.  It parked 9 VGPRs in scratch; now 5, all written before the loop and
     //  read back in the epilogues -- the loop itself never touched scratch, before or after)
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    (void)c_in; (void)h_in;
     const int c = lane & 31, h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rg = make_rsrc8(G2 + row0 * ld2);
     uint32_t gvo[R];
@@ -381,14 +380,14 @@ __global__ __launch_bounds__(256, RMAX == 4 ? 1 : 2) void k_gq_2bit(const uint8_
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (RMAX == 4)
-        for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut);
+        for (; u + 4 <= u_end; u += 4) gq2_group<4, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, lane, lut);
     else        // (kbench experiment: two tiles per sweep, two waves per SIMD)
-        for (; u + 2 <= u_end; u += 2) gq2_group<2, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut);
+        for (; u + 2 <= u_end; u += 2) gq2_group<2, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, lane, lut);
     // the 1-3 units left over go in ONE more sweep over the samples (a wave with 31 units used to make two, of 2 and of 1 tile:
     // every sweep re-reads all of Q's planes and pays its prologue)
-    if (RMAX == 4 && u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut); u += 3; }
-    else if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut); u += 2; }
-    else if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, 0, 0, lane, lut); u += 1; }
+    if (RMAX == 4 && u + 3 <= u_end) { gq2_group<3, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, lane, lut); u += 3; }
+    else if (u + 2 <= u_end) { gq2_group<2, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, lane, lut); u += 2; }
+    else if (u + 1 <= u_end) { gq2_group<1, ND>(G2, ld2, nsuper, Qd, qscale, rv, bv, sv, Tout, scale_out, ldt, cpart, amax, (int64_t)u * 32, lane, lut); u += 1; }
     float am_lo, am_hi; halves_pair(amax, am_lo, am_hi);
     const float am = fmaxf(am_lo, am_hi);
     {
@@ -529,10 +528,7 @@ __device__ __forceinline__ i32x4 gqd_rsrc(const void* p) {
 #ifndef GPCA_T_NT_MODE
 #define GPCA_T_NT_MODE 2      // (harness: 0 never, 1 every round, 2 every round but a workgroup's last)
 #endif
-#ifndef GPCA_GQD_DIRECT
-#define GPCA_GQD_DIRECT 0     // (harness: 1 = sixteen dword buffer stores per lane instead of the pass through LDS; measured slower)
-#endif
-template <int BITS, bool RB_LDS, bool ACC_ASM = false>
+template <int BITS, bool RB_LDS>
 __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rrow, float brow, const float* rl, const float* bl,
                                             double qs, float sj, int scale_out,
                                             float* __restrict__ tile, float* __restrict__ Tout, int64_t ldt, int64_t unit,
@@ -545,59 +541,13 @@ __device__ __forceinline__ void gq_tile_out(const i32x16 (&a)[kDigits], float rr
     asm volatile("" : "+v"(lane));
     const int c = lane & 31, h = lane >> 5;
     float ct = 0.f;
-#if GPCA_GQD_DIRECT
-    // DIRECT form.  Element e of a lane is row (e & 3) + 8 (e >> 2) + 4 h, column c of the tile: one dword store per element writes two
-    // whole rows of the tile (lanes 0-31 one 128-byte row, lanes 32-63 the row four below) -- full lines, nothing to transpose.  As
-    // BUFFER stores they need one address register for all 16: the lane's place (column, half) is the vector offset, the row of the
-    // element an immediate ((e & 3) rows) plus a scalar offset (8 (e >> 2) rows).  No pass through LDS, no wave fences, no wait for an
-    // LDS round trip between the arithmetic and the stores: 3.84 -> X us per round of four tiles (scripts/kbench/kbench_gqd.hip).
-    {
-        (void)tile;
-        const uint32_t pitch = (uint32_t)ldt * 4u;
-        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(Tout + unit * 32 * ldt, 0, 32 * (int)pitch, GPCA_RSRC_FLAGS);
-        const uint32_t vo = (uint32_t)c * 4u + (uint32_t)h * 4u * pitch;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float ri = RB_LDS ? rl[rin] : __shfl(rrow, rin), bi = RB_LDS ? bl[rin] : __shfl(brow, rin);
-            const float gq = (float)(combine_digits<BITS>(a, e) * qs);
-            const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
-            ct = __fmaf_rn(bi, tv, ct);
-            const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
-            amax = fmaxf(amax, fabsf(ov));
-            const uint32_t so = (uint32_t)(8 * (e >> 2)) * pitch;
-            // streaming store when another round follows (see the LDS form below for why); a workgroup's last round stores plainly
-            if (GPCA_T_NT_MODE == 1 || (GPCA_T_NT_MODE == 2 && stream_store)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ov), rt, vo + (uint32_t)(e & 3) * pitch, so, 2);
-            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ov), rt, vo + (uint32_t)(e & 3) * pitch, so, 0);
-        }
-        GPCA_STORE_CUNIT(unit)
-        __builtin_amdgcn_sched_barrier(0);
-        return;
-    }
-#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;          // row of element e inside the tile
         // r and b of that row: from the wave's LDS staging (k_gq_d: DMA-ed at the start of the round, no compiler-visible load whose
         // wait would drain the DMA queue), or from lane `rin` of registers loaded one row per lane
         const float ri = RB_LDS ? rl[rin] : __shfl(rrow, rin), bi = RB_LDS ? bl[rin] : __shfl(brow, rin);
-        double comb;
-        if (ACC_ASM) {
-            // (harness kernel k_gq_s, scripts/kbench/gqs_skew.inc) the four digit sums of element e, read from the accumulation registers
-            // HERE: left to the register allocator, the 64 reads of a tile that leaves in the middle of the stage loop became copies it
-            // made every stage -- through scratch
-            static_assert(!ACC_ASM || BITS == 7, "four base-128 digits");
-            int d0, d1, d2, d3;
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d0) : "a"(a[0][e]));
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d1) : "a"(a[1][e]));
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d2) : "a"(a[2][e]));
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d3) : "a"(a[kDigits - 1][e]));
-            comb = (double)d0 + 128.0 * (double)d1 + 16384.0 * (double)d2 + 2097152.0 * (double)d3;      // (= combine_digits<7>)
-            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        } else {
-            comb = combine_digits<BITS>(a, e);
-        }
-        const float gq = (float)(comb * qs);
+        const float gq = (float)(combine_digits<BITS>(a, e) * qs);
         const float tv = __fmaf_rn(ri, gq, __fmul_rn(bi, sj));   // roundings pinned: every K1 variant returns the same bits
         ct = __fmaf_rn(bi, tv, ct);
         const float ov = scale_out ? __fmul_rn(ri, tv) : tv;
