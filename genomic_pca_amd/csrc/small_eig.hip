@@ -26,8 +26,10 @@
 // waves.  A lone wave issues one instruction every ~5 cycles and waits 8 for a dependent f64 result, 20 for v_rsq_f64, ~75 for an LDS
 // round trip (scripts/kbench/probe_lat.hip): the 923 serial plane rotations of n = 30 cost ~370 cycles each however they were arranged --
 // 250 us a call against 126 us for the host round trip they replace, and 7 ms at n = 128 (profiles/r5_kbench_summary.md).  Jacobi spends
-// more flops and keeps four to sixteen waves busy: 138 us at n = 30 (248 steps of ~1 200 cycles: two rotation chains ~550, the LDS
-// exchange and its barrier the rest), 0.9 ms at n = 64; at n = 128 the exchange is LDS-bandwidth bound (8.5 ms: open).
+// more flops and keeps four to sixteen waves busy: 117 us at n = 30 (203 steps of ~1 200 cycles: the rotation chain ~550, the LDS
+// exchange and its barrier the rest), 0.8 ms at n = 64; at n = 128 the exchange is LDS-bandwidth bound (6.3 ms), and sketches of
+// 65-128 columns go through k_small_eigh_ql below: QL again, but with its serial chain on one wave and the eigenvector updates on
+// two others (4.6 ms).
 #include "kernels.h"
 
 #ifndef GPCA_EIG_ABL
@@ -37,7 +39,7 @@
 #define GPCA_EIG_STAMP 0        // scripts/kbench/kbench_eig.hip: s_memrealtime (100 MHz) at the phase boundaries into res[kEigResFlag + 2 ..]
 #endif
 #if GPCA_EIG_STAMP
-__device__ unsigned long long g_eig_stamp[16];      // [2 s]: s_memrealtime (100 MHz), [2 s + 1]: s_memtime (shader clock) at stamp s; [10] sweeps, [11] steps
+__device__ unsigned long long g_eig_stamp[20];      // [2 s]: s_memrealtime (100 MHz), [2 s + 1]: s_memtime (shader clock) at stamp s; [10] sweeps, [11] steps
 #define EIG_STAMP(SLOT) { if (threadIdx.x == 0) { g_eig_stamp[2 * (SLOT)] = __builtin_amdgcn_s_memrealtime(); g_eig_stamp[2 * (SLOT) + 1] = __builtin_amdgcn_s_memtime(); } }
 #else
 #define EIG_STAMP(SLOT)
@@ -96,6 +98,46 @@ EIGDEV void jac_rot(double app, double a01, double a10, double aqq, double& c, d
     const double h = fma(0.5, c2, 0.5);                        // cos^2 t, in [0.5, 1]
     const double ci = eig_rsqrt(h);
     c = live ? h * ci : 1.0; s = live ? 0.5 * s2 * ci : 0.0;
+}
+
+// The results from eigenvalue-by-slot `wsl` (prescaled by 1 / unsc), the eigenvector of slot s = getV(row, s), and which slots are genuine
+// (a padded index of the Jacobi form keeps a unit vector outside the first n rows).  Called by every thread of the workgroup; `wsl`,
+// `order` are LDS arrays of 128.
+template <int NT, class GetV>
+EIGDEV void eig_emit(GetV getV, double* wsl, int* order, const int* genuine, int slots, int n, int Lw, int k, int zmode, double denom, double unsc,
+                     const int* __restrict__ cholflag, int capped, double* __restrict__ Z, double* __restrict__ res, double* __restrict__ Vout, int tid) {
+    // descending order over the genuine slots: rank_s = #{t genuine : w_t > w_s or (w_t == w_s and t < s)}  (= the host's stable selection sort)
+    double wmine = 0.0; int rank = -1;
+    if (tid < slots && genuine[tid]) {
+        wmine = wsl[tid]; rank = 0;
+        for (int t = 0; t < slots; ++t) { const double wt = wsl[t]; if (t != tid && genuine[t] && (wt > wmine || (wt == wmine && t < tid))) ++rank; }
+    }
+    __syncthreads();
+    if (rank >= 0 && rank < n) { order[rank] = tid; wsl[rank] = wmine; }       // (wsl re-used: every thread has read what it needs)
+    __syncthreads();
+    for (int j = tid; j < kMaxSketchCols; j += NT) {
+        const double w = j < n ? wsl[j] * unsc : 0.0;
+        res[kEigResW + j] = w;
+        res[kEigResSv + j] = w > 0.0 ? sqrt(w) : 0.0;
+        res[kEigResEig + j] = j < k ? w / denom : 0.0;
+    }
+    if (tid == 0) { res[kEigResFlag] = cholflag ? (double)cholflag[0] : 0.0; res[kEigResFlag + 1] = (double)capped; }
+    for (int e0 = tid; e0 < Lw * k; e0 += NT) {
+        const int r = e0 / k, c = e0 - r * k;
+        double z0 = 0.0, z1 = 0.0;
+        if (r < n && c < n) {
+            const double x = getV(r, order[c]);
+            if (zmode == 0) {
+                const double w = wsl[c] * unsc;
+                const double sv = w > 0.0 ? sqrt(w) : 0.0;
+                z0 = x * sv; z1 = sv > 0.0 ? x / sv : 0.0;
+            } else { z0 = x; z1 = x; }
+        }
+        Z[e0] = z0; Z[(size_t)Lw * k + e0] = z1;
+    }
+    EIG_STAMP(4)
+    if (Vout)
+        for (int e0 = tid; e0 < n * n; e0 += NT) { const int r = e0 / n, c = e0 - r * n; Vout[e0] = getV(r, order[c]); }
 }
 
 // src: the Gram W [Lw][Lw] (nslices == 0) or `nslices` partial sums of it [nslices][Lw * Lw] (summed here in slice order); only the
@@ -286,43 +328,431 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
     // a padded index keeps a unit vector outside the first n rows: slot t is genuine when its column has weight inside them
     if (tid < L) { double ss = 0.0; for (int r = 0; r < n; ++r) { const double x = bufV[r * LP + tid]; ss = fma(x, x, ss); } genuine[tid] = ss > 0.25; }
     __syncthreads();
-    // descending order over the genuine slots: rank_s = #{t genuine : w_t > w_s or (w_t == w_s and t < s)}  (= the host's stable selection sort)
-    double wmine = 0.0; int rank = -1;
-    if (tid < L && genuine[tid]) {
-        wmine = wsl[tid]; rank = 0;
-        for (int t = 0; t < L; ++t) { const double wt = wsl[t]; if (t != tid && genuine[t] && (wt > wmine || (wt == wmine && t < tid))) ++rank; }
-    }
+    eig_emit<NT>([&](int r, int slot) { return bufV[r * LP + slot]; }, wsl, order, genuine, L, n, Lw, k, zmode, denom, unsc, cholflag, capped, Z, res, Vout, tid);
+}
+
+
+// ================================================================================================
+// Sketches of 65 .. 128 columns: Householder tridiagonalisation + implicit QL (the pair the host pin runs), arranged for one workgroup.
+// The Jacobi form above moves the whole matrix through LDS every step: 0.57 / 0.79 ms at n = 50 / 64, 5.0 / 6.3 ms at n = 100 / 128
+// (LDS-bandwidth bound).  This form: 0.60 / 0.93 ms at n = 50 / 64 (so Jacobi keeps L = 64), **2.8 / 4.6 ms at n = 100 / 128**
+// (scripts/kbench/kbench_eig.hip, profiles/r5_kbench_summary.md section 1): 0.34 / 0.53 ms of tridiagonalisation + Q, the rest the
+// serial chain at ~530 cycles per rotation (10 753 / 18 074 rotations).
+//   * tridiagonalisation and the accumulation of Q: n - 2 reflectors, each a matrix-vector product and a rank-2 (rank-1) update
+//     spread over all 1 024 threads, four (three) barriers per reflector; the matrix sits in LDS with row r rotated by r places
+//     (ql_at), so rows and columns are both conflict-free without padding (128 x 128 doubles = 128 KiB of the 160);
+//   * the QL iteration on (d, e) is a serial chain of plane rotations that does not depend on the eigenvectors: ONE wave runs it and posts every rotation (index, c, s) into a ring in LDS; one or
+//     two other waves apply the rotations to the rows of Z (a lane owns a row; the element two consecutive rotations share stays
+//     in a register), lagging behind by what the ring holds.  The other waves wait at the barrier.
+//   * every wait is bounded: a side that polls too long sets the cap flag (-> GPCA_ERR_NOT_CONVERGED) and leaves.
+// Results through eig_emit like the Jacobi form.  Same prescale (largest entry in [0.5, 1)): "negligible" is relative to a running
+// |d| + |e| with a floor of 1e-20, so no square underflows.
+// ================================================================================================
+template <int L> struct QlCfg {
+    static constexpr int NT = 1024;
+    static constexpr int RING = 512;                           // rotations in flight between the chain and the waves that apply them (ql_tag assumes 512)
+    static constexpr int NCONS = L / 64;                       // applying waves: one row of Z per lane
+    static constexpr int kDoubles = L * L + 6 * L + 64 + 2 * RING;
+    static constexpr size_t kBytes = sizeof(double) * kDoubles + sizeof(int) * (RING + 16);
+};
+template <int L> EIGDEV int ql_at(int r, int c) { return r * L + ((c + r) & (L - 1)); }
+EIGDEV int ql_tag(int seq) { return (((seq >> 9) + 1) & 0xffff) << 12; }                  // (RING = 512 entries per lap)
+// the DPP-selected lane's value (0 where the selection leaves the row or the row is masked): two VALU moves, no LDS crossbar trip
+template <int CTRL, int ROWMASK> EIGDEV double eig_dpp0(double v) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+EIGDEV double eig_lane(double v, int i) {                     // lane i's value in every lane (i wave-uniform): two v_readlane
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i));
+}
+// sum over the 64 lanes, in every lane: inclusive scan inside the rows of 16 (row_shr 1, 2, 4, 8), row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3, lane 63 read back -- ~20 VALU operations instead of six LDS crossbar round trips of ~100 cycles
+EIGDEV double wave_sum(double x) {
+    x += eig_dpp0<0x111, 0xf>(x); x += eig_dpp0<0x112, 0xf>(x); x += eig_dpp0<0x114, 0xf>(x); x += eig_dpp0<0x118, 0xf>(x);
+    x += eig_dpp0<0x142, 0xa>(x); x += eig_dpp0<0x143, 0xc>(x);
+    return eig_lane(x, 63);
+}
+// sum over the 8 lanes of an aligned group of eight, in each of them: xor 1, xor 2 inside the quads (quad_perm), then the other quad of the
+// eight (row_half_mirror: lane i <-> 7 - i)
+EIGDEV double oct_sum(double x) {
+    x += eig_dpp0<0xb1, 0xf>(x);          // quad_perm [1, 0, 3, 2]
+    x += eig_dpp0<0x4e, 0xf>(x);          // quad_perm [2, 3, 0, 1]
+    x += eig_dpp0<0x141, 0xf>(x);         // row_half_mirror
+    return x;
+}
+EIGDEV double wave_max(double x) { for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o)); return x; }
+// a ring entry's tag word: index of the rotation (bits 0-7), first / last of its sweep, end of the stream, and the entry's sequence
+// number divided by the ring size (bits 12-27: which lap of the ring it belongs to) + 1, so that a slot that still holds an older lap --
+// or the zeros the ring starts with -- is told from one that has been written
+constexpr int kQlFirst = 1 << 30, kQlLast = 1 << 29, kQlDoneFlag = 1 << 28, kQlIndex = 0xff, kQlTagMask = 0xffff << 12;
+constexpr int kQlSpinCap = 4000000;                            // polls (tens of cycles each) before a waiting side gives up
+enum { kQlTail0 = 2, kQlTail1 = 3, kQlGaveUp = 4 };
+
+template <int L>
+__global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __restrict__ src, int nslices, int n, int Lw, int k, int zmode, double denom,
+                                                                const int* __restrict__ cholflag, double* __restrict__ Z, double* __restrict__ res,
+                                                                double* __restrict__ Vout) {
+    using C = QlCfg<L>;
+    constexpr int NT = C::NT, RING = C::RING;
+    extern __shared__ double eig_sm[];
+    // (LDS pointers by type: a volatile access through a generic pointer is a FLAT instruction with a full wait behind it -- the first
+    //  form of this kernel spent 1 400 cycles per rotation that way)
+    typedef __attribute__((address_space(3))) double lds_d;
+    typedef __attribute__((address_space(3))) int lds_i;
+    lds_d* A = (lds_d*)eig_sm;                                 // [L x L], element (r, c) at ql_at(r, c); becomes Q, then Z
+    volatile lds_d* dd = A + L * L;                            // diagonal / eigenvalues
+    volatile lds_d* ee = dd + L;                               // ee[i] couples i and i + 1
+    lds_d* vv = A + L * L + 2 * L;                             // the reflector of the step
+    lds_d* pp = vv + L;
+    lds_d* ww = pp + L;
+    lds_d* bb = ww + L;                                        // beta of reflector k
+    lds_d* red = bb + L;                                       // [64] reduction scratch
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2d lds_d2;
+    volatile lds_d2* ringcs = (volatile lds_d2*)(red + 64);    // (c, s) of a rotation
+    volatile lds_i* ringi = (volatile lds_i*)(red + 64 + 2 * RING);
+    volatile lds_i* ctrl = ringi + RING;
+    __shared__ double wsl[128];
+    __shared__ int order[128], genuine[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    EIG_STAMP(0)
+    const int S = nslices > 0 ? nslices : 1;
+    const size_t LL = (size_t)Lw * Lw;
+    for (int e0 = tid; e0 < L * L; e0 += NT) A[e0] = 0.0;
+    if (tid < 16) ctrl[tid] = 0;
+    for (int e0 = tid; e0 < RING; e0 += NT) ringi[e0] = 0;     // (no slot carries a valid tag yet)
+    if (tid < 128) { order[tid] = 0; genuine[tid] = tid < n; }
     __syncthreads();
-    if (rank >= 0 && rank < n) { order[rank] = tid; wsl[rank] = wmine; }       // (wsl re-used: every thread has read what it needs)
-    __syncthreads();
-    for (int j = tid; j < kMaxSketchCols; j += NT) {
-        const double w = j < n ? wsl[j] * unsc : 0.0;
-        res[kEigResW + j] = w;
-        res[kEigResSv + j] = w > 0.0 ? sqrt(w) : 0.0;
-        res[kEigResEig + j] = j < k ? w / denom : 0.0;
-    }
-    if (tid == 0) { res[kEigResFlag] = cholflag ? (double)cholflag[0] : 0.0; res[kEigResFlag + 1] = (double)capped; }
-    for (int e0 = tid; e0 < Lw * k; e0 += NT) {
-        const int r = e0 / k, c = e0 - r * k;
-        double z0 = 0.0, z1 = 0.0;
-        if (r < n && c < n) {
-            const double x = bufV[r * LP + order[c]];
-            if (zmode == 0) {
-                const double w = wsl[c] * unsc;
-                const double sv = w > 0.0 ? sqrt(w) : 0.0;
-                z0 = x * sv; z1 = sv > 0.0 ? x / sv : 0.0;
-            } else { z0 = x; z1 = x; }
+    // fold the slices (slice order), eight of them in flight per element
+    for (int e0 = tid; e0 < n * n; e0 += NT) {
+        const int r = e0 / n, c = e0 - r * n;
+        const double* p0 = src + (size_t)r * Lw + c;
+        double acc = 0.0;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p0[(s0 + u < S ? s0 + u : s0) * LL];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (s0 + u < S) ? v[u] : 0.0;
         }
-        Z[e0] = z0; Z[(size_t)Lw * k + e0] = z1;
+        A[ql_at<L>(r, c)] = acc;
     }
-    EIG_STAMP(4)
-    if (Vout)
-        for (int e0 = tid; e0 < n * n; e0 += NT) { const int r = e0 / n, c = e0 - r * n; Vout[e0] = bufV[r * LP + order[c]]; }
+    __syncthreads();
+    // symmetrise (the upper-triangle thread of a pair writes both), largest finite magnitude, prescale by a power of two
+    double amax = 0.0;
+    for (int e0 = tid; e0 < n * n; e0 += NT) {
+        const int r = e0 / n, c = e0 - r * n;
+        if (r <= c) {
+            const double x = 0.5 * (A[ql_at<L>(r, c)] + A[ql_at<L>(c, r)]);
+            A[ql_at<L>(r, c)] = x; A[ql_at<L>(c, r)] = x;
+            const double ax = fabs(x);
+            amax = (ax > amax && ax < INFINITY) ? ax : amax;
+        }
+    }
+    amax = wave_max(amax);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = 0.0;
+    for (int w = 0; w < NT / 64; ++w) amax = fmax(amax, red[w]);
+    int ex = 0;
+    if (amax > 0.0) (void)frexp(amax, &ex);
+    const double sc = ldexp(1.0, -ex), unsc = ldexp(1.0, ex);
+    for (int e0 = tid; e0 < n * n; e0 += NT) { const int r = e0 / n, c = e0 - r * n; A[ql_at<L>(r, c)] *= sc; }
+    __syncthreads();
+    EIG_STAMP(1)
+    // a row (column) of the active block and an eighth of its elements per thread.  Element (r, c) sits in bank (r + c) mod 32 (8-byte
+    // banks), so the 32 lanes one LDS pass serves take 4 rows x 8 column groups with the columns of a group 4 apart:
+    // r + 4 part + const is a different bank for each of them; a thread's columns are 4 part + a + 32 b, a < 4
+    const int r8 = wave * 8 + ((lane >> 3) & 3) + 4 * (lane >> 5), part = lane & 7;         // (the eight parts of a row in eight adjacent lanes: oct_sum)
+    // ---- tridiagonalisation: reflector kk annihilates column kk below the subdiagonal ----
+    for (int kk = 0; kk + 2 < n; ++kk) {
+        const int m = n - kk - 1;
+        if (wave == 0) {
+            const int t1 = lane + 64;
+            const double x0 = lane < m ? A[ql_at<L>(kk + 1 + lane, kk)] : 0.0, x1 = t1 < m ? A[ql_at<L>(kk + 1 + t1, kk)] : 0.0;
+            const double sig = wave_sum(fma(x0, x0, x1 * x1));
+            const double xf = eig_lane(x0, 0);
+            double alpha = 0.0, beta = 0.0;
+            if (sig > 1e-280 && sig < INFINITY) {              // H = I - beta v v^T, v = x - alpha e_1, H x = alpha e_1 (a column below 1e-140 of the scale is left alone)
+                const double nrm = sig * eig_rsqrt(sig);
+                alpha = xf >= 0.0 ? -nrm : nrm;
+                beta = eig_rcp(sig - alpha * xf);
+            }
+            if (lane < m) vv[lane] = lane == 0 ? x0 - alpha : x0;
+            if (t1 < m) vv[t1] = x1;
+            if (lane == 0) { dd[kk] = A[ql_at<L>(kk, kk)]; ee[kk] = alpha; bb[kk] = beta; }
+        }
+        __syncthreads();
+        const double beta = bb[kk];
+        {   // p = beta A22 v
+            double acc = 0.0;
+            if (r8 < m)
+                for (int b = 0; 32 * b < m; ++b) {             // four loads in flight per trip (a lone dependent LDS read is ~100 cycles)
+                    double av[4], xv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { const int c = 4 * part + a + 32 * b, cc = c < m ? c : 0; av[a] = A[ql_at<L>(kk + 1 + r8, kk + 1 + cc)]; xv[a] = c < m ? vv[cc] : 0.0; }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc = fma(av[a], xv[a], acc);
+                }
+            acc = oct_sum(acc);
+            if (part == 0 && r8 < m) pp[r8] = beta * acc;
+        }
+        __syncthreads();
+        if (wave == 0) {                                       // w = p - (beta / 2) (v^T p) v
+            const int t1 = lane + 64;
+            const double v0 = lane < m ? vv[lane] : 0.0, v1 = t1 < m ? vv[t1] : 0.0, p0 = lane < m ? pp[lane] : 0.0, p1 = t1 < m ? pp[t1] : 0.0;
+            const double kq = 0.5 * beta * wave_sum(fma(v0, p0, v1 * p1));
+            if (lane < m) ww[lane] = fma(-kq, v0, p0);
+            if (t1 < m) ww[t1] = fma(-kq, v1, p1);
+        }
+        __syncthreads();
+        if (r8 < m) {                                          // A22 -= v w^T + w v^T
+            const double vr = vv[r8], wr = ww[r8];
+            for (int b = 0; 32 * b < m; ++b) {
+                double av[4], wv[4], xv[4]; int at[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { const int c = 4 * part + a + 32 * b, cc = c < m ? c : 0; at[a] = ql_at<L>(kk + 1 + r8, kk + 1 + cc); av[a] = A[at[a]]; wv[a] = ww[cc]; xv[a] = vv[cc]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) if (4 * part + a + 32 * b < m) A[at[a]] = fma(-vr, wv[a], fma(-wr, xv[a], av[a]));
+            }
+        }
+        if (tid < m) A[ql_at<L>(kk + 1 + tid, kk)] = vv[tid];  // the reflector stays in its column for the accumulation below
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (n >= 2) { dd[n - 2] = A[ql_at<L>(n - 2, n - 2)]; ee[n - 2] = A[ql_at<L>(n - 1, n - 2)]; }
+        dd[n - 1] = A[ql_at<L>(n - 1, n - 1)]; ee[n - 1] = 0.0;
+    }
+    __syncthreads();
+    // ---- Q = H_0 H_1 ... in place, from the last reflector back: the trailing block holds the product so far ----
+    if (tid < 4 && n >= 2) { const int r = n - 2 + (tid >> 1), c = n - 2 + (tid & 1); A[ql_at<L>(r, c)] = r == c ? 1.0 : 0.0; }
+    if (tid == 0 && n == 1) A[0] = 1.0;
+    __syncthreads();
+    for (int kk = n - 3; kk >= 0; --kk) {
+        const int m = n - kk - 1;
+        const double beta = bb[kk];
+        if (tid < m) vv[tid] = A[ql_at<L>(kk + 1 + tid, kk)];
+        __syncthreads();
+        {   // t = beta v^T Q22  (column r8 of the block, an eighth of its rows per thread)
+            double acc = 0.0;
+            if (r8 < m)
+                for (int b = 0; 32 * b < m; ++b) {
+                    double av[4], xv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { const int r = 4 * part + a + 32 * b, rr = r < m ? r : 0; av[a] = A[ql_at<L>(kk + 1 + rr, kk + 1 + r8)]; xv[a] = r < m ? vv[rr] : 0.0; }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc = fma(xv[a], av[a], acc);
+                }
+            acc = oct_sum(acc);
+            if (part == 0 && r8 < m) pp[r8] = beta * acc;
+        }
+        __syncthreads();
+        if (r8 < m) {                                          // Q22 -= v t
+            const double vr = vv[r8];
+            for (int b = 0; 32 * b < m; ++b) {
+                double av[4], tv[4]; int at[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { const int c = 4 * part + a + 32 * b, cc = c < m ? c : 0; at[a] = ql_at<L>(kk + 1 + r8, kk + 1 + cc); av[a] = A[at[a]]; tv[a] = pp[cc]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) if (4 * part + a + 32 * b < m) A[at[a]] = fma(-vr, tv[a], av[a]);
+            }
+        }
+        if (tid < m) { A[ql_at<L>(kk, kk + 1 + tid)] = 0.0; A[ql_at<L>(kk + 1 + tid, kk)] = 0.0; }
+        if (tid == 0) A[ql_at<L>(kk, kk)] = 1.0;
+        __syncthreads();
+    }
+    EIG_STAMP(2)
+    // ---- implicit QL on (dd, ee); rotations through the ring to the waves that own the rows of Z ----
+    int capped = 0;
+    if (wave == 0) {
+        // The chain.  A lone wave issues an instruction every ~5 cycles whatever it is (scripts/kbench/probe_lat.hip), so a rotation
+        // costs its instruction COUNT: the first forms of this loop (d and e in LDS behind volatile accesses; per-rotation ring checks
+        // and give-up branches on VGPR-held counters) ran 150 instructions = 700-850 cycles per rotation.  Now: d and e in REGISTERS,
+        // entry i in lane i % 64 of register i / 64, read by v_readlane (both registers, a scalar select: no branch), written by a
+        // compare-and-select; loop counters in SGPRs; room in the ring checked once per sweep (a sweep is at most n - 1 < RING
+        // rotations); one 16-byte and one 4-byte LDS store per rotation -- the entry's tag carries its sequence number, there is no
+        // separate head to publish.
+        constexpr int NR = L / 64;
+        const double eps = 2.220446049250313e-16;
+        double dr[NR], er[NR];
+#pragma unroll
+        for (int b2 = 0; b2 < NR; ++b2) { const int i = lane + 64 * b2; dr[b2] = i < n ? (double)dd[i] : 0.0; er[b2] = i < n ? (double)ee[i] : 0.0; }
+        auto getv = [&](const double (&r)[NR], int iu) -> double {          // iu: an SGPR value
+            const double lo = eig_lane(r[0], iu & 63);
+            if (NR == 1) return lo;
+            const double hi = eig_lane(r[NR - 1], iu & 63);
+            return iu < 64 ? lo : hi;
+        };
+        auto setv = [&](double (&r)[NR], int iu, double v) {
+#pragma unroll
+            for (int b2 = 0; b2 < NR; ++b2) r[b2] = (lane + 64 * b2 == iu) ? v : r[b2];
+        };
+        const int nu = __builtin_amdgcn_readfirstlane(n);
+        double f = 0.0, tst1 = 1e-20;
+        int head = 0, tail_seen = 0, iters_all = 0; long long full_spins = 0;
+        bool gave_up = false;
+        for (int l = 0; l < nu && !gave_up; ++l) {
+            tst1 = fmax(tst1, fabs(getv(dr, l)) + fabs(getv(er, l)));
+            auto first_small = [&]() -> int {                  // smallest m >= l with |e[m]| <= eps tst1 (e[n - 1] = 0 ends the search)
+                int mine = nu - 1;
+#pragma unroll
+                for (int b2 = NR - 1; b2 >= 0; --b2) { const int i = lane + 64 * b2; if (i >= l && i < nu && !(fabs(er[b2]) > eps * tst1)) mine = i; }
+                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(mine, o); mine = other < mine ? other : mine; }
+                return __builtin_amdgcn_readfirstlane(mine);
+            };
+            int m = first_small();
+            if (m > l) {
+                int iter = 0;
+                bool more = true;
+                while (more) {
+                    ++iter; ++iters_all;
+                    // room for the whole sweep (bounded wait)
+                    if (head + (m - l) - tail_seen > RING) {
+                        int spins = 0;
+                        for (;;) {
+                            int t = ctrl[kQlTail0];
+                            if (C::NCONS > 1) { const int t1 = ctrl[kQlTail1]; t = t1 < t ? t1 : t; }
+                            tail_seen = __builtin_amdgcn_readfirstlane(t);
+                            if (head + (m - l) - tail_seen <= RING) break;
+                            ++full_spins;
+                            if (++spins > kQlSpinCap) { gave_up = true; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        if (gave_up) break;
+                    }
+                    double g = getv(dr, l);
+                    const double el = getv(er, l);
+                    double p = (getv(dr, l + 1) - g) / (2.0 * el);
+                    double r = sqrt(fma(p, p, 1.0));
+                    if (p < 0.0) r = -r;
+                    const double dl = el / (p + r), dl1 = el * (p + r);
+                    double h = g - dl;
+#pragma unroll
+                    for (int b2 = 0; b2 < NR; ++b2) { const int i = lane + 64 * b2; dr[b2] = i == l ? dl : (i == l + 1 ? dl1 : (i >= l + 2 && i < nu ? dr[b2] - h : dr[b2])); }
+                    f += h;
+                    p = getv(dr, m);
+                    double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+                    const double el1 = getv(er, l + 1);
+                    double e_i = getv(er, m - 1), d_i = getv(dr, m - 1);
+                    for (int i = m - 1; i >= l; --i) {
+                        const int ip = i > l ? i - 1 : i;
+                        const double e_nx = getv(er, ip), d_nx = getv(dr, ip);        // one rotation ahead
+                        c3 = c2; c2 = c; s2 = s;
+                        g = c * e_i; h = c * p;
+                        const double q2 = fma(p, p, e_i * e_i);
+                        const double rinv = eig_rsqrt(q2);
+                        r = q2 * rinv;
+                        const double s_old = s;
+                        s = e_i * rinv; c = p * rinv;
+                        p = fma(c, d_i, -(s * g));
+                        setv(er, i + 1, s_old * r); setv(dr, i + 1, fma(s, fma(c, g, s * d_i), h));
+                        if (lane == 0) {
+                            const int slot = head & (RING - 1);
+                            ringcs[slot] = v2d{c, s};
+                            ringi[slot] = i | (i == m - 1 ? kQlFirst : 0) | (i == l ? kQlLast : 0) | ql_tag(head);
+                        }
+                        ++head;
+                        e_i = e_nx; d_i = d_nx;
+                    }
+                    p = -s * s2 * c3 * el1 * getv(er, l) / dl1;
+                    setv(er, l, s * p); setv(dr, l, c * p);
+                    more = fabs(s * p) > eps * tst1;
+                    if (more && iter >= 60) { capped = 1; more = false; }
+                    if (more) m = first_small();               // (the block may have split during the sweep)
+                    if (more && m == l) more = false;
+                }
+            }
+            setv(dr, l, getv(dr, l) + f); setv(er, l, 0.0);
+        }
+        if (gave_up) capped = 1;
+#pragma unroll
+        for (int b2 = 0; b2 < NR; ++b2) { const int i = lane + 64 * b2; if (i < n) dd[i] = dr[b2]; }
+#if GPCA_EIG_STAMP
+        if (lane == 0) { g_eig_stamp[10] = (unsigned long long)iters_all; g_eig_stamp[11] = (unsigned long long)head; g_eig_stamp[12] = (unsigned long long)full_spins; }
+#endif
+        (void)iters_all; (void)full_spins;
+        // the end of the stream: an entry with the Done flag (the ring has room for it: wait like a sweep of one)
+        if (lane == 0) {
+            int spins = 0;
+            while (head + 1 - (C::NCONS > 1 ? (ctrl[kQlTail1] < ctrl[kQlTail0] ? ctrl[kQlTail1] : ctrl[kQlTail0]) : ctrl[kQlTail0]) > RING && ++spins < kQlSpinCap) __builtin_amdgcn_s_sleep(2);
+            const int slot = head & (RING - 1);
+            ringcs[slot] = v2d{0.0, 0.0};
+            ringi[slot] = kQlDoneFlag | ql_tag(head);
+            if (capped) ctrl[kQlGaveUp] = 1;
+        }
+    } else if (wave <= C::NCONS) {
+        const int row = (wave - 1) * 64 + lane;
+        const bool live = row < n;
+        lds_d* zr = A + row * L;                               // element c of the row at (c + row) & (L - 1)
+        int tail = 0, spins = 0;
+        long long batches = 0, empty_polls = 0;
+        double carry = 0.0;
+        bool finished = false;
+        while (!finished) {
+            // how many entries from `tail` on carry the tag of their sequence number?  (up to four; a wave's LDS stores land in order:
+            // a tag that is there has its c and s behind it)
+            int ii[4], navail = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ii[j] = ringi[(tail + j) & (RING - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (navail == j && (ii[j] & kQlTagMask) == ql_tag(tail + j)) navail = j + 1;
+            if (navail == 0) {
+                if (++spins > kQlSpinCap) { ctrl[kQlGaveUp] = 1; break; }
+                ++empty_polls;
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            spins = 0;
+            int len = navail;
+#pragma unroll
+            for (int j = 3; j >= 1; --j) if (j < len && (ii[j] & (kQlFirst | kQlDoneFlag))) len = j;     // a new sweep (or the end) starts a new batch
+            if (ii[0] & kQlDoneFlag) { finished = true; break; }
+            v2d cs[4]; double lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = ringcs[(tail + (j < len ? j : 0)) & (RING - 1)];
+            if (live) {
+                const int i0 = ii[0] & kQlIndex;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lo[j] = zr[((ii[j < len ? j : 0] & kQlIndex) + row) & (L - 1)];
+                double hi = (ii[0] & kQlFirst) ? (double)zr[(i0 + 1 + row) & (L - 1)] : carry;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < len) {
+                        const int i = ii[j] & kQlIndex;
+                        zr[(i + 1 + row) & (L - 1)] = fma(cs[j].y, lo[j], cs[j].x * hi);
+                        hi = fma(cs[j].x, lo[j], -(cs[j].y * hi));
+                        if (ii[j] & kQlLast) zr[(i + row) & (L - 1)] = hi;
+                    }
+                carry = hi;
+            }
+            tail += len; ++batches;
+            if ((tail & 63) < len && lane == 0) ctrl[kQlTail0 + wave - 1] = tail;          // (the chain looks at it once per sweep: every 64 entries is often enough)
+        }
+#if GPCA_EIG_STAMP
+        if (wave == 1 && lane == 0) { g_eig_stamp[13] = (unsigned long long)batches; g_eig_stamp[14] = (unsigned long long)empty_polls; }
+#endif
+        (void)batches; (void)empty_polls;
+    }
+    __syncthreads();
+    capped = ctrl[kQlGaveUp] != 0 || (wave == 0 && capped);
+    if (wave == 0 && lane == 0 && capped) ctrl[kQlGaveUp] = 1;
+    __syncthreads();
+    capped = ctrl[kQlGaveUp];
+    EIG_STAMP(3)
+    if (tid < 128) wsl[tid] = tid < n ? dd[tid] : 0.0;
+    __syncthreads();
+    eig_emit<NT>([&](int r, int slot) { return A[ql_at<L>(r, slot)]; }, wsl, order, genuine, L, n, Lw, k, zmode, denom, unsc, cholflag, capped, Z, res, Vout, tid);
 }
 
 template <int L> static size_t small_eigh_lds() { return sizeof(double) * (size_t)L * JacCfg<L>::LP * JacCfg<L>::NBUF; }
+#ifndef GPCA_EIG_QL
+#define GPCA_EIG_QL 1           // 1: sketches of 65-128 columns by tridiagonalisation + QL (k_small_eigh_ql), the rest by Jacobi; harness A/B: 0 = Jacobi
+#endif                          // everywhere, 2 = QL from 33 columns
 int init_device_kernels_eig() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds<128>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh_ql<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)QlCfg<128>::kBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh_ql<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)QlCfg<64>::kBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds<64>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_eigh<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_eigh_lds<32>());
     return (int)e;
@@ -330,6 +760,8 @@ int init_device_kernels_eig() {
 void launch_small_eigh(hipStream_t st, const double* src, int nslices, int n, int L, int k, int zmode, double denom, const int* cholflag,
                        double* Z, double* res, double* Vout) {
     if (n <= 32) hipLaunchKernelGGL(k_small_eigh<32>, dim3(1), dim3(JacCfg<32>::NT), small_eigh_lds<32>(), st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
+    else if (GPCA_EIG_QL == 2 && n <= 64) hipLaunchKernelGGL(k_small_eigh_ql<64>, dim3(1), dim3(QlCfg<64>::NT), QlCfg<64>::kBytes, st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
+    else if (GPCA_EIG_QL && n > 64) hipLaunchKernelGGL(k_small_eigh_ql<128>, dim3(1), dim3(QlCfg<128>::NT), QlCfg<128>::kBytes, st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
     else if (n <= 64) hipLaunchKernelGGL(k_small_eigh<64>, dim3(1), dim3(JacCfg<64>::NT), small_eigh_lds<64>(), st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
     else hipLaunchKernelGGL(k_small_eigh<128>, dim3(1), dim3(JacCfg<128>::NT), small_eigh_lds<128>(), st, src, nslices, n, L, k, zmode, denom, cholflag, Z, res, Vout);
 }

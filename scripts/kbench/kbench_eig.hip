@@ -37,13 +37,16 @@ static int run(int n, int k, int slices) {
         resid = std::fmax(resid, std::fabs(av - V[(size_t)i * n + c] * R[gpca::kEigResW + c]));
         orth = std::fmax(orth, std::fabs(vv - (i == c ? 1.0 : 0.0)));
     }
-    unsigned long long sp[16];
+    unsigned long long sp[20];
     CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_eig_stamp), sizeof sp));
     auto us = [&](int a, int b) { return (double)(sp[2 * b] - sp[2 * a]) * 0.01; };
     const double ghz = (double)(sp[2 * 4 + 1] - sp[1]) / ((double)(sp[2 * 4] - sp[0]) * 10.0);
     printf("k_small_eigh n = %3d (L = %3d, %2d slices): %.1f us per launch back to back | stamps: fold %.1f, sweeps %.1f, sort+out %.1f us, shader clock %.2f GHz, %llu Jacobi sweeps, %llu steps = %.0f cycles each | "
            "w0 = %.6e, residual / w0 = %.1e, |V^T V - I| = %.1e, cap flag %.0f\n", n, L, slices, ms / 50 * 1e3,
            us(0, 1), us(1, 3), us(3, 4), ghz, sp[10], sp[11], (double)(sp[2 * 3 + 1] - sp[2 * 1 + 1]) / (double)(sp[11] ? sp[11] : 1), R[gpca::kEigResW], resid / R[gpca::kEigResW], orth, R[gpca::kEigResFlag + 1]);
+    if (n > 32 && sp[2 * 2] > sp[2 * 1] && sp[2 * 2] < sp[2 * 3])      // the QL form stamps the end of its tridiagonalisation
+        printf("    (tridiagonalisation + accumulation of Q %.1f us, QL chain with its rotations applied %.1f us = %.0f cycles per rotation; chain waited for ring room %llu polls; applying wave: %llu batches, %llu empty polls)\n",
+               us(1, 2), us(2, 3), (double)(sp[2 * 3 + 1] - sp[2 * 2 + 1]) / (double)(sp[11] ? sp[11] : 1), sp[12], sp[13], sp[14]);
     hipFree(dW); hipFree(dZ); hipFree(dR); hipFree(dV);
     return 0;
 }
