@@ -29,7 +29,7 @@
 // more flops and keeps four to sixteen waves busy: 117 us at n = 30 (203 steps of ~1 200 cycles: the rotation chain ~550, the LDS
 // exchange and its barrier the rest), 0.8 ms at n = 64; at n = 128 the exchange is LDS-bandwidth bound (6.3 ms), and sketches of
 // 65-128 columns go through k_small_eigh_ql below: QL again, but with its serial chain on one wave and the eigenvector updates on
-// two others (4.6 ms).
+// two others (4.0 ms).
 #include "kernels.h"
 
 #ifndef GPCA_EIG_ABL
@@ -335,9 +335,9 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
 // ================================================================================================
 // Sketches of 65 .. 128 columns: Householder tridiagonalisation + implicit QL (the pair the host pin runs), arranged for one workgroup.
 // The Jacobi form above moves the whole matrix through LDS every step: 0.57 / 0.79 ms at n = 50 / 64, 5.0 / 6.3 ms at n = 100 / 128
-// (LDS-bandwidth bound).  This form: 0.60 / 0.93 ms at n = 50 / 64 (so Jacobi keeps L = 64), **2.8 / 4.6 ms at n = 100 / 128**
+// (LDS-bandwidth bound).  This form: 0.62 / 0.95 ms at n = 50 / 64 (so Jacobi keeps L = 64), **2.45 / 4.0 ms at n = 100 / 128**
 // (scripts/kbench/kbench_eig.hip, profiles/r5_kbench_summary.md section 1): 0.34 / 0.53 ms of tridiagonalisation + Q, the rest the
-// serial chain at ~530 cycles per rotation (10 753 / 18 074 rotations).
+// serial chain at ~460 cycles per rotation (10 753 / 18 074 rotations).
 //   * tridiagonalisation and the accumulation of Q: n - 2 reflectors, each a matrix-vector product and a rank-2 (rank-1) update
 //     spread over all 1 024 threads, four (three) barriers per reflector; the matrix sits in LDS with row r rotated by r places
 //     (ql_at), so rows and columns are both conflict-free without padding (128 x 128 doubles = 128 KiB of the 160);
@@ -567,37 +567,23 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
     int capped = 0;
     if (wave == 0) {
         // The chain.  A lone wave issues an instruction every ~5 cycles whatever it is (scripts/kbench/probe_lat.hip), so a rotation
-        // costs its instruction COUNT: the first forms of this loop (d and e in LDS behind volatile accesses; per-rotation ring checks
-        // and give-up branches on VGPR-held counters) ran 150 instructions = 700-850 cycles per rotation.  Now: d and e in REGISTERS,
-        // entry i in lane i % 64 of register i / 64, read by v_readlane (both registers, a scalar select: no branch), written by a
-        // compare-and-select; loop counters in SGPRs; room in the ring checked once per sweep (a sweep is at most n - 1 < RING
-        // rotations); one 16-byte and one 4-byte LDS store per rotation -- the entry's tag carries its sequence number, there is no
-        // separate head to publish.
-        constexpr int NR = L / 64;
+        // costs its instruction COUNT (profiles/r5_kbench_summary.md section 1 has the forms that were tried).  d and e in LDS through
+        // LDS-typed plain pointers, the next rotation's entries fetched one rotation ahead; loop counters in SGPRs; room in the ring
+        // checked once per sweep (a sweep is at most n - 1 < RING rotations); four stores of lane 0 per rotation -- the entry's tag
+        // carries its sequence number, there is no separate head to publish.
         const double eps = 2.220446049250313e-16;
-        double dr[NR], er[NR];
-#pragma unroll
-        for (int b2 = 0; b2 < NR; ++b2) { const int i = lane + 64 * b2; dr[b2] = i < n ? (double)dd[i] : 0.0; er[b2] = i < n ? (double)ee[i] : 0.0; }
-        auto getv = [&](const double (&r)[NR], int iu) -> double {          // iu: an SGPR value
-            const double lo = eig_lane(r[0], iu & 63);
-            if (NR == 1) return lo;
-            const double hi = eig_lane(r[NR - 1], iu & 63);
-            return iu < 64 ? lo : hi;
-        };
-        auto setv = [&](double (&r)[NR], int iu, double v) {
-#pragma unroll
-            for (int b2 = 0; b2 < NR; ++b2) r[b2] = (lane + 64 * b2 == iu) ? v : r[b2];
-        };
+        lds_d* dp = (lds_d*)dd; lds_d* ep = (lds_d*)ee;          // (this wave is the only one that touches d and e from here on)
         const int nu = __builtin_amdgcn_readfirstlane(n);
         double f = 0.0, tst1 = 1e-20;
         int head = 0, tail_seen = 0, iters_all = 0; long long full_spins = 0;
         bool gave_up = false;
         for (int l = 0; l < nu && !gave_up; ++l) {
-            tst1 = fmax(tst1, fabs(getv(dr, l)) + fabs(getv(er, l)));
+            tst1 = fmax(tst1, fabs(dp[l]) + fabs(ep[l]));
             auto first_small = [&]() -> int {                  // smallest m >= l with |e[m]| <= eps tst1 (e[n - 1] = 0 ends the search)
                 int mine = nu - 1;
-#pragma unroll
-                for (int b2 = NR - 1; b2 >= 0; --b2) { const int i = lane + 64 * b2; if (i >= l && i < nu && !(fabs(er[b2]) > eps * tst1)) mine = i; }
+                const int i0 = l + lane, i1 = i0 + 64;
+                if (i1 < nu && !(fabs(ep[i1]) > eps * tst1)) mine = i1;
+                if (i0 < nu && !(fabs(ep[i0]) > eps * tst1)) mine = i0;
                 for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(mine, o); mine = other < mine ? other : mine; }
                 return __builtin_amdgcn_readfirstlane(mine);
             };
@@ -621,23 +607,24 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                         }
                         if (gave_up) break;
                     }
-                    double g = getv(dr, l);
-                    const double el = getv(er, l);
-                    double p = (getv(dr, l + 1) - g) / (2.0 * el);
+                    double g = dp[l];
+                    const double el = ep[l];
+                    double p = (dp[l + 1] - g) / (2.0 * el);
                     double r = sqrt(fma(p, p, 1.0));
                     if (p < 0.0) r = -r;
                     const double dl = el / (p + r), dl1 = el * (p + r);
                     double h = g - dl;
-#pragma unroll
-                    for (int b2 = 0; b2 < NR; ++b2) { const int i = lane + 64 * b2; dr[b2] = i == l ? dl : (i == l + 1 ? dl1 : (i >= l + 2 && i < nu ? dr[b2] - h : dr[b2])); }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = l + lane; i < nu; i += 64) { const double x = dp[i]; dp[i] = i == l ? dl : (i == l + 1 ? dl1 : x - h); }
+                    __builtin_amdgcn_wave_barrier();
                     f += h;
-                    p = getv(dr, m);
+                    p = dp[m];
                     double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
-                    const double el1 = getv(er, l + 1);
-                    double e_i = getv(er, m - 1), d_i = getv(dr, m - 1);
+                    const double el1 = ep[l + 1];
+                    double e_i = ep[m - 1], d_i = dp[m - 1];
                     for (int i = m - 1; i >= l; --i) {
                         const int ip = i > l ? i - 1 : i;
-                        const double e_nx = getv(er, ip), d_nx = getv(dr, ip);        // one rotation ahead
+                        const double e_nx = ep[ip], d_nx = dp[ip];               // one rotation ahead
                         c3 = c2; c2 = c; s2 = s;
                         g = c * e_i; h = c * p;
                         const double q2 = fma(p, p, e_i * e_i);
@@ -646,28 +633,30 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                         const double s_old = s;
                         s = e_i * rinv; c = p * rinv;
                         p = fma(c, d_i, -(s * g));
-                        setv(er, i + 1, s_old * r); setv(dr, i + 1, fma(s, fma(c, g, s * d_i), h));
                         if (lane == 0) {
                             const int slot = head & (RING - 1);
+                            ep[i + 1] = s_old * r; dp[i + 1] = fma(s, fma(c, g, s * d_i), h);
                             ringcs[slot] = v2d{c, s};
                             ringi[slot] = i | (i == m - 1 ? kQlFirst : 0) | (i == l ? kQlLast : 0) | ql_tag(head);
                         }
                         ++head;
                         e_i = e_nx; d_i = d_nx;
                     }
-                    p = -s * s2 * c3 * el1 * getv(er, l) / dl1;
-                    setv(er, l, s * p); setv(dr, l, c * p);
+                    p = -s * s2 * c3 * el1 * ep[l] / dl1;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { ep[l] = s * p; dp[l] = c * p; }
+                    __builtin_amdgcn_wave_barrier();
                     more = fabs(s * p) > eps * tst1;
                     if (more && iter >= 60) { capped = 1; more = false; }
                     if (more) m = first_small();               // (the block may have split during the sweep)
                     if (more && m == l) more = false;
                 }
             }
-            setv(dr, l, getv(dr, l) + f); setv(er, l, 0.0);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { dp[l] = dp[l] + f; ep[l] = 0.0; }
+            __builtin_amdgcn_wave_barrier();
         }
         if (gave_up) capped = 1;
-#pragma unroll
-        for (int b2 = 0; b2 < NR; ++b2) { const int i = lane + 64 * b2; if (i < n) dd[i] = dr[b2]; }
 #if GPCA_EIG_STAMP
         if (lane == 0) { g_eig_stamp[10] = (unsigned long long)iters_all; g_eig_stamp[11] = (unsigned long long)head; g_eig_stamp[12] = (unsigned long long)full_spins; }
 #endif
