@@ -466,7 +466,7 @@ def streamed_main(a, g, rank, world, local_rank, rdzv):
     if rdzv is not None:
         def uid_fn(eng):
             connect(g, a, eng, rdzv, rank, world, snp_offset)
-    dt, tim, ev, t_stats = streamed_run(g, a, M_local, N, k, a.storage, local_rank, snp_offset, rdzv, uid_fn, cache_gb=a.cache_gb)
+    dt, tim, ev, t_stats = streamed_run(g, a, M_local, N, k, a.storage, local_rank, snp_offset, rdzv, uid_fn, cache_gb=a.cache_gb, bench_hold=a.bench_hold)
     n_cached = tim.pop("_panels_cached")
     mem = tim.pop("_memory", None)
     rank_info = tim.pop("_ranks", None)
@@ -561,6 +561,9 @@ def main():
     ap.add_argument("--cache-gb", type=float, default=-1.0,
                     help="--streamed: GiB of spare HBM that keep the leading panels resident (gpca_stream_set_cache); -1 = what is free, 0 = none")
     ap.add_argument("--unfused", action="store_true", help="--streamed: 6 passes per call (bit-identical to the resident engine) instead of 4")
+    ap.add_argument("--bench-hold", action="store_true",
+                    help="--streamed, MEASUREMENT ONLY (GPCA_SOURCE_BENCH_HOLD): buffers keep the panel they were given first, nothing is regenerated; "
+                         "the engine's own rate on streamed panels, meaningless eigenvalues")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="N > 1: rccl = ncclAllReduce on the engine's stream inside libgpca.so (the product path); host = the host-staged hook over the "
                          "launcher's hub, a rehearsal of everything but RCCL for boxes with fewer GPUs than ranks")
@@ -789,8 +792,9 @@ def main():
                 "engine_rate_with_fills_hidden": {
                     "definition": "the same call, same ring and HBM panel cache, with GPCA_SOURCE_BENCH_HOLD: no panel is generated in the timed call "
                                   "(every buffer keeps the panel it was given first; the eigenvalues mean nothing): the engine's own rate on streamed "
-                                  "panels of this shape.  Beside it, `gemm_share_of_step` of the real line: the part of the real step that is GEMM "
-                                  "kernel time -- near 1, the fills are hidden behind the sweeps and the generator is not what bounds the line",
+                                  "panels of this shape.  The real line above shares the GPU with the synthetic generator (136 fills x ~24 ms of its "
+                                  "kernels per step), which slows every GEMM launch beside it: that line is a lower bound on the engine, this one is "
+                                  "what a source that costs the GPU nothing (host link, disk) would see",
                     "ms_per_step": dt5h * 1e3, "value": M5 * N5 / dt5h, "unit": "SNPs*samples/s",
                     "gemm_sweeps_ms_per_step": hidden["gemm_sweeps_ms_per_step"],
                     "hbm_GBs_per_sweep_algorithmic": hidden["hbm_GBs_per_sweep_algorithmic"]},
@@ -798,7 +802,6 @@ def main():
                             "resident), k = 40, l = 50, panels of 131 072 rows from the device generator (GPCA_PANEL_SYNTH16) through a ring of 3",
                 "snps": M5, "samples": N5, "k": k5, "steps": 1, "warmup": 0, "ms_per_step": dt5 * 1e3, "value": M5 * N5 / dt5,
                 "unit": "SNPs*samples/s", "snp_stats_s": t_stats5, "panels_cached_in_hbm": n_cached5,
-                "gemm_share_of_step": streamed_summary(tim5, 1, M5, N5, k5 + a.oversample, "2bit")["gemm_sweeps_ms_per_step"] / (dt5 * 1e3),
                 "streaming": streamed_summary(tim5, 1, M5, N5, k5 + a.oversample, "2bit"),
                 "top_eigenvalues": [float(x) for x in ev5[:3]],
                 "properties": {"eigenvalues_descending": bool(np.all(np.diff(ev5) <= 0)), "structured_eigenvalues_found": int(np.sum(ev5 > 20 * ev5[-1])),

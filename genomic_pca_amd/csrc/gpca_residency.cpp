@@ -468,7 +468,13 @@ extern "C" int gpca_stream_open(gpca_handle* h, const gpca_panel_source* src, in
     sm.panel_rows = panel_rows;
     sm.n_panels = (int)((M + panel_rows - 1) / panel_rows);
     sm.ring = ring_slots; sm.seq = 0; sm.fused = 1;
-    HIPCHK(hipStreamCreateWithFlags(&sm.st_fill, hipStreamNonBlocking));
+    {   // The stream that produces panels runs at the LOWEST priority the device offers: a device generator launches grids that fill the
+        // chip for ~20 ms at a time, and behind them the pass's small kernels (a panel's column scales between its K1 and its K2: 0.13 ms of
+        // work) waited ~4 ms each for a wave slot -- 1.5 s of a 5.9 s configs[4] step (profiles/r5_kbench_summary.md section 6).
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        HIPCHK(hipStreamCreateWithPriority(&sm.st_fill, hipStreamNonBlocking, lo));      // (lo = numerically greatest = least urgent)
+    }
     sm.on = true;   // from here on stream_close() releases whatever was set up
     int rc = GPCA_OK;
     for (int i = 0; i < ring_slots && rc == GPCA_OK; ++i) {

@@ -89,7 +89,7 @@ class PanelSource:
         if self.mapped is not None:
             st.user = self.mapped.ctypes.data_as(C.c_void_p)
             st.host_ld = self.mapped.strides[0]
-            st.flags = self.flags
+        st.flags = self.flags
         return st
 
     @staticmethod

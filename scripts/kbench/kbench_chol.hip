@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256) void k_chol_inv_any_old(const double* __restri
 }  // namespace gpca
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 template <int NN>
-static int run() {
+static int run(double scale = 1.0) {
     std::vector<double> A(NN * NN), W(NN * NN, 0.0);
     unsigned x = 12345u;
     for (auto& a : A) { x = x * 1664525u + 1013904223u; a = ((x >> 8) & 0xffff) / 65536.0 - 0.5; }
-    for (int i = 0; i < NN; ++i) for (int j = 0; j < NN; ++j) { double s = (i == j) ? 0.5 : 0.0; for (int k = 0; k < NN; ++k) s += A[k * NN + i] * A[k * NN + j]; W[i * NN + j] = s; }
+    for (int i = 0; i < NN; ++i) for (int j = 0; j < NN; ++j) { double s = (i == j) ? 0.5 : 0.0; for (int k = 0; k < NN; ++k) s += A[k * NN + i] * A[k * NN + j]; W[i * NN + j] = s * scale; }
+    if (scale != 1.0) printf("(matrix scaled by %.1e) ", scale);
     double *dW, *dZ0, *dZ1; int* flag;
     CK(hipMalloc(&dW, NN * NN * 8)); CK(hipMalloc(&dZ0, NN * NN * 8)); CK(hipMalloc(&dZ1, NN * NN * 8)); CK(hipMalloc(&flag, 4)); CK(hipMemset(flag, 0, 4));
     CK(hipMemcpy(dW, W.data(), NN * NN * 8, hipMemcpyHostToDevice));
@@ -200,4 +201,4 @@ static int run_wide(int n) {
            n, t[0] / 3, t[1] / 3, memcmp(Z0.data(), Z1.data(), L * L * 8) == 0 ? "bit-identical" : "DIFFER", zero_rows);
     return 0;
 }
-int main() { return run<32>() || run<64>() || run_wide(70) || run_wide(100) || run_wide(128); }
+int main() { return run<32>() || run<64>() || run<64>(1e23) || run<64>(1e-23) || run_wide(70) || run_wide(100) || run_wide(128); }
