@@ -365,7 +365,15 @@ int filler_fill(gpca_handle* h, Filler& f, int64_t row0, int64_t rows, void* dst
                 if (it != f.held.end() && it->second == rows) return GPCA_OK;
                 f.held[dst] = rows;
             }
-            launch_synth16(st, dst, packed ? 1 : 0, rows, h->N, packed ? h->ld2 : h->ld8, s.snp_offset + row0, s.seed, f.d_thresh + (size_t)row0 * s.n_pop, s.n_pop);
+            // In launches of 8 192 rows: one grid over a whole panel keeps the dispatcher busy for ~24 ms at 500k samples, and a small kernel
+            // of the pass that becomes ready meanwhile (a panel's column scales between its K1 and its K2) waited for it -- 3.9 ms on
+            // average, 1.5 s of a configs[4] step (profiles/r5_kbench_summary.md section 6).
+            for (int64_t r0 = 0; r0 < rows; r0 += 8192) {
+                const int64_t nr = std::min<int64_t>(8192, rows - r0);
+                const size_t pitch = (size_t)(packed ? h->ld2 : h->ld8);
+                launch_synth16(st, (char*)dst + (size_t)r0 * pitch, packed ? 1 : 0, nr, h->N, packed ? h->ld2 : h->ld8, s.snp_offset + row0 + r0, s.seed,
+                               f.d_thresh + (size_t)(row0 + r0) * s.n_pop, s.n_pop);
+            }
             HIPCHK(hipGetLastError());
             return GPCA_OK;
         case GPCA_PANEL_HOST_I8: case GPCA_PANEL_HOST_BED: case GPCA_PANEL_MAPPED_I8: case GPCA_PANEL_MAPPED_BED: {
