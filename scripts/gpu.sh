@@ -13,6 +13,11 @@
 #   kbench=<name>[,args]             hipcc scripts/kbench/<name>.hip and run it   -> gpurun_out/kbench_<name>_<tag>.log
 #   py=<script.py>[,args]            python <script> args                         -> gpurun_out/py_<tag>.log (appended)
 #   sh=<script.sh>[,args]            bash <script> args                           -> gpurun_out/sh_<tag>.log (appended)
+#        scripts/stats_of.sh,<bench.py args>            rocprofv3 per-kernel totals of one bench.py command line
+#        scripts/trace_around.sh,<pattern> <args>       the launches around every kernel whose name holds <pattern>
+#        scripts/config5_who_bounds.sh                  configs[4]'s streamed shard with and without the panel generator
+#        scripts/kbench/sweep_gqd_short.sh              int8 K1 on short sample axes, k_gq_d against the skewed-round experiment
+#        scripts/kbench/eig_ablate.sh                   the Jacobi eigensolver's ablations
 tag=$1; shift
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
