@@ -41,8 +41,10 @@
 #if GPCA_EIG_STAMP
 __device__ unsigned long long g_eig_stamp[20];      // [2 s]: s_memrealtime (100 MHz), [2 s + 1]: s_memtime (shader clock) at stamp s; [10] sweeps, [11] steps
 #define EIG_STAMP(SLOT) { if (threadIdx.x == 0) { g_eig_stamp[2 * (SLOT)] = __builtin_amdgcn_s_memrealtime(); g_eig_stamp[2 * (SLOT) + 1] = __builtin_amdgcn_s_memtime(); } }
+#define EIG_COUNT(X) (++(X))            // harness counters of the QL form: iterations, polls, batches
 #else
 #define EIG_STAMP(SLOT)
+#define EIG_COUNT(X) ((void)(X))
 #endif
 
 namespace gpca {
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                 int iter = 0;
                 bool more = true;
                 while (more) {
-                    ++iter; ++iters_all;
+                    ++iter; EIG_COUNT(iters_all);
                     // room for the whole sweep (bounded wait)
                     if (head + (m - l) - tail_seen > RING) {
                         int spins = 0;
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                             if (C::NCONS > 1) { const int t1 = ctrl[kQlTail1]; t = t1 < t ? t1 : t; }
                             tail_seen = __builtin_amdgcn_readfirstlane(t);
                             if (head + (m - l) - tail_seen <= RING) break;
-                            ++full_spins;
+                            EIG_COUNT(full_spins);
                             if (++spins > kQlSpinCap) { gave_up = true; break; }
                             __builtin_amdgcn_s_sleep(2);
                         }
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
             for (int j = 0; j < 4; ++j) if (navail == j && (ii[j] & kQlTagMask) == ql_tag(tail + j)) navail = j + 1;
             if (navail == 0) {
                 if (++spins > kQlSpinCap) { ctrl[kQlGaveUp] = 1; break; }
-                ++empty_polls;
+                EIG_COUNT(empty_polls);
                 __builtin_amdgcn_s_sleep(1);
                 continue;
             }
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                     }
                 carry = hi;
             }
-            tail += len; ++batches;
+            tail += len; EIG_COUNT(batches);
             if ((tail & 63) < len && lane == 0) ctrl[kQlTail0 + wave - 1] = tail;          // (the chain looks at it once per sweep: every 64 entries is often enough)
         }
 #if GPCA_EIG_STAMP
