@@ -241,12 +241,13 @@ GPCA_API int gpca_get_snp_qc_detail(gpca_handle* h, uint32_t* counts, uint8_t* r
 GPCA_API int gpca_set_standardization(gpca_handle* h, const float* mu, const float* sigma, const uint8_t* keep);
 /* Current parameters, length M each (any may be NULL): what gpca_snp_stats computed or gpca_set_standardization set. */
 GPCA_API int gpca_get_standardization(gpca_handle* h, float* mu, float* sigma, uint8_t* keep);
-/* Host helper (no GPU): the symmetric eigen-solver gpca_rsvd uses for its l x l host step (Householder tridiagonalisation +
- * implicit QL), exposed so that CPU-only tests can pin it against LAPACK.  a_sym: n x n row-major (n <= 128); w: eigenvalues
- * descending; v: eigenvectors in columns, row-major. */
+/* Host helper (no GPU): a symmetric eigen-solver (Householder tridiagonalisation + implicit QL) -- what gpca_rsvd ran for its l x l
+ * step on the host up to round 4, kept as the pin of the device solver: CPU-only tests hold it to LAPACK, GPU tests hold the device
+ * solver to it.  a_sym: n x n row-major (n <= 128); w: eigenvalues descending; v: eigenvectors in columns, row-major. */
 GPCA_API int gpca_host_eigh_desc(const double* a_sym, int32_t n, double* w, double* v);
-/* Test hook (GPU): the DEVICE eigen-solver gpca_rsvd runs for its l x l step (csrc/small_eig.hip: the same tridiagonalisation + implicit
- * QL pair on one or two waves, the call's stream never waits for the host), on a caller's matrix; same conventions as above. */
+/* Test hook (GPU): the DEVICE eigen-solver gpca_rsvd runs for its l x l step (csrc/small_eig.hip: cyclic two-sided Jacobi in LDS up to
+ * 64 columns, tridiagonalisation + QL split over waves for 65-128; the call's stream never waits for the host), on a caller's matrix;
+ * same conventions as above. */
 GPCA_API int gpca_device_eigh_desc(gpca_handle* h, const double* a_sym, int32_t n, double* w, double* v);
 /* Host helper, same branches as prepare.rs:1641-1745. */
 GPCA_API double gpca_hwe_chi_squared_p_value(uint64_t n_hom1, uint64_t n_het, uint64_t n_hom2);
