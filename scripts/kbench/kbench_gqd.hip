@@ -6,6 +6,7 @@
 #endif
 #include "../../genomic_pca_amd/csrc/gemm_i8.hip"
 #include "gqs_skew.inc"
+#include "gqt_drip.inc"
 #include <algorithm>
 #include <cstdio>
 #include <string>
@@ -45,6 +46,7 @@ static int ab_main(int argc, char** argv) {
     std::vector<gpca::KernelOpts> kos;
     std::vector<int> skews;
     auto go = [&](size_t c_) -> int {
+        if (skews[c_] == 100) return gpca::launch_gq_t(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[c_].gq_phase);
         if (skews[c_]) return gpca::launch_gq_s(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[c_].gq_phase, skews[c_] - 1);
         return gpca::launch_gq_d(0, G, ld8, plan, Npad, Qd, qs, r, b, s, T, cp, ap, 1, 32, kos[c_]);
     };
