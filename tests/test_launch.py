@@ -223,11 +223,13 @@ def test_weak_scaling_record_is_self_consistent():
 
 @pytest.mark.timeout(300)
 @pytest.mark.skipif(gpu_present(), reason="the GPU-less behaviour: on a GPU box the ranks would run")
-@pytest.mark.parametrize("how", ["plain", "torchrun"])
-def test_bench_gpus_2_starts_its_ranks_and_fails_in_them_without_a_gpu(how):
+@pytest.mark.parametrize("how,streamed", [("plain", False), ("torchrun", False), ("plain", True)])
+def test_bench_gpus_2_starts_its_ranks_and_fails_in_them_without_a_gpu(how, streamed):
     """`python bench.py --gpus 2` invoked the way `--gpus 1` is must reach gpca_create in two ranks of its own (here:
     GPCA_ERR_NO_DEVICE from each, non-zero exit), and the same under torch.distributed.run -- where torch only starts the processes."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
+    if streamed:                     # (configs[4]'s form at N > 1 takes the same road)
+        cmd += ["--streamed", "--snps", "100000", "--samples", "2000", "--storage", "2bit"]
     if how == "torchrun":
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(29100 + os.getpid() % 800)] + cmd[1:]
