@@ -29,7 +29,7 @@
 // more flops and keeps four to sixteen waves busy: 117 us at n = 30 (203 steps of ~1 200 cycles: the rotation chain ~550, the LDS
 // exchange and its barrier the rest), 0.8 ms at n = 64; at n = 128 the exchange is LDS-bandwidth bound (6.3 ms), and sketches of
 // 65-128 columns go through k_small_eigh_ql below: QL again, but with its serial chain on one wave and the eigenvector updates on
-// two others (4.0 ms).
+// two others (3.6 ms).
 #include "kernels.h"
 
 #ifndef GPCA_EIG_ABL
@@ -337,9 +337,9 @@ __global__ __launch_bounds__(JacCfg<L>::NT) void k_small_eigh(const double* __re
 // ================================================================================================
 // Sketches of 65 .. 128 columns: Householder tridiagonalisation + implicit QL (the pair the host pin runs), arranged for one workgroup.
 // The Jacobi form above moves the whole matrix through LDS every step: 0.57 / 0.79 ms at n = 50 / 64, 5.0 / 6.3 ms at n = 100 / 128
-// (LDS-bandwidth bound).  This form: 0.62 / 0.95 ms at n = 50 / 64 (so Jacobi keeps L = 64), **2.45 / 4.0 ms at n = 100 / 128**
+// (LDS-bandwidth bound).  This form: 0.62 / 0.95 ms at n = 50 / 64 (so Jacobi keeps L = 64), **2.2 / 3.6 ms at n = 100 / 128**
 // (scripts/kbench/kbench_eig.hip, profiles/r5_kbench_summary.md section 1): 0.34 / 0.53 ms of tridiagonalisation + Q, the rest the
-// serial chain at ~460 cycles per rotation (10 753 / 18 074 rotations).
+// serial chain at ~407 cycles per rotation (10 753 / 18 074 rotations).
 //   * tridiagonalisation and the accumulation of Q: n - 2 reflectors, each a matrix-vector product and a rank-2 (rank-1) update
 //     spread over all 1 024 threads, four (three) barriers per reflector; the matrix sits in LDS with row r rotated by r places
 //     (ql_at), so rows and columns are both conflict-free without padding (128 x 128 doubles = 128 KiB of the 160);
@@ -402,16 +402,15 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
     //  form of this kernel spent 1 400 cycles per rotation that way)
     typedef __attribute__((address_space(3))) double lds_d;
     typedef __attribute__((address_space(3))) int lds_i;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2d lds_d2;
     lds_d* A = (lds_d*)eig_sm;                                 // [L x L], element (r, c) at ql_at(r, c); becomes Q, then Z
-    volatile lds_d* dd = A + L * L;                            // diagonal / eigenvalues
-    volatile lds_d* ee = dd + L;                               // ee[i] couples i and i + 1
+    lds_d* de = A + L * L;                                     // d[i] = de[2 i] (diagonal / eigenvalues), e[i] = de[2 i + 1] (couples i and i + 1): one 16-byte access for the pair
     lds_d* vv = A + L * L + 2 * L;                             // the reflector of the step
     lds_d* pp = vv + L;
     lds_d* ww = pp + L;
     lds_d* bb = ww + L;                                        // beta of reflector k
     lds_d* red = bb + L;                                       // [64] reduction scratch
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) v2d lds_d2;
     volatile lds_d2* ringcs = (volatile lds_d2*)(red + 64);    // (c, s) of a rotation
     volatile lds_i* ringi = (volatile lds_i*)(red + 64 + 2 * RING);
     volatile lds_i* ctrl = ringi + RING;
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
             }
             if (lane < m) vv[lane] = lane == 0 ? x0 - alpha : x0;
             if (t1 < m) vv[t1] = x1;
-            if (lane == 0) { dd[kk] = A[ql_at<L>(kk, kk)]; ee[kk] = alpha; bb[kk] = beta; }
+            if (lane == 0) { de[2 * kk] = A[ql_at<L>(kk, kk)]; de[2 * kk + 1] = alpha; bb[kk] = beta; }
         }
         __syncthreads();
         const double beta = bb[kk];
@@ -523,8 +522,8 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
         __syncthreads();
     }
     if (tid == 0) {
-        if (n >= 2) { dd[n - 2] = A[ql_at<L>(n - 2, n - 2)]; ee[n - 2] = A[ql_at<L>(n - 1, n - 2)]; }
-        dd[n - 1] = A[ql_at<L>(n - 1, n - 1)]; ee[n - 1] = 0.0;
+        if (n >= 2) { de[2 * (n - 2)] = A[ql_at<L>(n - 2, n - 2)]; de[2 * (n - 2) + 1] = A[ql_at<L>(n - 1, n - 2)]; }
+        de[2 * (n - 1)] = A[ql_at<L>(n - 1, n - 1)]; de[2 * (n - 1) + 1] = 0.0;
     }
     __syncthreads();
     // ---- Q = H_0 H_1 ... in place, from the last reflector back: the trailing block holds the product so far ----
@@ -574,18 +573,18 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
         // checked once per sweep (a sweep is at most n - 1 < RING rotations); four stores of lane 0 per rotation -- the entry's tag
         // carries its sequence number, there is no separate head to publish.
         const double eps = 2.220446049250313e-16;
-        lds_d* dp = (lds_d*)dd; lds_d* ep = (lds_d*)ee;          // (this wave is the only one that touches d and e from here on)
+        lds_d2* dep = (lds_d2*)de;                               // (this wave is the only one that touches d and e from here on)
         const int nu = __builtin_amdgcn_readfirstlane(n);
         double f = 0.0, tst1 = 1e-20;
         int head = 0, tail_seen = 0, iters_all = 0; long long full_spins = 0;
         bool gave_up = false;
         for (int l = 0; l < nu && !gave_up; ++l) {
-            tst1 = fmax(tst1, fabs(dp[l]) + fabs(ep[l]));
+            { const v2d x_ = dep[l]; tst1 = fmax(tst1, fabs(x_.x) + fabs(x_.y)); }
             auto first_small = [&]() -> int {                  // smallest m >= l with |e[m]| <= eps tst1 (e[n - 1] = 0 ends the search)
                 int mine = nu - 1;
                 const int i0 = l + lane, i1 = i0 + 64;
-                if (i1 < nu && !(fabs(ep[i1]) > eps * tst1)) mine = i1;
-                if (i0 < nu && !(fabs(ep[i0]) > eps * tst1)) mine = i0;
+                if (i1 < nu && !(fabs(de[2 * i1 + 1]) > eps * tst1)) mine = i1;
+                if (i0 < nu && !(fabs(de[2 * i0 + 1]) > eps * tst1)) mine = i0;
                 for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(mine, o); mine = other < mine ? other : mine; }
                 return __builtin_amdgcn_readfirstlane(mine);
             };
@@ -609,24 +608,27 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                         }
                         if (gave_up) break;
                     }
-                    double g = dp[l];
-                    const double el = ep[l];
-                    double p = (dp[l + 1] - g) / (2.0 * el);
+                    const v2d x0_ = dep[l];
+                    double g = x0_.x;
+                    const double el = x0_.y;
+                    double p = (de[2 * (l + 1)] - g) / (2.0 * el);
                     double r = sqrt(fma(p, p, 1.0));
                     if (p < 0.0) r = -r;
                     const double dl = el / (p + r), dl1 = el * (p + r);
                     double h = g - dl;
                     __builtin_amdgcn_wave_barrier();
-                    for (int i = l + lane; i < nu; i += 64) { const double x = dp[i]; dp[i] = i == l ? dl : (i == l + 1 ? dl1 : x - h); }
+                    for (int i = l + lane; i < nu; i += 64) { const double x = de[2 * i]; de[2 * i] = i == l ? dl : (i == l + 1 ? dl1 : x - h); }
                     __builtin_amdgcn_wave_barrier();
                     f += h;
-                    p = dp[m];
+                    p = de[2 * m];
                     double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
-                    const double el1 = ep[l + 1];
-                    double e_i = ep[m - 1], d_i = dp[m - 1];
+                    const double el1 = de[2 * (l + 1) + 1];
+                    double e_i, d_i;
+                    { const v2d x_ = dep[m - 1]; d_i = x_.x; e_i = x_.y; }
                     for (int i = m - 1; i >= l; --i) {
                         const int ip = i > l ? i - 1 : i;
-                        const double e_nx = ep[ip], d_nx = dp[ip];               // one rotation ahead
+                        const v2d nx_ = dep[ip];                                  // one rotation ahead
+                        const double e_nx = nx_.y, d_nx = nx_.x;
                         c3 = c2; c2 = c; s2 = s;
                         g = c * e_i; h = c * p;
                         const double q2 = fma(p, p, e_i * e_i);
@@ -637,16 +639,16 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                         p = fma(c, d_i, -(s * g));
                         if (lane == 0) {
                             const int slot = head & (RING - 1);
-                            ep[i + 1] = s_old * r; dp[i + 1] = fma(s, fma(c, g, s * d_i), h);
+                            dep[i + 1] = v2d{fma(s, fma(c, g, s * d_i), h), s_old * r};
                             ringcs[slot] = v2d{c, s};
                             ringi[slot] = i | (i == m - 1 ? kQlFirst : 0) | (i == l ? kQlLast : 0) | ql_tag(head);
                         }
                         ++head;
                         e_i = e_nx; d_i = d_nx;
                     }
-                    p = -s * s2 * c3 * el1 * ep[l] / dl1;
+                    p = -s * s2 * c3 * el1 * de[2 * l + 1] / dl1;
                     __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) { ep[l] = s * p; dp[l] = c * p; }
+                    if (lane == 0) dep[l] = v2d{c * p, s * p};
                     __builtin_amdgcn_wave_barrier();
                     more = fabs(s * p) > eps * tst1;
                     if (more && iter >= 60) { capped = 1; more = false; }
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) { dp[l] = dp[l] + f; ep[l] = 0.0; }
+            if (lane == 0) dep[l] = v2d{de[2 * l] + f, 0.0};
             __builtin_amdgcn_wave_barrier();
         }
         if (gave_up) capped = 1;
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(QlCfg<L>::NT) void k_small_eigh_ql(const double* __
     __syncthreads();
     capped = ctrl[kQlGaveUp];
     EIG_STAMP(3)
-    if (tid < 128) wsl[tid] = tid < n ? dd[tid] : 0.0;
+    if (tid < 128) wsl[tid] = tid < n ? de[2 * tid] : 0.0;
     __syncthreads();
     eig_emit<NT>([&](int r, int slot) { return A[ql_at<L>(r, slot)]; }, wsl, order, genuine, L, n, Lw, k, zmode, denom, unsc, cholflag, capped, Z, res, Vout, tid);
 }
